@@ -1,0 +1,52 @@
+"""TEST INFRASTRUCTURE - the shared table of golden cases (inputs are re-generated from these
+parameters by pcg_mi355x.brick; outputs live in tests/golden/<name>.npz, written by
+oracle/make_golden.py from the *reference's own functions*)."""
+from __future__ import annotations
+
+import numpy as np
+
+# name: dict(N, grid, n_types, tol, max_iter, ud (prescribed z-displacement on the fixed face), x0)
+CASES = {
+    "n9_p1":        dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0),
+    "n9_p2":        dict(N=9,  grid=(1, 1, 2), n_types=1, tol=1e-7, max_iter=10000, ud=0.0),
+    "n9_p8":        dict(N=9,  grid=(2, 2, 2), n_types=1, tol=1e-7, max_iter=10000, ud=0.0),
+    "n13_t3_p4_ud": dict(N=13, grid=(2, 2, 1), n_types=3, tol=1e-7, max_iter=10000, ud=0.01),
+    "n17_p1":       dict(N=17, grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0),
+    "n17_t2_p8":    dict(N=17, grid=(2, 2, 2), n_types=2, tol=1e-7, max_iter=10000, ud=0.0),
+    # failure / edge paths
+    "n9_maxiter":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=30,    ud=0.0),      # Flag 1 -> min-residual iterate
+    "n9_p2_maxiter": dict(N=9, grid=(1, 1, 2), n_types=1, tol=1e-7, max_iter=40,    ud=0.0),
+    "n9_stagnate":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-15, max_iter=1500, ud=0.0),      # Flag 3 via :560-562
+    "n9_raise":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-15, max_iter=10000, ud=0.0),     # MaxMSteps<0 -> raise Warning (:549)
+    "n9_p2_raise":  dict(N=9,  grid=(1, 1, 2), n_types=1, tol=1e-15, max_iter=10000, ud=0.0),
+    "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
+    "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
+}
+
+
+def build_case(name, golden_dir=None):
+    """Re-create the RefMeshPart dicts of a case (before updateBC)."""
+    import os
+    from pcg_mi355x.brick import Brick, make_parts, block_partition
+    c = CASES[name]
+    b = Brick(c["N"], seed=0, n_types=c["n_types"])
+    parts = make_parts(b, block_partition(b, *c["grid"]), tol=c["tol"], max_iter=c["max_iter"])
+    for p in parts:
+        if c.get("ud", 0.0) != 0.0:
+            fixed = p["LocFixedDof"]
+            ud = np.zeros(p["NDOF"])
+            zf = fixed[fixed % 3 == 2]
+            ud[zf] = c["ud"] * (1.0 + 0.25 * np.sin(p["DofVector"][zf].astype(float)))
+            p["Ud"] = ud
+        if c.get("zero_rhs"):
+            p["RefLoadVector"] = np.zeros(p["NDOF"])
+        if c.get("good_x0"):
+            gdir = golden_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+            g = np.load(os.path.join(gdir, c["good_x0"] + ".npz"))
+            p["Un"] = g["Un"][p["DofVector"]].copy()
+    return b, parts
+
+
+def probe_vector(brick, seed=7):
+    """Seeded global vector used for the mat-vec probe of every case."""
+    return np.random.default_rng(seed).standard_normal(brick.n_dof)
