@@ -1,0 +1,156 @@
+/* pcg_mi355x.h - C ABI of the MI355X-native PCG iteration engine (libpcg_mi355x.so).
+ *
+ * Drop-in boundary for the hot path of ankitskr/PCG-MPI-solver.  The reference has no native
+ * layer and no FFI: its hot path is the Python functions in src/solver/pcg_solver.py that the
+ * load-step loop (:1002-1008) calls.  Each entry point below replaces one of them; the binding a
+ * reference maintainer adds is the ctypes stub shown in INTEGRATION.md (it is what
+ * pcg_mi355x/_lib.py contains).
+ *
+ *   reference function (src/solver/pcg_solver.py)         C ABI
+ *   ----------------------------------------------------  ------------------------------------
+ *   calcMatVecProd(..,'Strain', x)        :242-336        pcg_apply()          (+ halo hooks)
+ *   calcMatVecProd(..,'Preconditioner')   :282-287        pcg_diag()
+ *   updatePreconditioner                  :346-352        pcg_build_jacobi()
+ *   updateBC                              :226-238        pcg_update_bc()
+ *   PCG(RefMeshPart)                      :356-598        pcg_solve_begin/_run/_end, pcg_solve()
+ *   MPI_SUM                               :622-628        pcg_comm_hooks.allreduce
+ *   Isend/Recv/Waitall interface sums     :318-334        pcg_comm_hooks.halo_begin/halo_end
+ *   np.dot(a, b*w)                        :381,415,462..  pcg_dot_w()
+ *   element tables -> operator            (partition_mesh.py:443-491,576-581 data contract)
+ *                                                          pcg_asm_*()
+ *
+ * Conventions: every function returns int (0 = OK, <0 = engine error; text via
+ * pcg_last_error()).  Solver outcome flags 0-4 keep the reference's meaning and are DATA
+ * (pcg_result.flag), never error codes.  The caller owns every host buffer before and after a
+ * call; the engine owns all device memory.  A handle is not thread-safe; one handle per GPU.
+ * All floating data is IEEE f64; vectors passed to the engine have the part's full local length
+ * n = 3 * n_nodes in the ENGINE's node numbering (the Python shim applies the boundary-first
+ * permutation).  There is no CPU fallback: without a usable gfx950 device pcg_create() fails.
+ */
+#ifndef PCG_MI355X_H
+#define PCG_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcg_engine pcg_engine;
+typedef struct pcg_asm pcg_asm;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *pcg_last_error(void);
+const char *pcg_backend_name(void);          /* "hip-gfx950" for the product library */
+int pcg_device_count(void);
+
+/* ---- host-side operator assembly ------------------------------------------------------------
+ * One pattern-type group of the reference's SubDomainData['StrucDataList'][j]
+ * (partition_mesh.py:470-489,577-578): ElemList_LocDofVector (nd,Ne) element-minor int64,
+ * ElemList_SignVector (nd,Ne) bool, ElemList_Ck (Ne), ElemStiffMat (nd,nd).
+ * Local DOF d belongs to node d/3, direction d%3 (partition_mesh.py:826). */
+typedef struct {
+    int32_t nd;
+    int64_t ne;
+    const int64_t *dof;
+    const uint8_t *sign;
+    const double *ck;
+    const double *ke;
+} pcg_elem_group;
+
+/* A = sum_e P_e^T S_e (Ck_e Ke_type(e)) S_e P_e  as 3x3-block CSR over nodes, summed per entry
+ * in ascending (group, element, local row, local col) order (deterministic).
+ * node_perm: new index of each old node (NULL = identity). */
+int pcg_asm_create(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
+                   const int64_t *node_perm, int32_t n_threads, pcg_asm **out);
+int64_t pcg_asm_nnzb(const pcg_asm *a);
+int pcg_asm_rowptr(const pcg_asm *a, int64_t *rowptr /* n_nodes+1 */);
+int pcg_asm_fill(const pcg_asm *a, int32_t *cols /* nnzb */, double *vals /* nnzb*9, row-major 3x3 */);
+void pcg_asm_destroy(pcg_asm *a);
+
+/* ---- engine ---------------------------------------------------------------------------------
+ * n_boundary_nodes: nodes [0, n_boundary_nodes) are shared with another part (their rows are
+ * computed first so the interface exchange overlaps the interior rows); 0 for a single part.
+ * rows_per_lane: SELL slice = 64*rows_per_lane block rows (1 or 2; 0 = library default). */
+int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols,
+               const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
+void pcg_destroy(pcg_engine *e);
+
+/* flags[d]: bit0 = this part owns dof d (DofWeightVector == 1, partition_mesh.py:870-887),
+ *           bit1 = dof d is free (in LocDofEff, partition_mesh.py:350-351). */
+int pcg_set_masks(pcg_engine *e, const uint8_t *flags /* n */);
+
+/* Interface lists (OvrlpLocalDofVecList / NbrMPIdVector, partition_mesh.py:817-830), in the
+ * reference's neighbour order; recv layout mirrors send layout. */
+int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const int64_t *send_ptr /* n_peers+1 */,
+                 const int32_t *send_idx /* send_ptr[n_peers] local dofs */);
+
+/* Communication hooks (one process per GPU; the Python shim implements them with
+ * torch.distributed = RCCL over xGMI).  All buffers are DEVICE pointers, `stream` is the
+ * engine's hipStream_t.  halo_begin is called once the send buffer has been packed on `stream`;
+ * halo_end must make `stream` wait until the receive buffer is complete.  allreduce sums
+ * `count` doubles in place across ranks.  NULL hooks = single part. */
+typedef struct {
+    void *ctx;
+    int (*halo_begin)(void *ctx, double *dev_send, double *dev_recv, int64_t count, void *stream);
+    int (*halo_end)(void *ctx, void *stream);
+    int (*allreduce)(void *ctx, double *dev_buf, int32_t count, void *stream);
+} pcg_comm_hooks;
+int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks);
+void *pcg_stream(pcg_engine *e);
+
+/* ---- operator-level calls (host vectors, length n) ----------------------------------------- */
+int pcg_apply(pcg_engine *e, const double *x, double *y);            /* y = A x, interface-summed */
+int pcg_diag(pcg_engine *e, double *d);                              /* diag(A), interface-summed */
+int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out /* n, 0 on fixed dofs; may be NULL */);
+int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, double delta,
+                  double *fext_out, double *udi_out);                /* Fext = F*d - A*(Ud*d) */
+int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out);   /* global sum a*b*w */
+
+/* ---- PCG ------------------------------------------------------------------------------------ */
+enum { PCG_STATUS_NORMAL = 0, PCG_STATUS_ZERO_RHS = 1, PCG_STATUS_GOOD_X0 = 2,
+       PCG_STATUS_TOO_SMALL_TOL = 3, PCG_STATUS_RUNNING = 4 };
+
+typedef struct {
+    int32_t flag;          /* 0 converged, 1 MaxIter, 2 inf in M^-1 r, 3 stagnation, 4 breakdown  */
+    int32_t status;        /* PCG_STATUS_*; TOO_SMALL_TOL = the reference's raise Warning (:549)  */
+    int64_t iter;          /* as the reference stores it (loop index + 1, :584)                   */
+    int64_t iters_done;    /* loop iterations executed so far                                      */
+    int64_t n_matvec;
+    double relres;
+    double norm_b;         /* sqrt(sum Fext^2 w)                                                   */
+    double normr_act;
+    double t_total_s, t_comm_s;            /* host wall split (dT_Calc = total - comm), :631-641  */
+    double spmv_ms_sum;    /* HIP-event time of the SpMV launches when profiling is on            */
+    int64_t spmv_count;
+} pcg_result;
+
+/* inv_diag may be NULL: use the Jacobi vector built by pcg_build_jacobi().
+ * hist (may be NULL): rows [NormP, NormX, NormR] per iteration (the :507 allreduce). */
+int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const double *inv_diag,
+                    double tol, int64_t max_iter, int64_t glob_n_eff);
+int pcg_solve_run(pcg_engine *e, int64_t n_iters /* <0 = to completion */, double *hist, int64_t hist_cap,
+                  pcg_result *res);
+int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res);
+int pcg_solve(pcg_engine *e, const double *b, const double *x0, const double *inv_diag, double tol,
+              int64_t max_iter, int64_t glob_n_eff, double *x_out, double *hist, int64_t hist_cap,
+              pcg_result *res);
+int pcg_set_profiling(pcg_engine *e, int32_t on);
+
+/* ---- measurement / unit-test entry points --------------------------------------------------- */
+/* Back-to-back local SpMV launches timed with HIP events on the engine stream. */
+int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
+int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
+/* single fused kernels on host vectors, for per-kernel parity tests */
+int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first);
+int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r,
+                       const double *x_old, double *x_new, const double *inv_diag,
+                       double *sums5 /* sqP, sqX, sqR, rho_next, n_inf */);
+int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, const double *inv_diag,
+                   double *sums3 /* sqR, rho, n_inf */);
+int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy /* sum x*y*w or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,658 @@
+// PCG control flow + operator-apply orchestration + the extern "C" surface.
+//
+// This file is back-end agnostic C++: every numeric operation is a Backend call (hand-written HIP
+// kernels in the product library).  The control flow restates PCG(RefMeshPart) of the reference
+// (/root/reference/src/solver/pcg_solver.py:356-598) branch by branch; line numbers in the
+// comments refer to that file.  Differences in *mechanism*, not in arithmetic:
+//   * vectors keep the part's full local length n; fixed dofs are masked (w=0, M^-1=0) instead of
+//     restricted through LocDofEff (:377-378,:482-484) - the extra terms are exact zeros;
+//   * z = M^-1 r, rho = z.r.w and the inf test of the NEXT iteration (:447-463) are produced by
+//     the same kernel that updates r (or recomputes the true residual), so an iteration is three
+//     vector-length kernels (update_p, SpMV+dot, fused_update) and two all-reduces (pq; 5 values);
+//   * the alpha/flag-4 tests on pq (:492-498) run on the device and freeze the update kernel, the
+//     host sees them in the one status read-back per iteration;
+//   * XMin (:555-558) is tracked by rotating three x buffers instead of copying.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include "pcg_internal.hpp"
+
+using namespace pcg;
+
+namespace {
+
+double now_s()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+const double kEps = std::numeric_limits<double>::epsilon();   // np.finfo(float).eps (:972)
+
+}  // namespace
+
+struct pcg_engine {
+    std::unique_ptr<Backend> be;
+    int64_t n_nodes = 0, n = 0, n_slices = 0, n_bnd_slices = 0;
+    int32_t C = 64;
+    int64_t nnzb = 0, stored_blocks = 0;
+    HaloHost halo;
+    bool has_halo = false;
+    bool has_masks = false;
+    pcg_comm_hooks hooks{};
+    bool has_hooks = false;
+    bool jacobi_built = false;
+    bool profiling = false;
+
+    double *d_send = nullptr, *d_recv = nullptr, *d_st = nullptr;
+    double *v_b = nullptr, *v_r = nullptr, *v_p = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
+    double *v_x[3] = {nullptr, nullptr, nullptr};
+    double *scr[4] = {nullptr, nullptr, nullptr, nullptr};
+    double h_st[ST_COUNT];
+
+    double t_comm = 0.0;
+
+    // ---- solve state (:399-418) ------------------------------------------------------------------
+    struct Solve {
+        bool active = false, done = false;
+        int32_t flag = 1, status = PCG_STATUS_RUNNING;
+        double tol = 0, n2b = 0, tolb = 0;
+        int64_t max_iter = 0, max_msteps = 0;
+        int64_t i = 0;            // next loop index
+        int64_t last_i = -1;      // loop index of the last executed/broken iteration
+        int64_t iter = 0, i_min = 0, n_matvec = 0;
+        double rho = 1.0, rho_next = 0.0, ninf_next = 0.0;
+        int stag = 0;
+        int64_t more = 0;
+        double normr_min = 0, normr_act = 0, relres = 0;
+        int cur = 0, min_idx = 0;
+        bool min_live = true;
+        const double *minv = nullptr;
+        double t_total = 0.0, t_comm0 = 0.0;
+    } s;
+
+    ~pcg_engine()
+    {
+        if (!be) return;
+        for (double *p : {d_send, d_recv, d_st, v_b, v_r, v_p, v_q, v_minv, v_minv_user, v_x[0], v_x[1], v_x[2],
+                          scr[0], scr[1], scr[2], scr[3]})
+            if (p) be->release(p);
+    }
+
+    double *vec() { return (double *)be->alloc(sizeof(double) * (size_t)n); }
+    double *scratch(int k)
+    {
+        if (!scr[k]) scr[k] = vec();
+        return scr[k];
+    }
+
+    // ---- communication -----------------------------------------------------------------------------
+    void allreduce(double *dev, int count)
+    {
+        if (!has_hooks || !hooks.allreduce) return;
+        double t0 = now_s();
+        if (hooks.allreduce(hooks.ctx, dev, count, be->stream()) != 0) throw std::runtime_error("allreduce hook failed");
+        t_comm += now_s() - t0;
+    }
+    void halo_begin()
+    {
+        if (!has_hooks || !hooks.halo_begin) throw std::runtime_error("part has neighbours but no halo hook is set");
+        double t0 = now_s();
+        if (hooks.halo_begin(hooks.ctx, d_send, d_recv, (int64_t)halo.send_idx.size(), be->stream()) != 0)
+            throw std::runtime_error("halo_begin hook failed");
+        t_comm += now_s() - t0;
+    }
+    void halo_end()
+    {
+        double t0 = now_s();
+        if (hooks.halo_end(hooks.ctx, be->stream()) != 0) throw std::runtime_error("halo_end hook failed");
+        t_comm += now_s() - t0;
+    }
+
+    // y = A x with the interface sum (:242-336).  Interface rows first, exchange overlapped with
+    // the interior rows, then the neighbour contributions are added in neighbour order (:333-334).
+    void apply(const double *x, double *y, bool with_dot)
+    {
+        if (with_dot) be->begin_dot();
+        if (!has_halo) {
+            be->spmv(x, y, 0, n_slices, with_dot);
+        } else {
+            be->spmv(x, y, 0, n_bnd_slices, false);
+            be->halo_pack(y, d_send);                         // :307-309
+            halo_begin();                                     // :318-326
+            be->spmv(x, y, n_bnd_slices, n_slices, with_dot);
+            halo_end();                                       // :328
+            be->boundary_fixup(y, d_recv, x, with_dot);       // :332-334 (+ dot over the interface slices)
+        }
+    }
+    void halo_sum(double *y)
+    {
+        if (!has_halo) return;
+        be->halo_pack(y, d_send);
+        halo_begin();
+        halo_end();
+        be->boundary_fixup(y, d_recv, nullptr, false);
+    }
+    void read_status() { be->d2h(h_st, d_st, sizeof(double) * ST_COUNT); }
+
+    // r = b - A x, then [sum r^2 w, rho_next, ninf] -> h_st[SQR..NINF]   (:412-416, :528-533, :569-574)
+    void true_residual(const double *x)
+    {
+        apply(x, v_q, false);
+        s.n_matvec++;
+        be->residual(v_b, v_q, v_r, s.minv);
+        be->reduce_residual(d_st + ST_SQR);
+        allreduce(d_st + ST_SQR, 3);
+        read_status();
+    }
+
+    int pick_new_x() const
+    {
+        for (int k = 0; k < 3; ++k)
+            if (k != s.cur && (s.min_live || k != s.min_idx)) return k;
+        return -1;
+    }
+};
+
+namespace {
+
+void ensure_solver_buffers(pcg_engine *e)
+{
+    if (e->v_b) return;
+    e->v_b = e->vec(); e->v_r = e->vec(); e->v_p = e->vec(); e->v_q = e->vec();
+    for (int k = 0; k < 3; ++k) e->v_x[k] = e->vec();
+}
+
+// One pass of the reference's `for i in range(MaxIter)` body (:438-562).  Returns true when the
+// loop is finished (break or exhausted).
+bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
+{
+    auto &s = e->s;
+    Backend &be = *e->be;
+    if (s.i >= s.max_iter) return true;                       // loop exhausted, Flag stays 1
+    const int64_t i = s.i;
+    s.last_i = i;
+    if (s.ninf_next > 0) { s.flag = 2; return true; }          // :447-450
+    const double rho_1 = s.rho;                                // :461
+    s.rho = s.rho_next;                                        // :462-463 (computed with the residual)
+    if (s.rho == 0 || std::isinf(s.rho)) { s.flag = 4; return true; }     // :467-469
+    double beta = 0.0;
+    if (i > 0) {                                               // :472-479
+        beta = s.rho / rho_1;
+        if (beta == 0 || std::isinf(beta)) { s.flag = 4; return true; }
+    }
+    be.update_p(e->v_p, e->v_r, s.minv, beta, i == 0);
+    e->apply(e->v_p, e->v_q, true);                            // :482-484
+    s.n_matvec++;
+    be.reduce_dot(e->d_st + ST_PQ);                            // :487
+    e->allreduce(e->d_st + ST_PQ, 1);                          // :488
+    be.scalar_alpha(e->d_st, s.rho);                           // :492-498 (device side)
+    const int nx = e->pick_new_x();
+    be.fused_update(e->d_st, e->v_p, e->v_q, e->v_r, e->v_x[s.cur], e->v_x[nx], s.minv);   // :501-516 (+ :447-462 of i+1)
+    be.reduce_update(e->d_st + ST_SQP);
+    e->allreduce(e->d_st + ST_SQP, 5);                         // :507 (+ next rho, inf count)
+    e->read_status();
+    const double *st = e->h_st;
+    if (st[ST_STOP] != 0) { s.flag = 4; return true; }         // pq<=0 / inf / alpha inf: nothing was updated
+    const double alpha = st[ST_ALPHA];
+    const double normp = std::sqrt(st[ST_SQP]), normx = std::sqrt(st[ST_SQX]);
+    double normr = std::sqrt(st[ST_SQR]);
+    s.rho_next = st[ST_RHO_NEXT];
+    s.ninf_next = st[ST_NINF];
+    if (hist && i < hist_cap) { hist[3 * i] = normp; hist[3 * i + 1] = normx; hist[3 * i + 2] = normr; }
+    if (normp * std::fabs(alpha) < kEps * normx) s.stag += 1;  // :512-513
+    else s.stag = 0;
+    s.cur = nx;                                                // :516
+    s.normr_act = normr;                                       // :518
+    s.i = i + 1;
+    if (normr <= s.tolb || s.stag >= 3 || s.more > 0) {        // :527
+        e->true_residual(e->v_x[s.cur]);                       // :528-533 (R is REPLACED, :531)
+        s.normr_act = std::sqrt(e->h_st[ST_SQR]);
+        s.rho_next = e->h_st[ST_RHO_NEXT];
+        s.ninf_next = e->h_st[ST_NINF];
+        if (s.normr_act <= s.tolb) {                           // :540-543
+            s.flag = 0;
+            s.iter = i;
+            return true;
+        }
+        if (s.stag >= 3 && s.more == 0) s.stag = 0;            // :545
+        s.more += 1;                                           // :546
+        if (s.more >= s.max_msteps) {                          // :548-549  raise Warning('PCG : TooSmallTolerance')
+            s.status = PCG_STATUS_TOO_SMALL_TOL;
+            s.flag = 3;
+            s.iter = i;
+            return true;
+        }
+    }
+    if (s.normr_act < s.normr_min) {                           // :555-558
+        s.normr_min = s.normr_act;
+        s.min_idx = s.cur;
+        s.min_live = false;
+        s.i_min = i;
+    }
+    if (s.stag >= 3) { s.flag = 3; return true; }              // :560-562
+    return false;
+}
+
+void fill_result(pcg_engine *e, pcg_result *res)
+{
+    if (!res) return;
+    auto &s = e->s;
+    std::memset(res, 0, sizeof(*res));
+    res->flag = s.flag;
+    res->status = s.status;
+    res->iter = s.iter;
+    res->iters_done = s.last_i + 1;
+    res->n_matvec = s.n_matvec;
+    res->relres = s.relres;
+    res->norm_b = s.n2b;
+    res->normr_act = s.normr_act;
+    res->t_total_s = s.t_total;
+    res->t_comm_s = e->t_comm - s.t_comm0;
+    double ms = 0;
+    int64_t cnt = 0;
+    if (e->profiling) e->be->collect_profile(&ms, &cnt);
+    res->spmv_ms_sum = ms;
+    res->spmv_count = cnt;
+}
+
+template <class F>
+int guarded(const char *where, F f)
+{
+    try {
+        return f();
+    } catch (const std::exception &ex) {
+        return set_error(std::string(where) + ": " + ex.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pcg_last_error(void) { return last_error_string().c_str(); }
+const char *pcg_backend_name(void) { return backend_static_name(); }
+int pcg_device_count(void) { return backend_device_count(); }
+
+int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
+               int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out)
+{
+    return guarded("pcg_create", [&]() -> int {
+        if (!out || !rowptr || !cols || !vals || n_nodes <= 0) return set_error("pcg_create: bad argument");
+        if (n_boundary_nodes < 0 || n_boundary_nodes > n_nodes) return set_error("pcg_create: bad n_boundary_nodes");
+        auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
+        e->be = make_backend(device);                       // throws when no usable device: no fallback
+        SellHost m;
+        bsr_to_sell(n_nodes, rowptr, cols, vals, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
+        e->n_nodes = n_nodes;
+        e->n = 3 * n_nodes;
+        e->n_slices = m.n_slices;
+        e->n_bnd_slices = m.n_bnd_slices;
+        e->C = m.C;
+        e->nnzb = m.nnzb;
+        e->stored_blocks = m.slice_ptr.back() * m.C;
+        e->be->upload_matrix(m);
+        e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
+        e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+        e->v_minv = e->vec();
+        // default masks: every dof owned and free
+        std::vector<uint8_t> f((size_t)e->n, 3);
+        e->be->upload_masks(f.data(), e->n);
+        *out = e.release();
+        return 0;
+    });
+}
+
+void pcg_destroy(pcg_engine *e) { delete e; }
+
+int pcg_set_masks(pcg_engine *e, const uint8_t *flags)
+{
+    return guarded("pcg_set_masks", [&]() -> int {
+        if (!e || !flags) return set_error("pcg_set_masks: null");
+        e->be->upload_masks(flags, e->n);
+        e->has_masks = true;
+        return 0;
+    });
+}
+
+int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const int64_t *send_ptr, const int32_t *send_idx)
+{
+    return guarded("pcg_set_halo", [&]() -> int {
+        if (!e || n_peers < 0) return set_error("pcg_set_halo: bad argument");
+        HaloHost &h = e->halo;
+        h = HaloHost();
+        h.n_peers = n_peers;
+        if (n_peers == 0) { e->has_halo = false; return 0; }
+        h.peer_ids.assign(peer_ids, peer_ids + n_peers);
+        h.send_ptr.assign(send_ptr, send_ptr + n_peers + 1);
+        const int64_t tot = send_ptr[n_peers];
+        h.send_idx.assign(send_idx, send_idx + tot);
+        const int64_t n_bnd_dofs = std::min<int64_t>(e->n, e->n_bnd_slices * e->C * 3);
+        // per interface dof: receive slots in neighbour order (the order of the reference's `+=`, :333-334)
+        std::vector<int64_t> cnt((size_t)n_bnd_dofs + 1, 0);
+        for (int64_t m = 0; m < tot; ++m) {
+            if (send_idx[m] < 0 || send_idx[m] >= n_bnd_dofs)
+                return set_error("pcg_set_halo: interface dof outside the boundary rows (numbering must be boundary-first)");
+            cnt[send_idx[m] + 1]++;
+        }
+        for (int64_t d = 0; d < n_bnd_dofs; ++d) cnt[d + 1] += cnt[d];
+        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+        std::vector<int32_t> pos((size_t)tot);
+        for (int64_t m = 0; m < tot; ++m) pos[cur[send_idx[m]]++] = (int32_t)m;     // ascending m = neighbour order
+        for (int64_t d = 0; d < n_bnd_dofs; ++d) {
+            if (cnt[d + 1] == cnt[d]) continue;
+            h.fix_dof.push_back((int32_t)d);
+            h.fix_ptr.push_back(cnt[d]);
+        }
+        h.fix_ptr.push_back(tot);
+        h.fix_pos = pos;
+        e->be->upload_halo(h);
+        if (e->d_send) e->be->release(e->d_send);
+        if (e->d_recv) e->be->release(e->d_recv);
+        e->d_send = (double *)e->be->alloc(sizeof(double) * (size_t)tot);
+        e->d_recv = (double *)e->be->alloc(sizeof(double) * (size_t)tot);
+        e->has_halo = true;
+        return 0;
+    });
+}
+
+int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks)
+{
+    if (!e) return set_error("pcg_set_comm: null");
+    if (hooks) { e->hooks = *hooks; e->has_hooks = true; }
+    else { e->hooks = pcg_comm_hooks{}; e->has_hooks = false; }
+    return 0;
+}
+
+void *pcg_stream(pcg_engine *e) { return e ? e->be->stream() : nullptr; }
+
+int pcg_apply(pcg_engine *e, const double *x, double *y)
+{
+    return guarded("pcg_apply", [&]() -> int {
+        double *dx = e->scratch(0), *dy = e->scratch(1);
+        e->be->h2d(dx, x, sizeof(double) * e->n);
+        e->apply(dx, dy, false);
+        e->be->d2h(y, dy, sizeof(double) * e->n);
+        return 0;
+    });
+}
+
+int pcg_diag(pcg_engine *e, double *d)
+{
+    return guarded("pcg_diag", [&]() -> int {
+        double *dd = e->scratch(0);
+        e->be->copy_diag(dd);                   // :282-287 element diagonals, assembled
+        e->halo_sum(dd);                        // :303-334
+        e->be->d2h(d, dd, sizeof(double) * e->n);
+        return 0;
+    });
+}
+
+int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out)
+{
+    return guarded("pcg_build_jacobi", [&]() -> int {
+        double *dd = e->scratch(0);
+        e->be->copy_diag(dd);
+        e->halo_sum(dd);
+        e->be->invert_free(e->v_minv, dd);      // :351-352
+        e->jacobi_built = true;
+        if (inv_diag_out) e->be->d2h(inv_diag_out, e->v_minv, sizeof(double) * e->n);
+        return 0;
+    });
+}
+
+int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, double delta, double *fext_out, double *udi_out)
+{
+    return guarded("pcg_update_bc", [&]() -> int {
+        double *dud = e->scratch(0), *dudi = e->scratch(1), *dfdi = e->scratch(2), *df = e->scratch(3);
+        e->be->h2d(dud, ud, sizeof(double) * e->n);
+        e->be->h2d(df, ref_load, sizeof(double) * e->n);
+        e->be->scale(dudi, delta, dud);                     // :234
+        e->apply(dudi, dfdi, false);                        // :235
+        e->be->axpby(df, delta, df, -1.0, dfdi);            // :236-237
+        if (fext_out) e->be->d2h(fext_out, df, sizeof(double) * e->n);
+        if (udi_out) e->be->d2h(udi_out, dudi, sizeof(double) * e->n);
+        return 0;
+    });
+}
+
+int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out)
+{
+    return guarded("pcg_dot_w", [&]() -> int {
+        double *da = e->scratch(0), *db = e->scratch(1);
+        e->be->h2d(da, a, sizeof(double) * e->n);
+        e->be->h2d(db, b, sizeof(double) * e->n);
+        e->be->dot_w(da, db);
+        e->be->reduce_dotw(e->d_st + ST_SQR);
+        e->allreduce(e->d_st + ST_SQR, 1);
+        e->read_status();
+        *out = e->h_st[ST_SQR];
+        return 0;
+    });
+}
+
+int pcg_set_profiling(pcg_engine *e, int32_t on)
+{
+    if (!e) return set_error("null");
+    e->profiling = on != 0;
+    e->be->set_profiling(on != 0);
+    return 0;
+}
+
+int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const double *inv_diag, double tol,
+                    int64_t max_iter, int64_t glob_n_eff)
+{
+    return guarded("pcg_solve_begin", [&]() -> int {
+        if (!e || !b) return set_error("pcg_solve_begin: null");
+        if (max_iter < 1) return set_error("pcg_solve_begin: max_iter must be >= 1");
+        const double t0 = now_s();
+        ensure_solver_buffers(e);
+        Backend &be = *e->be;
+        auto &s = e->s;
+        s = pcg_engine::Solve();
+        s.active = true;
+        s.t_comm0 = e->t_comm;
+        s.tol = tol;
+        s.max_iter = max_iter;
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        be.h2d(e->v_b, b, bytes);                                           // :377
+        if (x0) be.h2d(e->v_x[0], x0, bytes);                               // :378
+        else be.zero(e->v_x[0], bytes);
+        be.mask_free(e->v_x[0]);                                            // :408,:411 (X_Unq is 0 on fixed dofs)
+        if (inv_diag) {
+            if (!e->v_minv_user) e->v_minv_user = e->vec();
+            be.h2d(e->v_minv_user, inv_diag, bytes);
+            be.mask_free(e->v_minv_user);
+            s.minv = e->v_minv_user;
+        } else {
+            if (!e->jacobi_built) return set_error("pcg_solve_begin: no preconditioner (pass inv_diag or call pcg_build_jacobi)");
+            s.minv = e->v_minv;
+        }
+        be.dot_w(e->v_b, e->v_b);                                           // :381
+        be.reduce_dotw(e->d_st + ST_SQR);
+        e->allreduce(e->d_st + ST_SQR, 1);                                  // :382
+        e->read_status();
+        s.n2b = std::sqrt(e->h_st[ST_SQR]);                                 // :383
+        s.tolb = tol * s.n2b;                                               // :384
+        if (s.n2b == 0) {                                                   // :387-395
+            s.flag = 0; s.relres = 0; s.iter = 0; s.status = PCG_STATUS_ZERO_RHS; s.done = true;
+            s.t_total += now_s() - t0;
+            return 0;
+        }
+        {                                                                   // :404
+            const int64_t a = glob_n_eff / 50, c = glob_n_eff - max_iter;
+            s.max_msteps = std::min<int64_t>(std::min<int64_t>(a, 5), c);
+        }
+        s.cur = 0; s.min_idx = 0; s.min_live = true;                        // :380
+        e->true_residual(e->v_x[0]);                                        // :412-416
+        const double normr = std::sqrt(e->h_st[ST_SQR]);
+        s.rho_next = e->h_st[ST_RHO_NEXT];
+        s.ninf_next = e->h_st[ST_NINF];
+        s.normr_min = normr; s.normr_act = normr;                           // :417-418
+        if (normr <= s.tolb) {                                              // :421-426
+            s.flag = 0; s.relres = normr / s.n2b; s.iter = 0; s.status = PCG_STATUS_GOOD_X0; s.done = true;
+        }
+        s.t_total += now_s() - t0;
+        return 0;
+    });
+}
+
+int pcg_solve_run(pcg_engine *e, int64_t n_iters, double *hist, int64_t hist_cap, pcg_result *res)
+{
+    return guarded("pcg_solve_run", [&]() -> int {
+        if (!e || !e->s.active) return set_error("pcg_solve_run: no solve in progress");
+        const double t0 = now_s();
+        auto &s = e->s;
+        int64_t k = 0;
+        while (!s.done && (n_iters < 0 || k < n_iters)) {
+            if (iterate_once(e, hist, hist_cap)) s.done = true;
+            ++k;
+        }
+        e->be->sync();
+        s.t_total += now_s() - t0;
+        fill_result(e, res);
+        return 0;
+    });
+}
+
+int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res)
+{
+    return guarded("pcg_solve_end", [&]() -> int {
+        if (!e || !e->s.active) return set_error("pcg_solve_end: no solve in progress");
+        const double t0 = now_s();
+        auto &s = e->s;
+        const double *xf = e->v_x[s.cur];
+        if (s.status == PCG_STATUS_ZERO_RHS || s.status == PCG_STATUS_GOOD_X0) {
+            xf = e->v_x[0];
+        } else if (s.status == PCG_STATUS_TOO_SMALL_TOL) {
+            s.relres = s.normr_act / s.n2b;          // the reference raises here; report the live iterate
+            s.iter += 1;
+        } else {
+            const int64_t i = s.last_i;
+            if (s.flag == 0) {                                              // :566-567
+                s.relres = s.normr_act / s.n2b;
+            } else {                                                        // :568-582
+                const int xm = s.min_live ? s.cur : s.min_idx;
+                e->true_residual(e->v_x[xm]);                               // :569-574
+                const double normr = std::sqrt(e->h_st[ST_SQR]);
+                if (normr < s.normr_act) { s.iter = s.i_min; s.relres = normr / s.n2b; }   // :576-579
+                else { s.iter = i; s.relres = s.normr_act / s.n2b; }        // :580-582
+                xf = e->v_x[xm];                                            // X_Unq keeps XMin either way (:569,:598)
+            }
+            s.iter += 1;                                                    // :584
+            if (s.status == PCG_STATUS_RUNNING) s.status = PCG_STATUS_NORMAL;
+        }
+        if (x_out) e->be->d2h(x_out, xf, sizeof(double) * (size_t)e->n);
+        e->be->sync();
+        s.t_total += now_s() - t0;
+        fill_result(e, res);
+        s.active = false;
+        return 0;
+    });
+}
+
+int pcg_solve(pcg_engine *e, const double *b, const double *x0, const double *inv_diag, double tol, int64_t max_iter,
+              int64_t glob_n_eff, double *x_out, double *hist, int64_t hist_cap, pcg_result *res)
+{
+    int rc = pcg_solve_begin(e, b, x0, inv_diag, tol, max_iter, glob_n_eff);
+    if (rc) return rc;
+    rc = pcg_solve_run(e, -1, hist, hist_cap, nullptr);
+    if (rc) return rc;
+    return pcg_solve_end(e, x_out, res);
+}
+
+int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
+{
+    return guarded("pcg_bench_spmv", [&]() -> int {
+        double *dx = e->scratch(0), *dy = e->scratch(1);
+        std::vector<double> hx((size_t)e->n);
+        uint64_t sd = 0x9E3779B97F4A7C15ull;                 // random (not zero-filled) operand: DVFS-honest
+        for (auto &v : hx) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5; }
+        e->be->h2d(dx, hx.data(), sizeof(double) * e->n);
+        return e->be->bench_spmv(dx, dy, warmup, reps, ms_each);
+    });
+}
+
+int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows)
+{
+    if (!e) return set_error("null");
+    if (nnzb) *nnzb = e->nnzb;
+    if (stored_blocks) *stored_blocks = e->stored_blocks;
+    if (n_slices) *n_slices = e->n_slices;
+    if (slice_rows) *slice_rows = e->C;
+    return 0;
+}
+
+// ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
+int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first)
+{
+    return guarded("pcg_k_update_p", [&]() -> int {
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
+        e->be->h2d(dp, p, bytes); e->be->h2d(dr, r, bytes); e->be->h2d(dm, inv_diag, bytes);
+        e->be->update_p(dp, dr, dm, beta, first != 0);
+        e->be->d2h(p, dp, bytes);
+        return 0;
+    });
+}
+
+int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r, const double *x_old,
+                       double *x_new, const double *inv_diag, double *sums5)
+{
+    return guarded("pcg_k_fused_update", [&]() -> int {
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        ensure_solver_buffers(e);
+        double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
+        double *dxo = e->v_x[0], *dxn = e->v_x[1];
+        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
+        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
+        double st[ST_COUNT] = {0};
+        st[ST_ALPHA] = alpha;
+        e->be->h2d(e->d_st, st, sizeof(st));
+        e->be->fused_update(e->d_st, dp, dq, dr, dxo, dxn, dm);
+        e->be->reduce_update(e->d_st + ST_SQP);
+        e->read_status();
+        for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
+        e->be->d2h(r, dr, bytes);
+        e->be->d2h(x_new, dxn, bytes);
+        return 0;
+    });
+}
+
+int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, const double *inv_diag, double *sums3)
+{
+    return guarded("pcg_k_residual", [&]() -> int {
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        double *db = e->scratch(0), *da = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
+        e->be->h2d(db, b, bytes); e->be->h2d(da, ax, bytes); e->be->h2d(dm, inv_diag, bytes);
+        e->be->residual(db, da, dr, dm);
+        e->be->reduce_residual(e->d_st + ST_SQR);
+        e->read_status();
+        for (int k = 0; k < 3; ++k) sums3[k] = e->h_st[ST_SQR + k];
+        e->be->d2h(r, dr, bytes);
+        return 0;
+    });
+}
+
+int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
+{
+    return guarded("pcg_k_spmv_local", [&]() -> int {
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        double *dx = e->scratch(0), *dy = e->scratch(1);
+        e->be->h2d(dx, x, bytes);
+        if (pxy) e->be->begin_dot();
+        e->be->spmv(dx, dy, 0, e->n_slices, pxy != nullptr);
+        if (pxy) {
+            e->be->reduce_dot(e->d_st + ST_PQ);
+            e->read_status();
+            *pxy = e->h_st[ST_PQ];
+        }
+        e->be->d2h(y, dy, bytes);
+        return 0;
+    });
+}
+
+}  // extern "C"

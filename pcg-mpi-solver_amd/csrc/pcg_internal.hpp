@@ -1,0 +1,115 @@
+// Internal interfaces of libpcg_mi355x (not installed; the public surface is include/pcg_mi355x.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pcg_mi355x.h"
+
+namespace pcg {
+
+int set_error(const std::string &msg);   // stores the message, returns -1
+const std::string &last_error_string();
+
+// ---- operator storage ------------------------------------------------------------------------
+// SELL-C over 3x3 node blocks.  Slice s holds block rows [s*C, s*C+C), padded to the slice's
+// widest row (`width`).  Within a slice everything is column-major over the C rows so that
+// consecutive lanes read consecutive addresses:
+//     vals[((slice_ptr[s] + k) * 9 + c) * C + (row - s*C)]     c = 3*a + b of the 3x3 block
+//     cols[ (slice_ptr[s] + k)          * C + (row - s*C)]     block column (node) index
+// Padding entries carry value 0 and the row's own (valid) column.  C = 64 * rows_per_lane.
+struct SellHost {
+    int64_t n_nodes = 0;
+    int64_t n_slices = 0;
+    int32_t C = 64;
+    int64_t nnzb = 0;             // true (unpadded) block count
+    int64_t n_bnd_slices = 0;     // slices [0, n_bnd_slices) contain the interface rows
+    std::vector<int64_t> slice_ptr;
+    std::vector<int32_t> cols;
+    std::vector<double> vals;
+    std::vector<double> diag;     // diag(A) local, length 3*n_nodes (extracted at build time)
+};
+
+void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
+                 int64_t n_boundary_nodes, int32_t rows_per_lane, int n_threads, SellHost &out);
+
+// ---- device back end ----------------------------------------------------------------------------
+// The product library implements this with hand-written HIP kernels (hip_backend.hip).  The ONLY
+// other implementation lives under tests/hostops/ (a plain-loop test double compiled into a
+// separate test library so that the control flow in pcg_driver.cpp and the comm plumbing can be
+// exercised by the CPU/gloo test-suite).  The product never contains or loads a CPU path.
+//
+// All `double*` below are buffers obtained from alloc() ("device" pointers).
+enum { ST_RHO = 0, ST_PQ = 1, ST_ALPHA = 2, ST_STOP = 3, ST_SQP = 4, ST_SQX = 5, ST_SQR = 6,
+       ST_RHO_NEXT = 7, ST_NINF = 8, ST_COUNT = 16 };
+
+struct HaloHost {
+    int32_t n_peers = 0;
+    std::vector<int32_t> peer_ids;
+    std::vector<int64_t> send_ptr;       // n_peers + 1
+    std::vector<int32_t> send_idx;       // local dofs, concatenated by peer (neighbour order)
+    // derived: for every interface dof (ascending), the receive-buffer slots to add, neighbour order
+    std::vector<int32_t> fix_dof;        // unique interface dofs
+    std::vector<int64_t> fix_ptr;        // len fix_dof.size()+1
+    std::vector<int32_t> fix_pos;        // positions in the receive buffer
+};
+
+class Backend {
+public:
+    virtual ~Backend() {}
+    virtual const char *name() const = 0;
+    virtual void *stream() = 0;
+    virtual void *alloc(size_t bytes) = 0;
+    virtual void release(void *p) = 0;
+    virtual void h2d(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
+    virtual void d2h(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
+    virtual void d2d(void *dst, const void *src, size_t bytes) = 0;   // async on the stream
+    virtual void zero(void *dst, size_t bytes) = 0;                   // async on the stream
+    virtual void sync() = 0;
+
+    virtual void upload_matrix(const SellHost &m) = 0;
+    virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
+    virtual void upload_halo(const HaloHost &h) = 0;
+
+    // y[rows of slices lo..hi) = A x ; if partial_slot >= 0 also writes per-block partials of
+    // sum_{rows} xdot[i]*y[i]*own_free(i) into the partials buffer starting at that slot.
+    virtual void spmv(const double *x, double *y, int64_t slice_lo, int64_t slice_hi, bool with_dot) = 0;
+    virtual void halo_pack(const double *y, double *send) = 0;
+    // interface rows: y[d] += sum recv[...] (neighbour order); optional dot over the boundary-slice rows
+    virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) = 0;
+    // forget the dot partials of earlier launches (call before an apply that wants the fused dot)
+    virtual void begin_dot() = 0;
+    // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
+    virtual void reduce_dot(double *red) = 0;
+    // st[RHO] = rho ; st[ALPHA] = rho / st[PQ] ; st[STOP] per pcg_solver.py:492-498
+    virtual void scalar_alpha(double *st, double rho) = 0;
+    // p = first ? M^-1 r : M^-1 r + beta p                                (:447,:472-479)
+    virtual void update_p(double *p, const double *r, const double *minv, double beta, bool first) = 0;
+    // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r -= alpha q ; sum r^2 w ; x_new = x_old + alpha p ;
+    // z = M^-1 r ; sum z r w ; count of inf in z.  Partials -> reduce_update().   (:501-516,:447-462)
+    virtual void fused_update(const double *st, const double *p, const double *q, double *r, const double *x_old,
+                              double *x_new, const double *minv) = 0;
+    virtual void reduce_update(double *red5) = 0;
+    // r = b - ax ; sums r^2 w, (M^-1 r) r w, inf count                      (:413-416,:530-533)
+    virtual void residual(const double *b, const double *ax, double *r, const double *minv) = 0;
+    virtual void reduce_residual(double *red3) = 0;
+    virtual void dot_w(const double *a, const double *b) = 0;             // sum a*b*w
+    virtual void reduce_dotw(double *red1) = 0;
+    virtual void copy_diag(double *d) = 0;                                // local diag(A)
+    virtual void invert_free(double *minv, const double *d) = 0;          // free ? 1/d : 0   (:351-352)
+    virtual void axpby(double *out, double a, const double *x, double b, const double *y) = 0;  // a*x + b*y
+    virtual void scale(double *out, double a, const double *x) = 0;
+    virtual void mask_free(double *x) = 0;                                // zero the fixed dofs
+    // profiling of the SpMV launches with events on the stream
+    virtual void set_profiling(bool on) = 0;
+    virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
+    virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;
+};
+
+std::unique_ptr<Backend> make_backend(int device);   // defined by exactly one back end per library
+int backend_device_count();
+const char *backend_static_name();
+
+}  // namespace pcg

@@ -1,0 +1,73 @@
+// 3x3-block CSR -> SELL-C layout used by the SpMV kernel (see SellHost in pcg_internal.hpp),
+// plus the small shared utilities (error string, interface fix-up lists).
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+#include "pcg_internal.hpp"
+
+namespace pcg {
+
+static thread_local std::string g_err;
+int set_error(const std::string &msg) { g_err = msg; return -1; }
+const std::string &last_error_string() { return g_err; }
+
+void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
+                 int64_t n_boundary_nodes, int32_t rows_per_lane, int n_threads, SellHost &out)
+{
+    if (rows_per_lane != 1 && rows_per_lane != 2) throw std::runtime_error("rows_per_lane must be 1 or 2");
+    const int C = 64 * rows_per_lane;
+    out.n_nodes = n_nodes;
+    out.C = C;
+    out.n_slices = (n_nodes + C - 1) / C;
+    out.nnzb = rowptr[n_nodes];
+    out.n_bnd_slices = std::min<int64_t>(out.n_slices, (n_boundary_nodes + C - 1) / C);
+    out.slice_ptr.assign(out.n_slices + 1, 0);
+    for (int64_t s = 0; s < out.n_slices; ++s) {
+        int64_t w = 0;
+        for (int64_t r = s * C; r < std::min<int64_t>(n_nodes, (s + 1) * C); ++r)
+            w = std::max<int64_t>(w, rowptr[r + 1] - rowptr[r]);
+        out.slice_ptr[s + 1] = out.slice_ptr[s] + w;
+    }
+    const int64_t tot = out.slice_ptr[out.n_slices];
+    out.cols.assign((size_t)tot * C, 0);
+    out.vals.assign((size_t)tot * C * 9, 0.0);
+    out.diag.assign((size_t)n_nodes * 3, 0.0);
+    auto work = [&](int64_t s_lo, int64_t s_hi) {
+        for (int64_t s = s_lo; s < s_hi; ++s) {
+            const int64_t base = out.slice_ptr[s], w = out.slice_ptr[s + 1] - base;
+            for (int l = 0; l < C; ++l) {
+                const int64_t r = s * C + l;
+                const bool live = r < n_nodes;
+                const int64_t r0 = live ? rowptr[r] : 0, len = live ? rowptr[r + 1] - r0 : 0;
+                for (int64_t k = 0; k < w; ++k) {
+                    const size_t ci = (size_t)(base + k) * C + l;
+                    if (k < len) {
+                        out.cols[ci] = cols[r0 + k];
+                        const double *b = vals + (size_t)(r0 + k) * 9;
+                        for (int c = 0; c < 9; ++c) out.vals[((size_t)(base + k) * 9 + c) * C + l] = b[c];
+                        if (cols[r0 + k] == r)
+                            for (int a = 0; a < 3; ++a) out.diag[(size_t)r * 3 + a] = b[a * 3 + a];
+                    } else {
+                        out.cols[ci] = live ? (int32_t)r : 0;      // padding: value 0, harmless valid column
+                    }
+                }
+            }
+        }
+    };
+    int nt = std::max(1, n_threads);
+    if (nt == 1 || out.n_slices < 64) {
+        work(0, out.n_slices);
+    } else {
+        std::vector<std::thread> th;
+        int64_t chunk = (out.n_slices + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            int64_t lo = t * chunk, hi = std::min(out.n_slices, lo + chunk);
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        for (auto &t : th) t.join();
+    }
+}
+
+}  // namespace pcg

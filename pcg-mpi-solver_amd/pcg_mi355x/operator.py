@@ -1,0 +1,274 @@
+"""RefMeshPart -> engine operator (host-side set-up of the drop-in).
+
+`from_refmeshpart()` consumes exactly the arrays the reference's calcMatVecProd reads
+(src/solver/pcg_solver.py:245-250,263-276: SubDomainData['StrucDataList'][j] tables,
+OvrlpLocalDofVecList, NbrMPIdVector, NDOF) plus the ownership weights and the free-dof map
+(partition_mesh.py:868-887, :350-351), assembles the part's un-exchanged sub-domain matrix
+A = sum_e P_e^T S_e (Ck_e Ke_type) S_e P_e once (native host code, pcg_asm_*), renumbers the nodes
+interface-first so the exchange can overlap the interior rows, and uploads it to the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, PcgError
+
+__all__ = ["Operator", "from_refmeshpart", "assemble_bsr3"]
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def assemble_bsr3(groups, n_nodes, node_perm=None, n_threads=0):
+    """Run the native assembler on reference type groups -> (rowptr i64, cols i32, vals f64[nnzb,3,3])."""
+    L = _lib.lib()
+    keep = []
+    arr = (_lib.ElemGroup * len(groups))()
+    for k, g in enumerate(groups):
+        tbl = np.ascontiguousarray(g["ElemList_LocDofVector"], dtype=np.int64)
+        nd, ne = tbl.shape
+        sign = np.ascontiguousarray(g["ElemList_SignVector"], dtype=np.uint8)
+        if sign.shape != tbl.shape:
+            raise ValueError("ElemList_SignVector shape mismatch")
+        ck = _f64(g["ElemList_Ck"])
+        ke = _f64(g["ElemStiffMat"])
+        if ke.shape != (nd, nd) or ck.shape != (ne,):
+            raise ValueError("ElemStiffMat / ElemList_Ck shape mismatch")
+        keep += [tbl, sign, ck, ke]
+        arr[k] = _lib.ElemGroup(nd, ne, tbl.ctypes.data, sign.ctypes.data, ck.ctypes.data, ke.ctypes.data)
+    perm = None
+    if node_perm is not None:
+        perm = np.ascontiguousarray(node_perm, dtype=np.int64)
+    h = C.c_void_p()
+    check(L.pcg_asm_create(n_nodes, len(groups), arr, perm.ctypes.data if perm is not None else None,
+                           n_threads, C.byref(h)), "pcg_asm_create")
+    try:
+        nnzb = L.pcg_asm_nnzb(h)
+        rowptr = np.empty(n_nodes + 1, np.int64)
+        cols = np.empty(nnzb, np.int32)
+        vals = np.empty((nnzb, 3, 3), np.float64)
+        check(L.pcg_asm_rowptr(h, rowptr.ctypes.data), "pcg_asm_rowptr")
+        check(L.pcg_asm_fill(h, cols.ctypes.data, vals.ctypes.data), "pcg_asm_fill")
+    finally:
+        L.pcg_asm_destroy(h)
+    return rowptr, cols, vals
+
+
+class Operator:
+    """One part's operator on one GPU.  Vectors in/out are NumPy f64 of the part's local length
+    (`NDOF`) in the REFERENCE's local numbering; the interface-first renumbering is internal."""
+
+    def __init__(self, n_nodes, rowptr, cols, vals, n_boundary_nodes=0, dof_new_of_old=None, device=0,
+                 rows_per_lane=0):
+        L = _lib.lib()
+        self._L = L
+        self.n_nodes = int(n_nodes)
+        self.n = 3 * self.n_nodes
+        self._map = None if dof_new_of_old is None else np.ascontiguousarray(dof_new_of_old, dtype=np.int64)
+        self.nnzb = int(rowptr[-1])
+        self.nnz = 9 * self.nnzb
+        h = C.c_void_p()
+        rowptr = np.ascontiguousarray(rowptr, np.int64)
+        cols = np.ascontiguousarray(cols, np.int32)
+        vals = _f64(vals)
+        check(L.pcg_create(device, self.n_nodes, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data,
+                           int(n_boundary_nodes), int(rows_per_lane), C.byref(h)), "pcg_create")
+        self._h = h
+        self._comm = None
+        self._hooks = None
+        self.glob_n_eff = None
+        self.last_result = None
+
+    # -- numbering ------------------------------------------------------------------------------
+    def to_engine(self, v):
+        v = _f64(v)
+        if v.shape != (self.n,):
+            raise ValueError(f"vector length {v.shape} != {self.n}")
+        if self._map is None:
+            return v
+        out = np.empty_like(v)
+        out[self._map] = v
+        return out
+
+    def from_engine(self, v):
+        return v if self._map is None else v[self._map]
+
+    # -- set-up ---------------------------------------------------------------------------------
+    def set_masks(self, owned, free):
+        flags = (np.asarray(owned, bool).astype(np.uint8) | (np.asarray(free, bool).astype(np.uint8) << 1))
+        if self._map is not None:
+            f2 = np.empty_like(flags)
+            f2[self._map] = flags
+            flags = f2
+        flags = np.ascontiguousarray(flags)
+        check(self._L.pcg_set_masks(self._h, flags.ctypes.data), "pcg_set_masks")
+
+    def set_halo(self, peer_ids, dof_lists):
+        peer = np.ascontiguousarray(peer_ids, np.int32)
+        ptr = np.zeros(len(peer) + 1, np.int64)
+        ptr[1:] = np.cumsum([len(d) for d in dof_lists])
+        idx = np.concatenate([np.asarray(d, np.int64) for d in dof_lists]) if len(peer) else np.zeros(0, np.int64)
+        if self._map is not None and len(idx):
+            idx = self._map[idx]
+        idx = np.ascontiguousarray(idx, np.int32)
+        check(self._L.pcg_set_halo(self._h, len(peer), peer.ctypes.data, ptr.ctypes.data, idx.ctypes.data), "pcg_set_halo")
+        self.peer_ids = [int(p) for p in peer]
+        self.peer_counts = [int(c) for c in np.diff(ptr)]
+
+    def set_comm(self, comm):
+        """comm: pcg_mi355x.dist.TorchComm (or None)."""
+        self._comm = comm
+        if comm is None:
+            check(self._L.pcg_set_comm(self._h, None), "pcg_set_comm")
+            self._hooks = None
+            return
+        self._hooks = comm.make_hooks(self)
+        check(self._L.pcg_set_comm(self._h, C.byref(self._hooks)), "pcg_set_comm")
+
+    def stream_ptr(self):
+        return self._L.pcg_stream(self._h)
+
+    # -- operator-level calls -------------------------------------------------------------------
+    def _raise_comm(self):
+        if self._comm is not None:
+            self._comm.reraise()
+
+    def apply(self, x):
+        """calcMatVecProd(.., 'Strain', x) (:242-336)."""
+        xe = self.to_engine(x)
+        y = np.empty(self.n)
+        rc = self._L.pcg_apply(self._h, xe.ctypes.data, y.ctypes.data)
+        self._raise_comm(); check(rc, "pcg_apply")
+        return self.from_engine(y)
+
+    def diag(self):
+        """calcMatVecProd(.., 'Preconditioner') (:282-287 + exchange)."""
+        d = np.empty(self.n)
+        rc = self._L.pcg_diag(self._h, d.ctypes.data)
+        self._raise_comm(); check(rc, "pcg_diag")
+        return self.from_engine(d)
+
+    def build_jacobi(self):
+        """updatePreconditioner (:346-352); returns 1/diag on the free dofs (0 on fixed), full length."""
+        d = np.empty(self.n)
+        rc = self._L.pcg_build_jacobi(self._h, d.ctypes.data)
+        self._raise_comm(); check(rc, "pcg_build_jacobi")
+        return self.from_engine(d)
+
+    def update_bc(self, ref_load, ud, delta):
+        """updateBC (:226-238) -> (Fext, Udi)."""
+        f = self.to_engine(ref_load); u = self.to_engine(ud)
+        fo = np.empty(self.n); uo = np.empty(self.n)
+        rc = self._L.pcg_update_bc(self._h, f.ctypes.data, u.ctypes.data, float(delta), fo.ctypes.data, uo.ctypes.data)
+        self._raise_comm(); check(rc, "pcg_update_bc")
+        return self.from_engine(fo), self.from_engine(uo)
+
+    def dot_w(self, a, b):
+        out = C.c_double()
+        a = self.to_engine(a); b = self.to_engine(b)
+        rc = self._L.pcg_dot_w(self._h, a.ctypes.data, b.ctypes.data, C.byref(out))
+        self._raise_comm(); check(rc, "pcg_dot_w")
+        return out.value
+
+    # -- PCG ------------------------------------------------------------------------------------
+    def solve_begin(self, b, x0=None, inv_diag=None, tol=1e-7, max_iter=10000, glob_n_eff=None):
+        be = self.to_engine(b)
+        x0e = self.to_engine(x0) if x0 is not None else None
+        mde = self.to_engine(inv_diag) if inv_diag is not None else None
+        gne = int(glob_n_eff if glob_n_eff is not None else (self.glob_n_eff or self.n))
+        rc = self._L.pcg_solve_begin(self._h, be.ctypes.data, x0e.ctypes.data if x0e is not None else None,
+                                     mde.ctypes.data if mde is not None else None, float(tol), int(max_iter), gne)
+        self._raise_comm(); check(rc, "pcg_solve_begin")
+
+    def solve_run(self, n_iters=-1, hist=None):
+        res = _lib.Result()
+        hp, hc = (hist.ctypes.data, hist.shape[0]) if hist is not None else (None, 0)
+        rc = self._L.pcg_solve_run(self._h, int(n_iters), hp, hc, C.byref(res))
+        self._raise_comm(); check(rc, "pcg_solve_run")
+        return res
+
+    def solve_end(self):
+        res = _lib.Result()
+        x = np.empty(self.n)
+        rc = self._L.pcg_solve_end(self._h, x.ctypes.data, C.byref(res))
+        self._raise_comm(); check(rc, "pcg_solve_end")
+        self.last_result = res
+        return self.from_engine(x), res
+
+    def solve(self, b, x0=None, inv_diag=None, tol=1e-7, max_iter=10000, glob_n_eff=None, history=False):
+        """-> (x, Result, hist or None).  hist rows = [NormP, NormX, NormR] per iteration (:507)."""
+        self.solve_begin(b, x0, inv_diag, tol, max_iter, glob_n_eff)
+        hist = np.zeros((int(max_iter), 3)) if history else None
+        self.solve_run(-1, hist)
+        x, res = self.solve_end()
+        if hist is not None:
+            hist = hist[:max(0, min(int(res.iters_done), int(max_iter)))]
+        return x, res, hist
+
+    def set_profiling(self, on=True):
+        check(self._L.pcg_set_profiling(self._h, 1 if on else 0), "pcg_set_profiling")
+
+    def bench_spmv(self, warmup=10, reps=100):
+        ms = np.zeros(reps, np.float32)
+        check(self._L.pcg_bench_spmv(self._h, warmup, reps, ms.ctypes.data), "pcg_bench_spmv")
+        return ms
+
+    def matrix_info(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        check(self._L.pcg_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_matrix_info")
+        return {"nnzb": a.value, "stored_blocks": b.value, "n_slices": c.value, "slice_rows": d.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pcg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0):
+    """Build the GPU operator of one RefMeshPart (see module docstring for the keys read)."""
+    ndof = int(part["NDOF"])
+    if ndof % 3:
+        raise PcgError("NDOF must be a multiple of 3 (dof = 3*node + dir, partition_mesh.py:826)")
+    n_nodes = ndof // 3
+    groups = [g for g in part["SubDomainData"]["StrucDataList"] if g.get("ElemTypeId", 0) >= 0]   # :855-856
+    nbr = list(part.get("NbrMPIdVector", []))
+    ovl = [np.asarray(v, np.int64) for v in part.get("OvrlpLocalDofVecList", [])]
+    node_perm = None
+    dof_map = None
+    n_bnd = 0
+    if len(nbr):
+        is_b = np.zeros(n_nodes, bool)
+        for v in ovl:
+            is_b[v // 3] = True
+        order = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])     # old ids, interface first
+        node_perm = np.empty(n_nodes, np.int64)
+        node_perm[order] = np.arange(n_nodes)
+        n_bnd = int(is_b.sum())
+        dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
+    rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
+    op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, rows_per_lane)
+    w = np.asarray(part["DofWeightVector"], float)
+    if not np.all((w == 0) | (w == 1)):
+        raise PcgError("DofWeightVector must be 0/1 (partition_mesh.py:870-887)")
+    free = np.zeros(ndof, bool)
+    free[np.asarray(part["LocDofEff"], np.int64)] = True
+    op.set_masks(w == 1, free)
+    op.set_halo(nbr, ovl)
+    op.part_id = int(part.get("Id", 0))
+    op.glob_n_eff = int(part["GlobData"]["GlobNDofEff"]) if "GlobData" in part else None
+    if len(nbr) or comm is not None:
+        if comm is None:
+            raise PcgError("part has neighbours: pass comm=pcg_mi355x.dist.TorchComm(...)")
+        op.set_comm(comm)
+    return op

@@ -1,0 +1,73 @@
+"""Worker for the multi-process tests (one process per part, as in production: one process per GPU).
+
+usage: python -m torch.distributed.run --nproc-per-node P tests/dist_worker.py <case> <backend> <lib> <outdir>
+  backend gloo + lib hostops : CPU test of the N>1 path (control flow, interface lists, comm hooks)
+  backend nccl + lib product : the same on GPUs (world_size 1 on the 1-GPU test box)
+Each rank builds ITS part of the golden case, runs updateBC -> updatePreconditioner -> PCG through the
+drop-in functions and writes its results to <outdir>/rank<r>.npz.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "pcg-mpi-solver_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    case, backend, libkind, outdir = sys.argv[1:5]
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    from pcg_mi355x import _lib
+    if libkind == "hostops":
+        import conftest
+        _lib.use_library(conftest.HOSTOPS_LIB)
+    else:
+        _lib.use_library(None)
+    device = None
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dist.init_process_group(backend)
+    import pcg_mi355x as pm
+    from pcg_mi355x.dist import TorchComm
+    import golden_cases
+    brick, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
+    assert len(parts) == world, (len(parts), world)
+    P = parts[rank]
+    comm = TorchComm(device=device)
+    pm.configure(comm=comm, device=int(os.environ.get("LOCAL_RANK", 0)))
+    out = {"rank": rank}
+    x = golden_cases.probe_vector(brick)[P["DofVector"]]
+    out["y_probe"] = pm.calc_mpfint(x, P)
+    out["diag"] = pm.calc_matvec_prod(P, "Preconditioner")
+    pm.update_bc(P)
+    pm.update_preconditioner(P)
+    out["Fext"] = P["Fext"]
+    try:
+        ret = pm.solve(P, history=True)
+        out["raised"] = ""
+    except Warning as w:
+        ret = None
+        out["raised"] = str(w)
+    info = P["_pcg_mi355x_info"]
+    out["Un"] = P["Un"]
+    out["history"] = info.history
+    out["flag"], out["iter"], out["relres"] = info.flag, info.iter, info.relres
+    gd = P["GlobData"]
+    out["tl_flag"], out["tl_iter"], out["tl_relres"] = gd["TimeList_Flag"][1], gd["TimeList_Iter"][1], gd["TimeList_RelRes"][1]
+    out["n_allreduce"], out["n_halo"] = comm.n_allreduce, comm.n_halo
+    out["dofs"] = P["DofVector"]
+    out["t_comm"] = gd["MP_TimeRecData"]["dT_CommWait"]
+    out["t_calc"] = gd["MP_TimeRecData"]["dT_Calc"]
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

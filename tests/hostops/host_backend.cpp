@@ -1,0 +1,164 @@
+// TEST DOUBLE - plain-loop implementation of pcg::Backend.
+//
+// Compiled ONLY into tests/hostops/_build/libpcg_hostops.so together with the product's
+// back-end-agnostic sources (pcg_driver.cpp, assemble.cpp, sell.cpp).  It lets the CPU test-suite
+// (`pytest -m "not gpu"`, including the world_size-2 gloo tests) exercise the PCG control flow, the
+// SELL conversion, the interface fix-up lists and the Python comm hooks without a GPU.  It is never
+// part of libpcg_mi355x.so and the pcg_mi355x package never loads it on its own; the product
+// library has exactly one back end (HIP, gfx950) and no CPU path.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "pcg_internal.hpp"
+
+namespace pcg {
+
+class HostBackend : public Backend {
+    SellHost m_;
+    std::vector<uint8_t> flags_;
+    HaloHost h_;
+    double dot_spmv_ = 0, dot_fix_ = 0, dotw_ = 0;
+    double up_[5] = {0, 0, 0, 0, 0}, res_[3] = {0, 0, 0};
+    int64_t n_ = 0;
+    bool own_free(int64_t d) const { return (flags_[d] & 3) == 3; }
+    bool is_free(int64_t d) const { return (flags_[d] & 2) != 0; }
+
+public:
+    const char *name() const override { return "hostops-test"; }
+    void *stream() override { return nullptr; }
+    void *alloc(size_t b) override { void *p = std::malloc(b ? b : 8); if (!p) throw std::bad_alloc(); return p; }
+    void release(void *p) override { std::free(p); }
+    void h2d(void *d, const void *s, size_t b) override { std::memcpy(d, s, b); }
+    void d2h(void *d, const void *s, size_t b) override { std::memcpy(d, s, b); }
+    void d2d(void *d, const void *s, size_t b) override { std::memcpy(d, s, b); }
+    void zero(void *d, size_t b) override { std::memset(d, 0, b); }
+    void sync() override {}
+    void upload_matrix(const SellHost &m) override { m_ = m; n_ = 3 * m.n_nodes; }
+    void upload_masks(const uint8_t *f, int64_t n) override { flags_.assign(f, f + n); }
+    void upload_halo(const HaloHost &h) override { h_ = h; }
+
+    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
+    {
+        const int C = m_.C;
+        double acc = 0;
+        for (int64_t s = lo; s < hi; ++s) {
+            const int64_t base = m_.slice_ptr[s], w = m_.slice_ptr[s + 1] - base;
+            for (int l = 0; l < C; ++l) {
+                const int64_t r = s * C + l;
+                if (r >= m_.n_nodes) break;
+                double t[3] = {0, 0, 0};
+                for (int64_t k = 0; k < w; ++k) {
+                    const int64_t j = m_.cols[(size_t)(base + k) * C + l];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b)
+                            t[a] += m_.vals[((size_t)(base + k) * 9 + a * 3 + b) * C + l] * x[3 * j + b];
+                }
+                for (int a = 0; a < 3; ++a) {
+                    y[3 * r + a] = t[a];
+                    if (with_dot && own_free(3 * r + a)) acc += x[3 * r + a] * t[a];
+                }
+            }
+        }
+        if (with_dot) dot_spmv_ = acc;
+    }
+    void halo_pack(const double *y, double *send) override
+    {
+        for (size_t m = 0; m < h_.send_idx.size(); ++m) send[m] = y[h_.send_idx[m]];
+    }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) override
+    {
+        for (size_t k = 0; k < h_.fix_dof.size(); ++k) {
+            double v = y[h_.fix_dof[k]];
+            for (int64_t q = h_.fix_ptr[k]; q < h_.fix_ptr[k + 1]; ++q) v += recv[h_.fix_pos[q]];
+            y[h_.fix_dof[k]] = v;
+        }
+        if (with_dot) {
+            double acc = 0;
+            const int64_t nb = std::min<int64_t>(n_, m_.n_bnd_slices * m_.C * 3);
+            for (int64_t d = 0; d < nb; ++d)
+                if (own_free(d)) acc += xdot[d] * y[d];
+            dot_fix_ = acc;
+        }
+    }
+    void begin_dot() override { dot_spmv_ = dot_fix_ = 0; }
+    void reduce_dot(double *red) override { red[0] = dot_spmv_ + dot_fix_; }
+    void scalar_alpha(double *st, double rho) override
+    {
+        const double pq = st[ST_PQ];
+        st[ST_RHO] = rho;
+        st[ST_STOP] = 0;
+        if (pq <= 0 || std::isinf(pq)) { st[ST_STOP] = 1; return; }
+        st[ST_ALPHA] = rho / pq;
+        if (std::isinf(st[ST_ALPHA])) st[ST_STOP] = 1;
+    }
+    void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
+    {
+        for (int64_t i = 0; i < n_; ++i) {
+            const double z = minv[i] * r[i];
+            p[i] = first ? z : z + beta * p[i];
+        }
+    }
+    void fused_update(const double *st, const double *p, const double *q, double *r, const double *xo, double *xn,
+                      const double *minv) override
+    {
+        for (double &v : up_) v = 0;
+        if (st[ST_STOP] != 0) return;
+        const double alpha = st[ST_ALPHA];
+        for (int64_t i = 0; i < n_; ++i) {
+            const bool w = own_free(i);
+            if (w) { up_[0] += p[i] * p[i]; up_[1] += xo[i] * xo[i]; }
+            const double rn = r[i] - alpha * q[i];
+            r[i] = rn;
+            xn[i] = xo[i] + alpha * p[i];
+            const double z = minv[i] * rn;
+            if (is_free(i) && std::isinf(z)) up_[4] += 1;
+            if (w) { up_[2] += rn * rn; up_[3] += z * rn; }
+        }
+    }
+    void reduce_update(double *red5) override { for (int k = 0; k < 5; ++k) red5[k] = up_[k]; }
+    void residual(const double *b, const double *ax, double *r, const double *minv) override
+    {
+        for (double &v : res_) v = 0;
+        for (int64_t i = 0; i < n_; ++i) {
+            const double rn = b[i] - ax[i];
+            r[i] = rn;
+            const double z = minv[i] * rn;
+            if (is_free(i) && std::isinf(z)) res_[2] += 1;
+            if (own_free(i)) { res_[0] += rn * rn; res_[1] += z * rn; }
+        }
+    }
+    void reduce_residual(double *red3) override { for (int k = 0; k < 3; ++k) red3[k] = res_[k]; }
+    void dot_w(const double *a, const double *b) override
+    {
+        dotw_ = 0;
+        for (int64_t i = 0; i < n_; ++i) if (own_free(i)) dotw_ += a[i] * b[i];
+    }
+    void reduce_dotw(double *red1) override { red1[0] = dotw_; }
+    void copy_diag(double *d) override { std::memcpy(d, m_.diag.data(), sizeof(double) * n_); }
+    void invert_free(double *minv, const double *d) override
+    {
+        for (int64_t i = 0; i < n_; ++i) minv[i] = is_free(i) ? 1.0 / d[i] : 0.0;
+    }
+    void axpby(double *o, double a, const double *x, double b, const double *y) override
+    {
+        for (int64_t i = 0; i < n_; ++i) o[i] = a * x[i] + b * y[i];
+    }
+    void scale(double *o, double a, const double *x) override { for (int64_t i = 0; i < n_; ++i) o[i] = a * x[i]; }
+    void mask_free(double *x) override { for (int64_t i = 0; i < n_; ++i) if (!is_free(i)) x[i] = 0.0; }
+    void set_profiling(bool) override {}
+    void collect_profile(double *ms, int64_t *c) override { *ms = 0; *c = 0; }
+    int bench_spmv(const double *x, double *y, int, int reps, float *ms) override
+    {
+        spmv(x, y, 0, m_.n_slices, false);
+        for (int k = 0; k < reps; ++k) ms[k] = 0.f;
+        return 0;
+    }
+};
+
+std::unique_ptr<Backend> make_backend(int) { return std::unique_ptr<Backend>(new HostBackend()); }
+int backend_device_count() { return 0; }
+const char *backend_static_name() { return "hostops-test"; }
+
+}  // namespace pcg
