@@ -1,0 +1,662 @@
+// HIP back end for gfx950 (MI355X, CDNA4): the hand-written kernels of the PCG hot path.
+//
+// Everything here is HBM-bandwidth bound (SpMV arithmetic intensity ~0.2 flop/B), so the design
+// rules are: every wave-level load is lane-contiguous (SELL layout: 8 or 16 B per lane, 512 B /
+// 1 KiB per wave instruction), matrix data is streamed once with non-temporal loads so it does not
+// evict the x vector from L2/MALL, blocks are mapped XCD-aware (block b runs on XCD b%8: each XCD
+// walks one contiguous eighth of the matrix so that the x entries its waves gather stay in that
+// XCD's private L2), reductions are wave64 shuffles -> LDS -> one partial per block -> a fixed
+// tree (no float atomics: bit-reproducible run to run), and the vector part of an iteration is
+// fused into two streaming kernels.  No MFMA: there is no dense contraction on this path.
+//
+// Reference semantics implemented (src/solver/pcg_solver.py): k_spmv = calcMatVecProd :265-300 on
+// the assembled operator (+ fused p.Ap.w :487); k_fixup = :332-334; k_update_p = :447,:472-479;
+// k_fused_update = :501-516 plus :447-462 of the next iteration; k_residual = :413-416/:530-533;
+// k_dot_w = np.dot(a, b*w) :381.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "pcg_internal.hpp"
+
+#define HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            throw std::runtime_error(std::string(#expr) + " -> " + hipGetErrorString(_e));               \
+    } while (0)
+
+namespace pcg {
+
+constexpr int kBlock = 256;            // 4 wave64 per workgroup
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kMaxPartials = 4096;     // upper bound on blocks that write a partial
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;                           // valid in lane 0
+}
+
+// block-level sum of NV per-thread values; result valid in thread 0.  Fixed order -> deterministic.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* NV * kWavesPerBlock */)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) lds[k * kWavesPerBlock + wid] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = lds[k * kWavesPerBlock];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) s += lds[k * kWavesPerBlock + w];
+            v[k] = s;
+        }
+    }
+}
+
+// out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] for v==0 when pb != null)
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
+                                                   const double *__restrict__ pb, int count_b, double *out)
+{
+    __shared__ double lds[NV * kWavesPerBlock];
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < count_a; b += kBlock) s += pa[(size_t)k * stride + b];
+        if (k == 0 && pb)
+            for (int b = threadIdx.x; b < count_b; b += kBlock) s += pb[b];
+        v[k] = s;
+    }
+    block_sum<NV>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] = v[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV over the SELL-C 3x3-block matrix.  One wave per slice at a time; RPL rows per lane
+// (RPL=1: C=64, 8-B lane loads; RPL=2: C=128, 16-B lane loads).
+// ------------------------------------------------------------------------------------------------
+template <int RPL> struct VecT;
+template <> struct VecT<1> { using d = double; using i = int; };
+template <> struct VecT<2> { using d = double2; using i = int2; };
+
+__device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ int ntload(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double2 ntload(const double2 *p)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(p));
+    return make_double2(t.x, t.y);
+}
+__device__ __forceinline__ int2 ntload(const int2 *p)
+{
+    typedef int v2 __attribute__((ext_vector_type(2)));
+    v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(p));
+    return make_int2(t.x, t.y);
+}
+
+template <int RPL, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
+                                                 const double *__restrict__ vals, const double *__restrict__ x,
+                                                 double *__restrict__ y, const uint8_t *__restrict__ flags,
+                                                 double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
+                                                 int64_t n_nodes)
+{
+    constexpr int C = 64 * RPL;
+    using DV = typename VecT<RPL>::d;
+    using IV = typename VecT<RPL>::i;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // XCD-aware slice assignment: block b runs on XCD b & 7 (observed; speed only, never correctness).
+    // Each XCD owns one contiguous eighth of the slice range and its waves sweep it together.
+    const int64_t S = slice_hi - slice_lo;
+    const int xcd = blockIdx.x & 7;
+    const int64_t lb = blockIdx.x >> 3;
+    const int64_t blocks_per_xcd = (gridDim.x + 7 - xcd) >> 3;      // blocks with b&7 == xcd
+    const int64_t c_lo = slice_lo + (S * xcd) / 8, c_hi = slice_lo + (S * (xcd + 1)) / 8;
+    const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
+    double dot = 0.0;
+    for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const DV *vp = reinterpret_cast<const DV *>(vals + (size_t)base * 9 * C) + lane;
+        const IV *cp = reinterpret_cast<const IV *>(cols + (size_t)base * C) + lane;
+        double acc[RPL][3];
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.0;
+#pragma unroll 3
+        for (int k = 0; k < w; ++k) {
+            const IV jv = ntload(cp + (size_t)k * 64);
+            DV v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
+            if constexpr (RPL == 1) {
+                const double *xp = x + 3 * (size_t)jv;
+                const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    acc[0][a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[0][a])));
+            } else {
+                const double *xa = x + 3 * (size_t)jv.x, *xb = x + 3 * (size_t)jv.y;
+                const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
+                const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    acc[0][a] = fma(v[3 * a + 2].x, a2, fma(v[3 * a + 1].x, a1, fma(v[3 * a].x, a0, acc[0][a])));
+                    acc[1][a] = fma(v[3 * a + 2].y, b2, fma(v[3 * a + 1].y, b1, fma(v[3 * a].y, b0, acc[1][a])));
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+            const int64_t row = s * C + (int64_t)lane * RPL + h;
+            if (row < n_nodes) {
+                double *yp = y + 3 * row;
+                yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2];
+                if constexpr (DOT) {
+                    const uint8_t *fp = flags + 3 * row;
+                    const double *xp = x + 3 * row;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if ((fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
+                }
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// interface kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__ y, const int *__restrict__ idx,
+                                                      double *__restrict__ send, int64_t count)
+{
+    for (int64_t m = blockIdx.x * (int64_t)kBlock + threadIdx.x; m < count; m += (int64_t)gridDim.x * kBlock)
+        send[m] = y[idx[m]];
+}
+
+// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
+                                                  const int *__restrict__ fptr, const int *__restrict__ fpos,
+                                                  const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
+                                                  int64_t nb, double *__restrict__ partials)
+{
+    double dot = 0.0;
+    for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
+        double v = y[d];
+        const int q0 = fptr[d], q1 = fptr[d + 1];
+        for (int q = q0; q < q1; ++q) v += recv[fpos[q]];
+        if (q1 > q0) y[d] = v;
+        if constexpr (DOT)
+            if ((flags[d] & 3) == 3) dot += xdot[d] * v;
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector kernels (grid-stride, 16 B per lane, scalar tail)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_scalar_alpha(double *st, double rho)
+{
+    const double pq = st[ST_PQ];
+    st[ST_RHO] = rho;
+    double stop = 0.0, alpha = st[ST_ALPHA];
+    if (pq <= 0.0 || isinf(pq)) stop = 1.0;                       // :492-494
+    else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }      // :495-498
+    st[ST_ALPHA] = alpha;
+    st[ST_STOP] = stop;
+}
+
+__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ p, const double *__restrict__ r,
+                                                     const double *__restrict__ minv, double beta, int first, int64_t n)
+{
+    const int64_t n2 = n >> 1;
+    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *m2 = reinterpret_cast<const double2 *>(minv);
+    for (int64_t t = t0; t < n2; t += ts) {
+        const double2 rr = r2[t], mm = m2[t];
+        double2 z = make_double2(mm.x * rr.x, mm.y * rr.y);        // :447
+        if (!first) { const double2 pp = p2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
+        p2[t] = z;
+    }
+    if ((n & 1) && t0 == 0) {
+        const int64_t i = n - 1;
+        double z = minv[i] * r[i];
+        if (!first) z = z + beta * p[i];
+        p[i] = z;
+    }
+}
+
+struct Up { double sqp, sqx, sqr, rho, ninf; };
+
+__device__ __forceinline__ void update_one(double alpha, double p, double q, double &r, double xo, double &xn, double m,
+                                           uint8_t f, Up &u)
+{
+    const bool w = (f & 3) == 3;
+    if (w) { u.sqp += p * p; u.sqx += xo * xo; }                  // :504-505 (x BEFORE the update)
+    const double rn = r - alpha * q;                               // :501
+    r = rn;
+    xn = xo + alpha * p;                                           // :516
+    const double z = m * rn;                                       // :447 of the next iteration
+    if ((f & 2) && isinf(z)) u.ninf += 1.0;                        // :448
+    if (w) { u.sqr += rn * rn; u.rho += z * rn; }                  // :506, :462
+}
+
+__global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restrict__ st, const double *__restrict__ p,
+                                                         const double *__restrict__ q, double *__restrict__ r,
+                                                         const double *__restrict__ xo, double *__restrict__ xn,
+                                                         const double *__restrict__ minv, const uint8_t *__restrict__ flags,
+                                                         double *__restrict__ partials, int64_t n)
+{
+    __shared__ double lds[5 * kWavesPerBlock];
+    Up u = {0, 0, 0, 0, 0};
+    if (st[ST_STOP] == 0.0) {                                      // frozen when pq/alpha broke down (:492-498)
+        const double alpha = st[ST_ALPHA];
+        const int64_t n2 = n >> 1;
+        const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+        const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
+        const double2 *x2 = reinterpret_cast<const double2 *>(xo), *m2 = reinterpret_cast<const double2 *>(minv);
+        double2 *r2 = reinterpret_cast<double2 *>(r), *xn2 = reinterpret_cast<double2 *>(xn);
+        const uchar2 *f2 = reinterpret_cast<const uchar2 *>(flags);
+        for (int64_t t = t0; t < n2; t += ts) {
+            const double2 pp = p2[t], qq = q2[t], xx = x2[t], mm = m2[t];
+            double2 rr = r2[t], xo2;
+            const uchar2 ff = f2[t];
+            update_one(alpha, pp.x, qq.x, rr.x, xx.x, xo2.x, mm.x, ff.x, u);
+            update_one(alpha, pp.y, qq.y, rr.y, xx.y, xo2.y, mm.y, ff.y, u);
+            r2[t] = rr;
+            xn2[t] = xo2;
+        }
+        if ((n & 1) && t0 == 0) {
+            const int64_t i = n - 1;
+            double rr = r[i], xnew;
+            update_one(alpha, p[i], q[i], rr, xo[i], xnew, minv[i], flags[i], u);
+            r[i] = rr;
+            xn[i] = xnew;
+        }
+    }
+    double v[5] = {u.sqp, u.sqx, u.sqr, u.rho, u.ninf};
+    block_sum<5>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_residual(const double *__restrict__ b, const double *__restrict__ ax,
+                                                     double *__restrict__ r, const double *__restrict__ minv,
+                                                     const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
+{
+    __shared__ double lds[3 * kWavesPerBlock];
+    double sqr = 0, rho = 0, ninf = 0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double rn = b[i] - ax[i];                            // :414, :531
+        r[i] = rn;
+        const double z = minv[i] * rn;
+        const uint8_t f = flags[i];
+        if ((f & 2) && isinf(z)) ninf += 1.0;
+        if ((f & 3) == 3) { sqr += rn * rn; rho += z * rn; }       // :415, :462
+    }
+    double v[3] = {sqr, rho, ninf};
+    block_sum<3>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_dot_w(const double *__restrict__ a, const double *__restrict__ b,
+                                                  const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
+{
+    __shared__ double lds[kWavesPerBlock];
+    double s = 0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if ((flags[i] & 3) == 3) s += a[i] * b[i];
+    double v[1] = {s};
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert_free(double *__restrict__ minv, const double *__restrict__ d,
+                                                        const uint8_t *__restrict__ flags, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        minv[i] = (flags[i] & 2) ? 1.0 / d[i] : 0.0;               // :351-352
+}
+
+__global__ __launch_bounds__(kBlock) void k_axpby(double *__restrict__ o, double a, const double *__restrict__ x, double b,
+                                                  const double *__restrict__ y, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        o[i] = a * x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale(double *__restrict__ o, double a, const double *__restrict__ x, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) o[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_free(double *__restrict__ x, const uint8_t *__restrict__ flags, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (!(flags[i] & 2)) x[i] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// back end
+// ------------------------------------------------------------------------------------------------
+class HipBackend : public Backend {
+    int dev_ = 0;
+    int n_cu_ = 256;
+    hipStream_t st_ = nullptr;
+    // matrix
+    int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
+    int C_ = 64;
+    int64_t *d_slice_ptr_ = nullptr;
+    int *d_cols_ = nullptr;
+    double *d_vals_ = nullptr, *d_diag_ = nullptr;
+    uint8_t *d_flags_ = nullptr;
+    // halo
+    int *d_send_idx_ = nullptr, *d_fptr_ = nullptr, *d_fpos_ = nullptr;
+    int64_t halo_count_ = 0, nb_dofs_ = 0;
+    // partials
+    double *d_part_ = nullptr;        // 5 * kMaxPartials (vector kernels)
+    double *d_part_spmv_ = nullptr;   // kMaxPartials
+    double *d_part_fix_ = nullptr;    // kMaxPartials
+    int cnt_spmv_ = 0, cnt_fix_ = 0, cnt_vec_ = 0;
+    // profiling
+    bool prof_ = false;
+    static constexpr int kMaxEv = 8192;
+    std::vector<hipEvent_t> ev0_, ev1_;
+    int ev_used_ = 0;
+    int64_t ev_applies_ = 0;
+
+    int vec_grid(int64_t n) const
+    {
+        int64_t g = (n / 2 + kBlock - 1) / kBlock;
+        int64_t cap = (int64_t)n_cu_ * 8;
+        if (cap > kMaxPartials) cap = kMaxPartials;
+        if (g > cap) g = cap;
+        return (int)(g < 1 ? 1 : g);
+    }
+    int spmv_grid(int64_t slices) const
+    {
+        int64_t g = (slices + kWavesPerBlock - 1) / kWavesPerBlock;
+        int64_t cap = (int64_t)n_cu_ * spmv_blocks_per_cu_;
+        if (cap > kMaxPartials) cap = kMaxPartials;
+        if (g > cap) g = cap;
+        g = (g + 7) / 8 * 8;           // whole blocks per XCD
+        return (int)(g < 8 ? 8 : g);
+    }
+    int spmv_blocks_per_cu_ = 4;
+
+public:
+    explicit HipBackend(int device)
+    {
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+            throw std::runtime_error("no HIP device visible (this engine has no CPU fallback)");
+        if (device < 0 || device >= cnt) throw std::runtime_error("device index out of range");
+        dev_ = device;
+        HIP_CHECK(hipSetDevice(dev_));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw std::runtime_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        n_cu_ = prop.multiProcessorCount;
+        HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
+        d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
+        d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
+        if (const char *e = getenv("PCG_SPMV_BLOCKS_PER_CU")) spmv_blocks_per_cu_ = std::max(1, atoi(e));
+    }
+    ~HipBackend() override
+    {
+        (void)hipSetDevice(dev_);
+        for (void *p : {(void *)d_slice_ptr_, (void *)d_cols_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
+                        (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
+                        (void *)d_part_fix_})
+            if (p) (void)hipFree(p);
+        for (auto e : ev0_) (void)hipEventDestroy(e);
+        for (auto e : ev1_) (void)hipEventDestroy(e);
+        if (st_) (void)hipStreamDestroy(st_);
+    }
+    const char *name() const override { return "hip-gfx950"; }
+    void *stream() override { return (void *)st_; }
+    void *alloc(size_t bytes) override
+    {
+        HIP_CHECK(hipSetDevice(dev_));
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+        return p;
+    }
+    void release(void *p) override { (void)hipFree(p); }
+    void h2d(void *d, const void *s, size_t b) override
+    {
+        HIP_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    void d2h(void *d, const void *s, size_t b) override
+    {
+        HIP_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    void d2d(void *d, const void *s, size_t b) override { HIP_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, st_)); }
+    void zero(void *d, size_t b) override { HIP_CHECK(hipMemsetAsync(d, 0, b, st_)); }
+    void sync() override { HIP_CHECK(hipStreamSynchronize(st_)); }
+
+    void upload_matrix(const SellHost &m) override
+    {
+        n_nodes_ = m.n_nodes; n_ = 3 * m.n_nodes; n_slices_ = m.n_slices; n_bnd_slices_ = m.n_bnd_slices; C_ = m.C;
+        d_slice_ptr_ = (int64_t *)alloc(sizeof(int64_t) * m.slice_ptr.size());
+        d_cols_ = (int *)alloc(sizeof(int) * m.cols.size());
+        d_vals_ = (double *)alloc(sizeof(double) * m.vals.size());
+        d_diag_ = (double *)alloc(sizeof(double) * m.diag.size());
+        d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
+        h2d(d_slice_ptr_, m.slice_ptr.data(), sizeof(int64_t) * m.slice_ptr.size());
+        h2d(d_cols_, m.cols.data(), sizeof(int) * m.cols.size());
+        h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
+        h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
+        nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * 3);
+    }
+    void upload_masks(const uint8_t *f, int64_t n) override { h2d(d_flags_, f, (size_t)n); }
+    void upload_halo(const HaloHost &h) override
+    {
+        for (void *p : {(void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_}) if (p) (void)hipFree(p);
+        halo_count_ = (int64_t)h.send_idx.size();
+        d_send_idx_ = (int *)alloc(sizeof(int) * h.send_idx.size());
+        h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
+        // dense CSR over all boundary-slice dofs
+        std::vector<int> fptr((size_t)nb_dofs_ + 1, 0);
+        for (size_t k = 0; k < h.fix_dof.size(); ++k) fptr[h.fix_dof[k] + 1] = (int)(h.fix_ptr[k + 1] - h.fix_ptr[k]);
+        for (int64_t d = 0; d < nb_dofs_; ++d) fptr[d + 1] += fptr[d];
+        d_fptr_ = (int *)alloc(sizeof(int) * fptr.size());
+        h2d(d_fptr_, fptr.data(), sizeof(int) * fptr.size());
+        d_fpos_ = (int *)alloc(sizeof(int) * std::max<size_t>(1, h.fix_pos.size()));
+        h2d(d_fpos_, h.fix_pos.data(), sizeof(int) * h.fix_pos.size());
+    }
+
+    template <int RPL>
+    void launch_spmv(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_spmv<RPL, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
+                               d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+        else
+            hipLaunchKernelGGL((k_spmv<RPL, false>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
+                               d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+    }
+    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
+    {
+        if (hi <= lo) { if (with_dot) cnt_spmv_ = 0; return; }
+        const int grid = spmv_grid(hi - lo);
+        const bool rec = prof_ && ev_used_ < kMaxEv;
+        if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
+        if (C_ == 64) launch_spmv<1>(x, y, lo, hi, with_dot, grid);
+        else launch_spmv<2>(x, y, lo, hi, with_dot, grid);
+        HIP_CHECK(hipGetLastError());
+        if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (hi == n_slices_) ++ev_applies_; }
+        if (with_dot) cnt_spmv_ = grid;
+    }
+    void halo_pack(const double *y, double *send) override
+    {
+        if (!halo_count_) return;
+        int grid = (int)std::min<int64_t>((halo_count_ + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(kBlock), 0, st_, y, d_send_idx_, send, halo_count_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) override
+    {
+        if (!nb_dofs_) { if (with_dot) cnt_fix_ = 0; return; }
+        int grid = (int)std::min<int64_t>((nb_dofs_ + kBlock - 1) / kBlock, 1024);
+        if (with_dot)
+            hipLaunchKernelGGL((k_fixup<true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
+                               nb_dofs_, d_part_fix_);
+        else
+            hipLaunchKernelGGL((k_fixup<false>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
+                               nb_dofs_, d_part_fix_);
+        HIP_CHECK(hipGetLastError());
+        if (with_dot) cnt_fix_ = grid;
+    }
+    void begin_dot() override { cnt_spmv_ = cnt_fix_ = 0; }
+    void reduce_dot(double *red) override
+    {
+        hipLaunchKernelGGL((k_reduce<1>), dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
+                           cnt_fix_, red);
+        HIP_CHECK(hipGetLastError());
+    }
+    void scalar_alpha(double *st, double rho) override
+    {
+        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, rho);
+        HIP_CHECK(hipGetLastError());
+    }
+    void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
+    {
+        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, p, r, minv, beta, first ? 1 : 0, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void fused_update(const double *st, const double *p, const double *q, double *r, const double *xo, double *xn,
+                      const double *minv) override
+    {
+        cnt_vec_ = vec_grid(n_);
+        hipLaunchKernelGGL(k_fused_update, dim3(cnt_vec_), dim3(kBlock), 0, st_, st, p, q, r, xo, xn, minv, d_flags_, d_part_, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void reduce_update(double *red5) override
+    {
+        hipLaunchKernelGGL((k_reduce<5>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5);
+        HIP_CHECK(hipGetLastError());
+    }
+    void residual(const double *b, const double *ax, double *r, const double *minv) override
+    {
+        cnt_vec_ = vec_grid(n_);
+        hipLaunchKernelGGL(k_residual, dim3(cnt_vec_), dim3(kBlock), 0, st_, b, ax, r, minv, d_flags_, d_part_, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void reduce_residual(double *red3) override
+    {
+        hipLaunchKernelGGL((k_reduce<3>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3);
+        HIP_CHECK(hipGetLastError());
+    }
+    void dot_w(const double *a, const double *b) override
+    {
+        cnt_vec_ = vec_grid(n_);
+        hipLaunchKernelGGL(k_dot_w, dim3(cnt_vec_), dim3(kBlock), 0, st_, a, b, d_flags_, d_part_, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void reduce_dotw(double *red1) override
+    {
+        hipLaunchKernelGGL((k_reduce<1>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1);
+        HIP_CHECK(hipGetLastError());
+    }
+    void copy_diag(double *d) override { d2d(d, d_diag_, sizeof(double) * (size_t)n_); }
+    void invert_free(double *minv, const double *d) override
+    {
+        hipLaunchKernelGGL(k_invert_free, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, minv, d, d_flags_, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void axpby(double *o, double a, const double *x, double b, const double *y) override
+    {
+        hipLaunchKernelGGL(k_axpby, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, o, a, x, b, y, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void scale(double *o, double a, const double *x) override
+    {
+        hipLaunchKernelGGL(k_scale, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, o, a, x, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void mask_free(double *x) override
+    {
+        hipLaunchKernelGGL(k_mask_free, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, x, d_flags_, n_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void set_profiling(bool on) override
+    {
+        prof_ = on;
+        if (on && ev0_.empty()) {
+            ev0_.resize(kMaxEv); ev1_.resize(kMaxEv);
+            for (int k = 0; k < kMaxEv; ++k) { HIP_CHECK(hipEventCreate(&ev0_[k])); HIP_CHECK(hipEventCreate(&ev1_[k])); }
+        }
+        ev_used_ = 0; ev_applies_ = 0;
+    }
+    void collect_profile(double *ms_sum, int64_t *count) override
+    {
+        HIP_CHECK(hipStreamSynchronize(st_));
+        double s = 0;
+        for (int k = 0; k < ev_used_; ++k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0_[k], ev1_[k])); s += ms; }
+        *ms_sum = s; *count = ev_applies_;
+    }
+    int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
+    {
+        const int grid = spmv_grid(n_slices_);
+        for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, false, grid); else launch_spmv<2>(x, y, 0, n_slices_, false, grid); }
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        for (int k = 0; k < reps; ++k) {
+            HIP_CHECK(hipEventRecord(a, st_));
+            if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, false, grid); else launch_spmv<2>(x, y, 0, n_slices_, false, grid);
+            HIP_CHECK(hipEventRecord(b, st_));
+            HIP_CHECK(hipEventSynchronize(b));
+            HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));
+        }
+        HIP_CHECK(hipEventDestroy(a)); HIP_CHECK(hipEventDestroy(b));
+        return 0;
+    }
+};
+
+std::unique_ptr<Backend> make_backend(int device) { return std::unique_ptr<Backend>(new HipBackend(device)); }
+int backend_device_count()
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+const char *backend_static_name() { return "hip-gfx950"; }
+
+}  // namespace pcg

@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Import it
+# BEFORE dlopen-ing the engine so that both resolve to one runtime instance (streams and device
+# pointers are shared with torch.distributed in dist.py); torch itself is only plumbing here.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpcg_mi355x.so")
 

@@ -1,0 +1,57 @@
+"""The product library: builds for gfx950 without a GPU, exports every symbol declared in
+include/pcg_mi355x.h, has exactly one back end and refuses to run without a device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from util import ROOT
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    import __graft_entry__ as ge
+    return ge.build_engine()
+
+
+def test_header_symbols_exported(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "pcg_mi355x.h")).read()
+    declared = set(re.findall(r"\b(pcg_[a-z0-9_]+)\s*\(", hdr)) - {"pcg_comm_hooks"}
+    lib = ctypes.CDLL(product_lib)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from pcg_mi355x import _lib
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_product_has_only_the_hip_backend(product_lib):
+    lib = ctypes.CDLL(product_lib)
+    lib.pcg_backend_name.restype = ctypes.c_char_p
+    assert lib.pcg_backend_name() == b"hip-gfx950"
+    syms = subprocess.run(["nm", "-DC", product_lib], capture_output=True, text=True).stdout
+    assert "HostBackend" not in syms and "k_spmv" in subprocess.run(
+        ["strings", product_lib], capture_output=True, text=True).stdout
+
+
+def test_fails_loudly_without_gpu(product_lib):
+    lib = ctypes.CDLL(product_lib)
+    if lib.pcg_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import numpy as np
+    h = ctypes.c_void_p()
+    rp = np.array([0, 1], np.int64); c = np.zeros(1, np.int32); v = np.eye(3).ravel()
+    lib.pcg_create.argtypes = [ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int32,
+                                                                                           ctypes.POINTER(ctypes.c_void_p)]
+    rc = lib.pcg_create(0, 1, rp.ctypes.data, c.ctypes.data, v.ctypes.data, 0, 0, ctypes.byref(h))
+    lib.pcg_last_error.restype = ctypes.c_char_p
+    assert rc != 0 and b"no CPU fallback" in lib.pcg_last_error()
+
+
+def test_package_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pcg-mpi-solver_amd", "pcg_mi355x")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "pcg_oracle" not in src and "import oracle" not in src and "ref_shim" not in src, f

@@ -1,0 +1,78 @@
+"""PCG control flow (csrc/pcg_driver.cpp), drop-in key contract and error behaviour against the
+reference fixtures, on the CPU TEST DOUBLE back end (tests/hostops).  The HIP kernels themselves are
+covered by the -m gpu tests; this file pins everything around them without a GPU."""
+import numpy as np
+import pytest
+
+import golden_cases
+import pcg_mi355x as pm
+from util import golden, relerr, check_solution_against_golden
+
+SINGLE = [n for n, c in golden_cases.CASES.items() if c["grid"] == (1, 1, 1)]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_single_part_solve_matches_reference(hostops, name):
+    brick, parts = golden_cases.build_case(name)
+    g = golden(name)
+    P = parts[0]
+    pm.configure(comm=None)
+    x = golden_cases.probe_vector(brick)
+    assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
+    assert relerr(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"]) < 1e-14
+    pm.update_bc(P)
+    pm.update_preconditioner(P)
+    assert relerr(P["Fext"], g["Fext"]) < 1e-14
+    un_before = P["Un"].copy()
+    if str(g["raised"]):
+        with pytest.raises(Warning, match="TooSmallTolerance"):
+            pm.solve(P)
+        assert np.array_equal(P["Un"], un_before)                 # the reference leaves Un untouched when it raises
+        return
+    out = pm.solve(P, history=True)
+    info = P["_pcg_mi355x_info"]
+    if int(g["early"]):
+        assert out is not None and np.array_equal(P["Un"], un_before)     # :387-395 / :421-426 return a tuple
+        assert (out[1], out[3]) == (int(g["early_flag"]), int(g["early_iter"]))
+        assert abs(out[2] - float(g["early_relres"])) <= 1e-6 * float(g["early_relres"]) + 1e-300
+        assert relerr(out[0], g["early_x"]) < 1e-14 or np.abs(g["early_x"]).max() == 0
+        return
+    assert out is None
+    gd = P["GlobData"]
+    assert gd["TimeList_Flag"][1] == info.flag and gd["TimeList_Iter"][1] == info.iter
+    tol_u = 1e-8 if info.flag == 0 else 1e-6
+    check_solution_against_golden(g, info.flag, info.iter, info.relres, P["Un"], info.history, tol_u=tol_u)
+    assert gd["MP_TimeRecData"]["dT_Calc"] > 0
+
+
+def test_functional_api_and_resume(hostops):
+    """solve_system() + begin/run/end in several chunks gives the identical result."""
+    brick, parts = golden_cases.build_case("n9_p1")
+    P = parts[0]
+    op = pm.get_operator(P)
+    fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+    inv = op.build_jacobi()
+    x1, info = pm.solve_system(op, fext, None, None, 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    op.solve_begin(fext, None, inv, 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    for _ in range(1000):
+        r = op.solve_run(7)
+        if r.status != 4 or r.iters_done >= 118:
+            break
+    op.solve_run(-1)
+    x2, res = op.solve_end()
+    assert (info.flag, info.iter) == (res.flag, res.iter) == (0, 118)
+    assert np.array_equal(x1, x2)
+
+
+def test_missing_preconditioner_is_an_error(hostops):
+    _, parts = golden_cases.build_case("n9_p1")
+    op = pm.get_operator(parts[0])
+    with pytest.raises(pm.PcgError):
+        op.solve(parts[0]["RefLoadVector"])
+
+
+def test_neighbours_without_comm_is_an_error(hostops):
+    _, parts = golden_cases.build_case("n9_p2")
+    pm.configure(comm=None)
+    with pytest.raises(pm.PcgError):
+        pm.get_operator(parts[0])

@@ -1,0 +1,63 @@
+"""The oracle (oracle/pcg_oracle.py) against the fixtures produced by the REFERENCE's own functions
+(oracle/make_golden.py asserted bit-equality in the build container; here a tight tolerance, since a
+different BLAS build may round the dgemm differently)."""
+import copy
+
+import numpy as np
+import pytest
+
+import golden_cases
+import pcg_oracle
+from util import golden, relerr, to_global
+
+CASES = list(golden_cases.CASES)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_fixture(name):
+    brick, parts = golden_cases.build_case(name)
+    g = golden(name)
+    xg = golden_cases.probe_vector(brick)
+    ys = pcg_oracle.calc_matvec(parts, [xg[p["DofVector"]] for p in parts])
+    assert relerr(to_global(brick, parts, ys), g["y_probe"]) < 1e-13
+    ds = pcg_oracle.calc_matvec(parts, None, "Preconditioner")
+    assert relerr(to_global(brick, parts, ds), g["diag"]) < 1e-14
+    raised = ""
+    try:
+        out = pcg_oracle.solve_step(parts)
+    except pcg_oracle.TooSmallTolerance as w:
+        raised = str(w)
+    assert raised == str(g["raised"])
+    assert relerr(to_global(brick, parts, "Fext"), g["Fext"]) < 1e-13
+    if raised:
+        return
+    if int(g["early"]):
+        e = out["early"][0]
+        assert (e[1], e[3]) == (int(g["early_flag"]), int(g["early_iter"]))
+        assert abs(float(e[2]) - float(g["early_relres"])) <= 1e-6 * abs(float(g["early_relres"])) + 1e-300
+        return
+    assert out["flag"] == int(g["flag"])
+    assert out["iter"] == int(g["iter"])
+    assert relerr(to_global(brick, parts, "Un"), g["Un"]) < 1e-9
+    m = min(100, len(g["history"]))
+    assert np.abs(out["history"][:m, 2] / g["history"][:m, 2] - 1).max() < 1e-10
+
+
+def test_oracle_c_kernel_matches_numpy(oracle_c):
+    brick, parts = golden_cases.build_case("n13_t3_p4_ud")
+    xg = golden_cases.probe_vector(brick)
+    for p in parts:
+        x = xg[p["DofVector"]]
+        a = pcg_oracle.matvec_local(p, x)
+        b = pcg_oracle.matvec_local(p, x, use_c=True)
+        assert relerr(b, a) < 1e-14
+
+
+def test_oracle_c_solve_equals_numpy_solve(oracle_c):
+    _, pa = golden_cases.build_case("n9_p2")
+    pb = copy.deepcopy(pa)
+    oa = pcg_oracle.solve_step(pa)
+    ob = pcg_oracle.solve_step(pb, use_c=True)
+    assert (oa["flag"], oa["iter"]) == (ob["flag"], ob["iter"])
+    for a, b in zip(pa, pb):
+        assert relerr(b["Un"], a["Un"]) < 1e-9
