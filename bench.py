@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py - PCG iterations/sec + SpMV achieved HBM GB/s on the BASELINE.json workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE full PCG iteration of the reference algorithm (src/solver/pcg_solver.py:438-562:
+operator apply + interface exchange, the weighted dots, the vector updates, the status read-back)
+on the synthetic 10M-DOF elasticity brick of SURVEY.md 8(d) (N=150 nodes per side, n=10 125 000,
+nnz=809 238 528), with every input already resident in HBM.  W warm-up iterations, then exactly K
+timed iterations between barrier+synchronize fences; the max over ranks is reported.  N>1 runs the
+SAME 10M system split into N parts, one part per GPU (strong scaling, BASELINE configs[3]).
+
+Extra objects on the JSON line:
+  roofline     - the SpMV kernel (dominant): ALGORITHMIC bytes 12*nnz + 20*n (the stored
+                 SELL-BSR3 format moves fewer bytes, reported as impl_*) / mean kernel time measured
+                 with HIP events on the engine stream inside the timed region; peak 8 TB/s.
+  cpu_baseline - the oracle (C port of the reference's EBE mat-vec + NumPy vector ops, 1 thread, as
+                 the reference pins its BLAS) timed on a bounded sample of the same system.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "pcg-mpi-solver_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(k, "1")          # the reference's mode (pcg_solver.py:10-15); set before NumPy loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(part, budget_s=20.0):
+    """Reference algorithm on the host: oracle (kind 'port'), 1 rank x 1 thread, bounded sample."""
+    import copy
+    import subprocess
+    import pcg_oracle
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    P = {k: v for k, v in part.items() if not k.startswith("_pcg_mi355x")}
+    P["GlobData"] = copy.deepcopy(part["GlobData"])
+    P["Un"] = np.zeros(P["NDOF"])
+    t0 = time.perf_counter()
+    pcg_oracle.update_bc([P], use_c=True)                 # one mat-vec: calibrates the sample size
+    t_mv = time.perf_counter() - t0
+    pcg_oracle.update_preconditioner([P])
+    m = int(max(3, min(50, budget_s / max(t_mv * 1.25, 1e-3))))
+    P["GlobData"]["MaxIter"] = m
+    t0 = time.perf_counter()
+    out = pcg_oracle.pcg([P], use_c=True, record=False)
+    t = time.perf_counter() - t0
+    return {"value": m / t, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} PCG iterations of the same system (MaxIter={m}, {out['n_matvec']} EBE mat-vecs incl. "
+                      f"initial and final residual), oracle/pcg_oracle.py + oracle/ebe_matvec.c, 1 thread",
+            "matvec_ms": t_mv * 1e3, "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nodes-per-side", type=int, default=int(os.environ.get("PCG_BENCH_N", "150")),
+                    help="brick size N (150 -> 10M dof = the metric's configuration; 70 -> 1M; 322 -> 100M)")
+    ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pcg_mi355x as pm
+    from pcg_mi355x import _lib
+    from pcg_mi355x.brick import Brick, make_parts, block_partition, default_grid
+    from pcg_mi355x.dist import TorchComm
+    _lib.use_library(None)
+    assert _lib.backend_name() == "hip-gfx950"
+    if world > 1:
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+    pm.configure(comm=comm, device=local_rank, rows_per_lane=args.rows_per_lane)
+
+    N = args.nodes_per_side
+    t0 = time.perf_counter()
+    brick = Brick(N, seed=0)
+    grid = default_grid(world)
+    part = make_parts(brick, block_partition(brick, *grid) if world > 1 else None, only=[rank])[0]
+    t_parts = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    op = pm.get_operator(part)                       # native host assembly + upload (set-up, not timed)
+    t_asm = time.perf_counter() - t0
+    info = op.matrix_info()
+    if rank == 0:
+        log(f"brick N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
+            f"RefMeshPart {t_parts:.1f}s, assemble+upload {t_asm:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
+            f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
+
+    pm.update_bc(part)                               # Fext  (:226-238)
+    pm.update_preconditioner(part)                   # Jacobi (:346-352)
+    # sanity (not timed): A . rigid translation == 0 on rows away from the interface
+    if world == 1:
+        t = np.zeros(op.n); t[2::3] = 1.0
+        rb = np.abs(op.apply(t)).max()
+        log(f"self-check |A.t_z|_max = {rb:.2e}")
+        assert rb < 1e-9
+
+    gd = part["GlobData"]
+    eff = np.asarray(part["LocDofEff"], np.int64)
+    inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
+    max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + 1)
+    op.solve_begin(part["Fext"], part["Un"], inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
+    r = op.solve_run(args.warmup)
+    assert r.status == 4 and r.iters_done == args.warmup, "solve ended inside the warm-up window"
+    op.set_profiling(True)                            # HIP events around every SpMV launch from here on
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    r = op.solve_run(args.steps)                      # exactly K PCG iterations
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert r.iters_done == args.warmup + args.steps and r.status == 4, \
+        f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
+    spmv_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
+    n_spmv = int(r.spmv_count)
+    op.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- not timed: finish the solve (convergence evidence) and the stand-alone SpMV sweep ----------
+    final = None
+    if not args.no_finish:
+        t0 = time.perf_counter()
+        op.solve_run(-1)
+        x, res = op.solve_end()
+        final = {"flag": int(res.flag), "iter": int(res.iter), "relres": float(res.relres),
+                 "n_matvec": int(res.n_matvec), "solve_s": time.perf_counter() - t0 + elapsed}
+    else:
+        op.solve_end()
+    standalone = None
+    if world == 1:
+        ms = op.bench_spmv(10, 100)
+        standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    n_loc, nnz_loc = op.n, op.nnz
+    alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                     # f64 val + i32 col per nnz; x, y, i32 rowptr
+    impl_bytes = info["stored_blocks"] * (72.0 + 4.0) + 16.0 * n_loc + 8.0 * (info["n_slices"] + 1)
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    iters_per_s = args.steps / elapsed
+    iter_bytes = alg_bytes + 176.0 * n_loc                         # SURVEY 8(d) B_iter
+    out = {
+        "metric": "PCG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3D elastostatic CSR",
+        "value": iters_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic 3D elasticity brick N={N} ({brick.n_dof} dof, {brick.nnz} nnz), Jacobi-PCG Tol 1e-7, "
+                               f"{world} part(s) {grid[0]}x{grid[1]}x{grid[2]}",
+                   "dofs": brick.n_dof, "nnz": brick.nnz, "parts": world, "format": f"SELL-{info['slice_rows']} over 3x3 blocks",
+                   "spmv_achieved_GBps": achieved, "iter_algorithmic_GBps": iter_bytes * world / (elapsed / args.steps) / 1e9},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL-BSR3 SpMV + fused p.Ap)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": n_spmv,
+                     "impl_bytes_per_launch": impl_bytes, "impl_achieved": impl_bytes / (spmv_ms * 1e-3) / 1e9,
+                     "impl_frac": impl_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "standalone_spmv": standalone},
+        "solve": final,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        log("timing the CPU baseline (oracle port, 1 thread) ...")
+        out["cpu_baseline"] = cpu_baseline(part)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,16 +154,26 @@ def glob_settings(brick: Brick, tol: float = 1e-7, max_iter: int = 10000) -> dic
 
 
 def make_parts(brick: Brick, elem_part: np.ndarray | None = None, tol: float = 1e-7,
-               max_iter: int = 10000, index_dtype=np.int64) -> list[dict]:
-    """RefMeshPart dicts, one per part (reference exports these per part: partition_mesh.py:1310-1317)."""
+               max_iter: int = 10000, index_dtype=np.int64, only=None) -> list[dict]:
+    """RefMeshPart dicts, one per part (reference exports these per part: partition_mesh.py:1310-1317).
+
+    only: iterable of part ids to build (default all) - a rank of a multi-GPU job builds just its own
+    part; the neighbours' node sets it needs for the overlap lists are cheap boolean masks."""
     if elem_part is None:
         elem_part = np.zeros(brick.n_elem, np.int32)
     n_parts = int(elem_part.max()) + 1
+    only = list(range(n_parts)) if only is None else [int(k) for k in only]
     F = brick.load_vector()
     fixed = np.zeros(brick.n_dof, bool)
     fixed[brick.fixed_dofs()] = True
+    node_mask = []
+    if n_parts > 1:
+        for pid in range(n_parts):
+            m = np.zeros(brick.n_node, bool)
+            m[brick.elem_nodes(np.flatnonzero(elem_part == pid)).ravel()] = True
+            node_mask.append(m)
     parts = []
-    for pid in range(n_parts):
+    for pid in only:
         eids = np.flatnonzero(elem_part == pid)                      # ascending element ids
         gnodes = brick.elem_nodes(eids)                              # (Ne, 8)
         if n_parts == 1:
@@ -219,17 +229,17 @@ def make_parts(brick: Brick, elem_part: np.ndarray | None = None, tol: float = 1
     # ascending part id (identify_PotentialNeighbours loops `for MP_Id_j in range(N_TotalMeshPart)`)
     ref_dir = np.arange(3)[:, None]
     for p in parts:
-        for q in parts:
-            if q["Id"] == p["Id"]:
+        for qid in range(n_parts):
+            if qid == p["Id"] or n_parts == 1:
                 continue
-            ov = np.intersect1d(p["NodeIdVector"], q["NodeIdVector"], assume_unique=True)
+            ov = np.flatnonzero(node_mask[p["Id"]] & node_mask[qid])             # = intersect1d (:822), ascending
             if len(ov) == 0:
                 continue
             loc = np.searchsorted(p["NodeIdVector"], ov)
             p["OvrlpLocalNodeIdVecList"].append(loc)
             p["OvrlpLocalDofVecList"].append((3 * loc + ref_dir).T.ravel())      # :826 node-major
-            p["NbrMPIdVector"].append(q["Id"])
-            if p["Id"] > q["Id"]:                                                 # :885-887
+            p["NbrMPIdVector"].append(qid)
+            if p["Id"] > qid:                                                     # :885-887
                 p["DofWeightVector"][p["OvrlpLocalDofVecList"][-1]] = 0
                 p["NodeWeightVector"][loc] = 0
         p["N_NbrDof"] = int(sum(len(v) for v in p["OvrlpLocalDofVecList"]))
