@@ -81,7 +81,8 @@ def test_vector_kernels_vs_numpy(gpu_lib):
         assert abs(a - c) <= 1e-13 * max(1.0, abs(c))
     # inf detection (:448)
     m2 = m.copy(); m2[P["LocDofEff"][3]] = np.inf
-    check(op._L.pcg_k_fused_update(op._h, alpha, p.ctypes.data, q.ctypes.data, r.copy().ctypes.data, x.ctypes.data,
+    r2 = r.copy()
+    check(op._L.pcg_k_fused_update(op._h, alpha, p.ctypes.data, q.ctypes.data, r2.ctypes.data, x.ctypes.data,
                                    xn.ctypes.data, m2.ctypes.data, sums.ctypes.data))
     assert sums[4] == 1.0
     # residual (:413-416)
@@ -149,8 +150,13 @@ def test_solve_vs_oracle_mid_size(gpu_lib, oracle_c, rpl):
     assert abs(info.iter - out["iter"]) <= max(2, out["iter"] // 100)
     assert info.relres <= 1e-7
     assert relerr(P["Un"], R["Un"]) < 1e-8
-    m = int(0.3 * len(out["history"]))
+    # comparable window: the oracle's own two summation orders (NumPy dgemm vs plain C loops, both CPU
+    # f64) drift apart by 2e-12 at iteration 87, 1.4e-10 at 100 and 1.4e-6 at 130 of the 437 iterations of
+    # this system, so 1e-10 is only meaningful over the first ~15 %.
+    m = int(0.15 * len(out["history"]))
     assert np.abs(info.history[:m, 2] / out["history"][:m, 2] - 1).max() < 1e-10
+    m2 = int(0.25 * len(out["history"]))
+    assert np.abs(info.history[:m2, 2] / out["history"][:m2, 2] - 1).max() < 1e-6
 
 
 def test_run_to_run_bit_reproducible(gpu_lib):
