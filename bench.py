@@ -194,6 +194,13 @@ def main():
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
     iters_per_s = args.steps / elapsed
     iter_bytes = alg_bytes + 176.0 * n_loc                         # SURVEY 8(d) B_iter
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per SpMV launch from the PMC passes (separate rocprofv3 runs, see profiles/pmc_traffic.json)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}")
+        if pmc and world == 1:
+            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+    except OSError:
+        pass
     out = {
         "metric": "PCG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3D elastostatic CSR",
         "value": iters_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +211,7 @@ def main():
                    "dofs": brick.n_dof, "nnz": brick.nnz, "parts": world, "format": f"SELL-{info['slice_rows']} over 3x3 blocks",
                    "spmv_achieved_GBps": achieved, "iter_algorithmic_GBps": iter_bytes * world / (elapsed / args.steps) / 1e9},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL-BSR3 SpMV + fused p.Ap)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": n_spmv,
                      "impl_bytes_per_launch": impl_bytes, "impl_achieved": impl_bytes / (spmv_ms * 1e-3) / 1e9,
                      "impl_frac": impl_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -67,25 +67,26 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* NV * k
     }
 }
 
-// out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] for v==0 when pb != null)
-template <int NV>
+// out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x.
+// One block per value; every thread keeps 4 independent partial sums (loads in flight), then a
+// fixed wave/LDS tree -> deterministic.
 __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
                                                    const double *__restrict__ pb, int count_b, double *out)
 {
-    __shared__ double lds[NV * kWavesPerBlock];
-    double v[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < count_a; b += kBlock) s += pa[(size_t)k * stride + b];
-        if (k == 0 && pb)
-            for (int b = threadIdx.x; b < count_b; b += kBlock) s += pb[b];
-        v[k] = s;
+    __shared__ double lds[kWavesPerBlock];
+    const int k = blockIdx.x;
+    const double *src = pa + (size_t)k * stride;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 3 * kBlock < count_a; b += 4 * kBlock) {
+        s0 += src[b]; s1 += src[b + kBlock]; s2 += src[b + 2 * kBlock]; s3 += src[b + 3 * kBlock];
     }
-    block_sum<NV>(v, lds);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < NV; ++k) out[k] = v[k];
+    for (; b < count_a; b += kBlock) s0 += src[b];
+    if (pb)
+        for (int c = threadIdx.x; c < count_b; c += kBlock) s1 += pb[c];
+    double v[1] = {(s0 + s1) + (s2 + s3)};
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) out[k] = v[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                                                  const double *__restrict__ vals, const double *__restrict__ x,
                                                  double *__restrict__ y, const uint8_t *__restrict__ flags,
                                                  double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
-                                                 int64_t n_nodes)
+                                                 int64_t n_nodes, int xcd_aware)
 {
     constexpr int C = 64 * RPL;
     using DV = typename VecT<RPL>::d;
@@ -125,10 +126,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     // XCD-aware slice assignment: block b runs on XCD b & 7 (observed; speed only, never correctness).
     // Each XCD owns one contiguous eighth of the slice range and its waves sweep it together.
     const int64_t S = slice_hi - slice_lo;
-    const int xcd = blockIdx.x & 7;
-    const int64_t lb = blockIdx.x >> 3;
-    const int64_t blocks_per_xcd = (gridDim.x + 7 - xcd) >> 3;      // blocks with b&7 == xcd
-    const int64_t c_lo = slice_lo + (S * xcd) / 8, c_hi = slice_lo + (S * (xcd + 1)) / 8;
+    const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
+    const int64_t lb = xcd_aware ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t blocks_per_xcd = xcd_aware ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
+    const int64_t c_lo = xcd_aware ? slice_lo + (S * xcd) / 8 : slice_lo;
+    const int64_t c_hi = xcd_aware ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
     const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
     double dot = 0.0;
     for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
@@ -415,6 +417,8 @@ class HipBackend : public Backend {
         return (int)(g < 8 ? 8 : g);
     }
     int spmv_blocks_per_cu_ = 4;
+    int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
+    bool bench_dot_ = false;
 
 public:
     explicit HipBackend(int device)
@@ -434,7 +438,10 @@ public:
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
+        // development knobs (tools/tune_spmv.py); the defaults are the tuned values
         if (const char *e = getenv("PCG_SPMV_BLOCKS_PER_CU")) spmv_blocks_per_cu_ = std::max(1, atoi(e));
+        if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
+        if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
     }
     ~HipBackend() override
     {
@@ -507,10 +514,10 @@ public:
     {
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
-                               d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+                               d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
         else
             hipLaunchKernelGGL((k_spmv<RPL, false>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
-                               d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+                               d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
     }
     void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
     {
@@ -547,7 +554,7 @@ public:
     void begin_dot() override { cnt_spmv_ = cnt_fix_ = 0; }
     void reduce_dot(double *red) override
     {
-        hipLaunchKernelGGL((k_reduce<1>), dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
                            cnt_fix_, red);
         HIP_CHECK(hipGetLastError());
     }
@@ -570,7 +577,7 @@ public:
     }
     void reduce_update(double *red5) override
     {
-        hipLaunchKernelGGL((k_reduce<5>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5);
+        hipLaunchKernelGGL(k_reduce, dim3(5), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5);
         HIP_CHECK(hipGetLastError());
     }
     void residual(const double *b, const double *ax, double *r, const double *minv) override
@@ -581,7 +588,7 @@ public:
     }
     void reduce_residual(double *red3) override
     {
-        hipLaunchKernelGGL((k_reduce<3>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3);
+        hipLaunchKernelGGL(k_reduce, dim3(3), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3);
         HIP_CHECK(hipGetLastError());
     }
     void dot_w(const double *a, const double *b) override
@@ -592,7 +599,7 @@ public:
     }
     void reduce_dotw(double *red1) override
     {
-        hipLaunchKernelGGL((k_reduce<1>), dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1);
         HIP_CHECK(hipGetLastError());
     }
     void copy_diag(double *d) override { d2d(d, d_diag_, sizeof(double) * (size_t)n_); }
@@ -635,12 +642,13 @@ public:
     int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
     {
         const int grid = spmv_grid(n_slices_);
-        for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, false, grid); else launch_spmv<2>(x, y, 0, n_slices_, false, grid); }
+        const bool dot = bench_dot_;
+        for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y, 0, n_slices_, dot, grid); }
         hipEvent_t a, b;
         HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
         for (int k = 0; k < reps; ++k) {
             HIP_CHECK(hipEventRecord(a, st_));
-            if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, false, grid); else launch_spmv<2>(x, y, 0, n_slices_, false, grid);
+            if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y, 0, n_slices_, dot, grid);
             HIP_CHECK(hipEventRecord(b, st_));
             HIP_CHECK(hipEventSynchronize(b));
             HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));

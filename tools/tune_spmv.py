@@ -47,16 +47,20 @@ alg = 12.0 * brick.nnz + 20.0 * brick.n_dof
 res["alg_bytes"] = alg
 res["runs"] = []
 for rpl in (1, 2):
-    for bpc in (2, 4, 6, 8):
-        os.environ["PCG_SPMV_BLOCKS_PER_CU"] = str(bpc)
-        op = Operator(brick.n_node, rp, c, v, 0, None, 0, rpl)
-        info = op.matrix_info()
-        ms = op.bench_spmv(5, 30)
-        impl = info["stored_blocks"] * 76.0 + 16.0 * brick.n_dof
-        r = {"rpl": rpl, "blocks_per_cu": bpc, "min_ms": float(ms.min()), "med_ms": float(np.median(ms)),
-             "alg_GBps": alg / (float(np.median(ms)) * 1e-3) / 1e9, "impl_GBps": impl / (float(np.median(ms)) * 1e-3) / 1e9,
-             "padding": info["stored_blocks"] / info["nnzb"] - 1}
-        res["runs"].append(r)
-        print(r, file=sys.stderr, flush=True)
-        op.close()
+    for dot in (0, 1):
+        for xcd in (1, 0):
+            for bpc in (4,):
+                os.environ["PCG_SPMV_BLOCKS_PER_CU"] = str(bpc)
+                os.environ["PCG_SPMV_XCD"] = str(xcd)
+                os.environ["PCG_BENCH_SPMV_DOT"] = str(dot)
+                op = Operator(brick.n_node, rp, c, v, 0, None, 0, rpl)
+                info = op.matrix_info()
+                ms = op.bench_spmv(5, 30)
+                impl = info["stored_blocks"] * 76.0 + 16.0 * brick.n_dof
+                r = {"rpl": rpl, "dot": dot, "xcd_aware": xcd, "blocks_per_cu": bpc, "min_ms": float(ms.min()),
+                     "med_ms": float(np.median(ms)), "alg_GBps": alg / (float(np.median(ms)) * 1e-3) / 1e9,
+                     "impl_GBps": impl / (float(np.median(ms)) * 1e-3) / 1e9, "padding": info["stored_blocks"] / info["nnzb"] - 1}
+                res["runs"].append(r)
+                print(r, file=sys.stderr, flush=True)
+                op.close()
 print(json.dumps(res))
