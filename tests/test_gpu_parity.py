@@ -191,6 +191,41 @@ def test_full_size_1m_properties(gpu_lib, oracle_c):
     assert np.linalg.norm(r) / np.linalg.norm(P["Fext"][eff]) <= 1.0e-7 * 1.01
 
 
+def test_full_size_10m_properties(gpu_lib, oracle_c):
+    """The metric's configuration (N=150, 10 125 000 dof, 809 238 528 nnz): size-independent properties
+    of the operator, oracle parity of one mat-vec, and 300 PCG iterations whose recurrence residual must
+    equal the TRUE residual b - A x recomputed by the oracle (CPU) at that iterate."""
+    b = Brick(150)
+    assert (b.n_dof, b.nnz) == (10125000, 809238528)
+    P = make_parts(b)[0]
+    op = pm.get_operator(P)
+    assert op.nnz == b.nnz
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(b.n_dof), rng.standard_normal(b.n_dof)
+    ax, ay = op.apply(x), op.apply(y)
+    assert relerr(ax, pcg_oracle.matvec_local(P, x, use_c=True)) < 1e-13             # oracle parity at full size
+    assert relerr(op.apply(0.5 * x + 4.0 * y), 0.5 * ax + 4.0 * ay) < 1e-13           # linearity
+    assert abs(np.dot(y, ax) - np.dot(x, ay)) <= 1e-12 * np.dot(np.abs(y), np.abs(ax))  # symmetry
+    for d in range(3):                                                               # rigid translations
+        t = np.zeros(b.n_dof); t[d::3] = 1.0
+        assert np.abs(op.apply(t)).max() < 1e-9
+    assert np.dot(x, ax) > 0                                                          # positive (semi-)definite
+    pm.update_bc(P); pm.update_preconditioner(P)
+    diag = pm.calc_matvec_prod(P, "Preconditioner")
+    assert relerr(diag, pcg_oracle.matvec_local(P, None, "Preconditioner")) < 1e-14
+    eff = P["LocDofEff"]
+    inv = np.zeros(b.n_dof); inv[eff] = P["InvDiagPreCondVector0"]
+    hist = np.zeros((300, 3))
+    op.solve_begin(P["Fext"], None, inv, 1e-7, 300, P["GlobData"]["GlobNDofEff"])
+    op.solve_run(-1, hist)
+    xk, res = op.solve_end()
+    assert res.flag == 1 and res.iters_done == 300                                    # MaxIter exit (:438)
+    r_true = (P["Fext"] - pcg_oracle.matvec_local(P, xk, use_c=True))[eff]
+    nb = np.linalg.norm(P["Fext"][eff])
+    assert abs(np.linalg.norm(r_true) / nb - res.relres) <= 1e-9 * res.relres + 1e-12
+    assert res.relres < hist[0, 2] / nb
+
+
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     """The RCCL comm hooks on the GPU (world_size 1 on the 1-GPU box): device-pointer views, the
     engine stream as ExternalStream, all_reduce in place.  Must equal the hook-free run."""
