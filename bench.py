@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--nodes-per-side", type=int, default=int(os.environ.get("PCG_BENCH_N", "150")),
                     help="brick size N (150 -> 10M dof = the metric's configuration; 70 -> 1M; 322 -> 100M)")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
+    ap.add_argument("--operator", choices=["sell", "ebe", "both"], default="both",
+                    help="sell = assembled SELL-BSR3 matrix (the headline value/roofline); both = also time the matrix-free operator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
     args = ap.parse_args()
@@ -120,32 +122,6 @@ def main():
     grid = default_grid(world)
     part = make_parts(brick, block_partition(brick, *grid) if world > 1 else None, only=[rank])[0]
     t_parts = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    op = pm.get_operator(part)                       # native host assembly + upload (set-up, not timed)
-    t_asm = time.perf_counter() - t0
-    info = op.matrix_info()
-    if rank == 0:
-        log(f"brick N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
-            f"RefMeshPart {t_parts:.1f}s, assemble+upload {t_asm:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
-            f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
-
-    pm.update_bc(part)                               # Fext  (:226-238)
-    pm.update_preconditioner(part)                   # Jacobi (:346-352)
-    # sanity (not timed): A . rigid translation == 0 on rows away from the interface
-    if world == 1:
-        t = np.zeros(op.n); t[2::3] = 1.0
-        rb = np.abs(op.apply(t)).max()
-        log(f"self-check |A.t_z|_max = {rb:.2e}")
-        assert rb < 1e-9
-
-    gd = part["GlobData"]
-    eff = np.asarray(part["LocDofEff"], np.int64)
-    inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
-    max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + 1)
-    op.solve_begin(part["Fext"], part["Un"], inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
-    r = op.solve_run(args.warmup)
-    assert r.status == 4 and r.iters_done == args.warmup, "solve ended inside the warm-up window"
-    op.set_profiling(True)                            # HIP events around every SpMV launch from here on
 
     def fence():
         torch.cuda.synchronize()
@@ -153,42 +129,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    r = op.solve_run(args.steps)                      # exactly K PCG iterations
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert r.iters_done == args.warmup + args.steps and r.status == 4, \
-        f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
-    spmv_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
-    n_spmv = int(r.spmv_count)
-    op.set_profiling(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- not timed: finish the solve (convergence evidence) and the stand-alone SpMV sweep ----------
-    final = None
-    if not args.no_finish:
+    def measure(kind):
+        """Set up the operator of `kind`, run W warm-up + K timed PCG iterations, finish the solve."""
+        part.pop("_pcg_mi355x_operator", None)
+        pm.configure(comm=comm, device=local_rank, rows_per_lane=args.rows_per_lane, operator=kind)
         t0 = time.perf_counter()
-        op.solve_run(-1)
-        x, res = op.solve_end()
-        final = {"flag": int(res.flag), "iter": int(res.iter), "relres": float(res.relres),
-                 "n_matvec": int(res.n_matvec), "solve_s": time.perf_counter() - t0 + elapsed}
-    else:
-        op.solve_end()
-    standalone = None
-    if world == 1:
-        ms = op.bench_spmv(10, 100)
-        standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
+        op = pm.get_operator(part)                   # native host set-up + upload (not timed)
+        t_setup = time.perf_counter() - t0
+        pm.update_bc(part)                           # Fext  (:226-238)
+        pm.update_preconditioner(part)               # Jacobi (:346-352)
+        if world == 1:                               # sanity (not timed): A . rigid translation == 0
+            t = np.zeros(op.n); t[2::3] = 1.0
+            rb = np.abs(op.apply(t)).max()
+            log(f"[{kind}] set-up {t_setup:.1f}s; self-check |A.t_z|_max = {rb:.2e}")
+            assert rb < 1e-9
+        gd = part["GlobData"]
+        eff = np.asarray(part["LocDofEff"], np.int64)
+        inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
+        max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + 1)
+        op.solve_begin(part["Fext"], np.zeros(op.n), inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
+        r = op.solve_run(args.warmup)
+        assert r.status == 4 and r.iters_done == args.warmup, "solve ended inside the warm-up window"
+        op.set_profiling(True)                        # HIP events around every operator launch from here on
+        fence()
+        t0 = time.perf_counter()
+        r = op.solve_run(args.steps)                  # exactly K PCG iterations
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert r.iters_done == args.warmup + args.steps and r.status == 4, \
+            f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
+        op_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
+        n_op = int(r.spmv_count)
+        op.set_profiling(False)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        final = None
+        if not args.no_finish:                        # not timed: convergence evidence
+            t0 = time.perf_counter()
+            op.solve_run(-1)
+            x, res = op.solve_end()
+            final = {"flag": int(res.flag), "iter": int(res.iter), "relres": float(res.relres),
+                     "n_matvec": int(res.n_matvec), "solve_s": time.perf_counter() - t0 + elapsed}
+        else:
+            op.solve_end()
+        standalone = None
+        if world == 1:
+            ms = op.bench_spmv(10, 100)
+            standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
+        return {"op": op, "elapsed": elapsed, "op_ms": op_ms, "n_op": n_op, "final": final, "standalone": standalone,
+                "t_setup": t_setup}
+
+    m = measure("sell")
+    op, elapsed, spmv_ms, n_spmv, final, standalone = m["op"], m["elapsed"], m["op_ms"], m["n_op"], m["final"], m["standalone"]
+    info = op.matrix_info()
+    if rank == 0:
+        log(f"brick N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
+            f"RefMeshPart {t_parts:.1f}s, assemble+upload {m['t_setup']:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
+            f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
+    n_loc, nnz_loc = op.n, op.nnz
+    matrix_free = None
+    if args.operator in ("both", "ebe"):
+        op.close()
+        e = measure("ebe")
+        oi = e["op"].operator_info()
+        matrix_free = {"note": "SURVEY 8(f)-1: the reference's element-by-element operator kept matrix-free (k_ebe, colour-ordered, "
+                               "deterministic); same PCG driver, same inputs", "value": args.steps / e["elapsed"],
+                       "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3, "operator_avg_ms": e["op_ms"],
+                       "operator_launches_timed": e["n_op"], "colors": oi["n_colors"], "n_elem": oi["n_elem"],
+                       "standalone_operator": e["standalone"], "solve": e["final"],
+                       "flops_per_apply": 2.0 * 24 * oi["n_slots"], "achieved_TFLOPs": 2.0 * 24 * oi["n_slots"] / (e["op_ms"] * 1e-3) / 1e12,
+                       "csr_equivalent_GBps": (12.0 * nnz_loc + 20.0 * n_loc) / (e["op_ms"] * 1e-3) / 1e9}
+        e["op"].close()
 
     if rank != 0:
         if world > 1:
             dist.barrier(); dist.destroy_process_group()
         return
 
-    n_loc, nnz_loc = op.n, op.nnz
     alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                     # SURVEY 8(d): f64 val + i32 col per nnz; x, y, i32 rowptr
     impl_bytes = info["stored_blocks"] * (72.0 + 4.0) + 16.0 * n_loc + 8.0 * (info["n_slices"] + 1)
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
@@ -217,6 +236,7 @@ def main():
                      "impl_frac": impl_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "standalone_spmv": standalone},
         "solve": final,
+        "matrix_free": matrix_free,
     }
     if not args.no_cpu_baseline and world == 1:
         log("timing the CPU baseline (oracle port, 1 thread) ...")

@@ -189,6 +189,81 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
 }
 
 // ------------------------------------------------------------------------------------------------
+// Matrix-free operator (the reference's element-by-element form, pcg_solver.py:277-280 + :300).
+// One thread per element of ONE colour (no two elements of a launch share a node -> plain
+// read-modify-write of y, no atomics, summation order = colour order).  All lanes of a wave work on
+// the same pattern type, so Ke[a][b] is wave-uniform: it is fetched with scalar loads into SGPRs and
+// used as the scalar operand of v_fma_f64 - no LDS, no per-lane copy of the 24x24 matrix.  Four
+// output rows are accumulated at a time (independent FMA chains).
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, const unsigned *__restrict__ sgn,
+                                                const double *__restrict__ ck, const double *__restrict__ ke,
+                                                const double *__restrict__ x, double *__restrict__ y, int64_t ne,
+                                                int64_t e_lo, int64_t e_hi)
+{
+    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (e >= e_hi) return;
+    int d[ND];
+    double u[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a) d[a] = __builtin_nontemporal_load(dof + (size_t)a * ne + e);
+    const unsigned sg = __builtin_nontemporal_load(sgn + e);
+    const double c = __builtin_nontemporal_load(ck + e);
+#pragma unroll
+    for (int b = 0; b < ND; ++b) {
+        double v = x[d[b]];                                  // :277 gather
+        if ((sg >> b) & 1u) v = -v;                          // :278
+        u[b] = c * v;                                        // :279 Ck * U
+    }
+    static_assert(ND % 4 == 0, "ND must be a multiple of 4");
+#pragma unroll
+    for (int a0 = 0; a0 < ND; a0 += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fma(ke[(a0 + i) * ND + b], u[b], acc[i]);   // :279 Ke @ (.)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double o = acc[i];
+            if ((sg >> (a0 + i)) & 1u) o = -o;               // :280
+            y[d[a0 + i]] += o;                               // :300 (conflict-free inside a colour)
+        }
+    }
+}
+
+// any nd (hanging-node patterns): same algorithm, x re-gathered per block of 4 output rows
+__global__ __launch_bounds__(kBlock) void k_ebe_generic(const int *__restrict__ dof, const uint8_t *__restrict__ sgn,
+                                                        const double *__restrict__ ck, const double *__restrict__ ke,
+                                                        const double *__restrict__ x, double *__restrict__ y, int nd,
+                                                        int64_t ne, int64_t e_lo, int64_t e_hi)
+{
+    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (e >= e_hi) return;
+    const double c = ck[e];
+    for (int a0 = 0; a0 < nd; a0 += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < nd; ++b) {
+            double v = x[dof[(size_t)b * ne + e]];
+            if (sgn[(size_t)b * ne + e]) v = -v;
+            v = c * v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (a0 + i < nd) acc[i] = fma(ke[(size_t)(a0 + i) * nd + b], v, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (a0 + i < nd) {
+                double o = acc[i];
+                if (sgn[(size_t)(a0 + i) * ne + e]) o = -o;
+                y[dof[(size_t)(a0 + i) * ne + e]] += o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // interface kernels
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__ y, const int *__restrict__ idx,
@@ -384,6 +459,11 @@ class HipBackend : public Backend {
     int *d_cols_ = nullptr;
     double *d_vals_ = nullptr, *d_diag_ = nullptr;
     uint8_t *d_flags_ = nullptr;
+    // matrix-free operator
+    struct EbeGroupDev { int nd; int64_t ne; int *dof; unsigned *sgn_bits; uint8_t *sgn_bytes; double *ck, *ke; };
+    std::vector<EbeGroupDev> ebe_groups_;
+    std::vector<EbeRange> ebe_ranges_[2];
+    bool ebe_ = false;
     // halo
     int *d_send_idx_ = nullptr, *d_fptr_ = nullptr, *d_fpos_ = nullptr;
     int64_t halo_count_ = 0, nb_dofs_ = 0;
@@ -450,6 +530,9 @@ public:
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
+        for (auto &D : ebe_groups_)
+            for (void *p : {(void *)D.dof, (void *)D.sgn_bits, (void *)D.sgn_bytes, (void *)D.ck, (void *)D.ke})
+                if (p) (void)hipFree(p);
         for (auto e : ev0_) (void)hipEventDestroy(e);
         for (auto e : ev1_) (void)hipEventDestroy(e);
         if (st_) (void)hipStreamDestroy(st_);
@@ -492,11 +575,62 @@ public:
         h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * 3);
     }
+    void upload_ebe(const EbeHost &m) override
+    {
+        ebe_ = true;
+        n_nodes_ = m.n_nodes; n_ = 3 * m.n_nodes;
+        d_diag_ = (double *)alloc(sizeof(double) * m.diag.size());
+        h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
+        d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
+        for (const auto &G : m.groups) {
+            EbeGroupDev D{G.nd, G.ne, nullptr, nullptr, nullptr, nullptr, nullptr};
+            D.dof = (int *)alloc(sizeof(int) * G.dof.size());
+            h2d(D.dof, G.dof.data(), sizeof(int) * G.dof.size());
+            D.ck = (double *)alloc(sizeof(double) * G.ck.size());
+            h2d(D.ck, G.ck.data(), sizeof(double) * G.ck.size());
+            D.ke = (double *)alloc(sizeof(double) * G.ke.size());
+            h2d(D.ke, G.ke.data(), sizeof(double) * G.ke.size());
+            if (G.nd == 24) {                                  // fast path: 24 sign bits per element in one word
+                std::vector<unsigned> bits((size_t)G.ne, 0u);
+                for (int a = 0; a < G.nd; ++a)
+                    for (int64_t e = 0; e < G.ne; ++e)
+                        if (G.sign[(size_t)a * G.ne + e]) bits[e] |= (1u << a);
+                D.sgn_bits = (unsigned *)alloc(sizeof(unsigned) * bits.size());
+                h2d(D.sgn_bits, bits.data(), sizeof(unsigned) * bits.size());
+            } else {
+                D.sgn_bytes = (uint8_t *)alloc(G.sign.size());
+                h2d(D.sgn_bytes, G.sign.data(), G.sign.size());
+            }
+            ebe_groups_.push_back(D);
+        }
+        for (int ph = 0; ph < 2; ++ph) ebe_ranges_[ph] = m.ranges[ph];
+    }
+    void ebe_launch_range(const EbeRange &r, const double *x, double *y)
+    {
+        const auto &D = ebe_groups_[r.group];
+        const int grid = (int)((r.hi - r.lo + kBlock - 1) / kBlock);
+        if (D.nd == 24)
+            hipLaunchKernelGGL((k_ebe<24>), dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bits, D.ck, D.ke, x, y, D.ne, r.lo, r.hi);
+        else
+            hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
+                               r.lo, r.hi);
+    }
+    void ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first) override
+    {
+        const bool rec = prof_ && ev_used_ < kMaxEv;
+        if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
+        if (zero_first) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
+        for (int ph = plo; ph < phi; ++ph)
+            for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);
+        HIP_CHECK(hipGetLastError());
+        if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (phi == 2) ++ev_applies_; }
+    }
     void upload_masks(const uint8_t *f, int64_t n) override { h2d(d_flags_, f, (size_t)n); }
     void upload_halo(const HaloHost &h) override
     {
         for (void *p : {(void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_}) if (p) (void)hipFree(p);
         halo_count_ = (int64_t)h.send_idx.size();
+        if (ebe_) nb_dofs_ = h.fix_dof.empty() ? 0 : (int64_t)h.fix_dof.back() + 1;
         d_send_idx_ = (int *)alloc(sizeof(int) * h.send_idx.size());
         h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
         // dense CSR over all boundary-slice dofs
@@ -641,6 +775,20 @@ public:
     }
     int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
     {
+        if (ebe_) {
+            for (int k = 0; k < warmup; ++k) ebe_apply(x, y, 0, 2, true);
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+            for (int k = 0; k < reps; ++k) {
+                HIP_CHECK(hipEventRecord(a, st_));
+                ebe_apply(x, y, 0, 2, true);
+                HIP_CHECK(hipEventRecord(b, st_));
+                HIP_CHECK(hipEventSynchronize(b));
+                HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));
+            }
+            HIP_CHECK(hipEventDestroy(a)); HIP_CHECK(hipEventDestroy(b));
+            return 0;
+        }
         const int grid = spmv_grid(n_slices_);
         const bool dot = bench_dot_;
         for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y, 0, n_slices_, dot, grid); }

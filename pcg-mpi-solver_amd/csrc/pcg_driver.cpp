@@ -38,7 +38,10 @@ struct pcg_engine {
     std::unique_ptr<Backend> be;
     int64_t n_nodes = 0, n = 0, n_slices = 0, n_bnd_slices = 0;
     int32_t C = 64;
-    int64_t nnzb = 0, stored_blocks = 0;
+    int32_t kind = 0;                 // 0 = assembled SELL-BSR3 operator, 1 = matrix-free (EBE)
+    int64_t n_bnd_dofs = 0;           // dofs [0, n_bnd_dofs) may receive interface contributions
+    int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
+    int32_t n_colors = 0;
     HaloHost halo;
     bool has_halo = false;
     bool has_masks = false;
@@ -116,6 +119,20 @@ struct pcg_engine {
     // the interior rows, then the neighbour contributions are added in neighbour order (:333-334).
     void apply(const double *x, double *y, bool with_dot)
     {
+        if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
+            if (!has_halo) {
+                be->ebe_apply(x, y, 0, 2, true);
+            } else {
+                be->ebe_apply(x, y, 0, 1, true);
+                be->halo_pack(y, d_send);
+                halo_begin();
+                be->ebe_apply(x, y, 1, 2, false);
+                halo_end();
+                be->boundary_fixup(y, d_recv, nullptr, false);
+            }
+            if (with_dot) be->dot_w(x, y);                    // :487 (y is complete only after the last colour)
+            return;
+        }
         if (with_dot) be->begin_dot();
         if (!has_halo) {
             be->spmv(x, y, 0, n_slices, with_dot);
@@ -135,6 +152,11 @@ struct pcg_engine {
         halo_begin();
         halo_end();
         be->boundary_fixup(y, d_recv, nullptr, false);
+    }
+    void reduce_apply_dot(double *out)
+    {
+        if (kind == 1) be->reduce_dotw(out);
+        else be->reduce_dot(out);
     }
     void read_status() { be->d2h(h_st, d_st, sizeof(double) * ST_COUNT); }
 
@@ -187,7 +209,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
     be.update_p(e->v_p, e->v_r, s.minv, beta, i == 0);
     e->apply(e->v_p, e->v_q, true);                            // :482-484
     s.n_matvec++;
-    be.reduce_dot(e->d_st + ST_PQ);                            // :487
+    e->reduce_apply_dot(e->d_st + ST_PQ);                      // :487
     e->allreduce(e->d_st + ST_PQ, 1);                          // :488
     be.scalar_alpha(e->d_st, s.rho);                           // :492-498 (device side)
     const int nx = e->pick_new_x();
@@ -291,6 +313,7 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->n = 3 * n_nodes;
         e->n_slices = m.n_slices;
         e->n_bnd_slices = m.n_bnd_slices;
+        e->n_bnd_dofs = std::min<int64_t>(3 * n_nodes, m.n_bnd_slices * m.C * 3);
         e->C = m.C;
         e->nnzb = m.nnzb;
         e->stored_blocks = m.slice_ptr.back() * m.C;
@@ -299,6 +322,35 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
         e->v_minv = e->vec();
         // default masks: every dof owned and free
+        std::vector<uint8_t> f((size_t)e->n, 3);
+        e->be->upload_masks(f.data(), e->n);
+        *out = e.release();
+        return 0;
+    });
+}
+
+int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
+                   const int64_t *node_perm, int64_t n_boundary_nodes, pcg_engine **out)
+{
+    return guarded("pcg_create_ebe", [&]() -> int {
+        if (!out || !groups || n_nodes <= 0 || n_groups <= 0 || n_nodes > INT32_MAX / 3)
+            return set_error("pcg_create_ebe: bad argument");
+        if (n_boundary_nodes < 0 || n_boundary_nodes > n_nodes) return set_error("pcg_create_ebe: bad n_boundary_nodes");
+        auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
+        e->be = make_backend(device);
+        EbeHost m;
+        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, m);
+        e->kind = 1;
+        e->n_nodes = n_nodes;
+        e->n = 3 * n_nodes;
+        e->n_bnd_dofs = 3 * n_boundary_nodes;
+        e->n_elem = m.n_elem;
+        e->n_slots = m.n_slots;
+        e->n_colors = std::max(m.n_colors[0], m.n_colors[1]);
+        e->be->upload_ebe(m);
+        e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
+        e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+        e->v_minv = e->vec();
         std::vector<uint8_t> f((size_t)e->n, 3);
         e->be->upload_masks(f.data(), e->n);
         *out = e.release();
@@ -330,7 +382,7 @@ int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const 
         h.send_ptr.assign(send_ptr, send_ptr + n_peers + 1);
         const int64_t tot = send_ptr[n_peers];
         h.send_idx.assign(send_idx, send_idx + tot);
-        const int64_t n_bnd_dofs = std::min<int64_t>(e->n, e->n_bnd_slices * e->C * 3);
+        const int64_t n_bnd_dofs = e->n_bnd_dofs;
         // per interface dof: receive slots in neighbour order (the order of the reference's `+=`, :333-334)
         std::vector<int64_t> cnt((size_t)n_bnd_dofs + 1, 0);
         for (int64_t m = 0; m < tot; ++m) {
@@ -576,6 +628,16 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
     });
 }
 
+int pcg_operator_info(pcg_engine *e, int32_t *kind, int64_t *n_elem, int64_t *n_slots, int32_t *n_colors)
+{
+    if (!e) return set_error("null");
+    if (kind) *kind = e->kind;
+    if (n_elem) *n_elem = e->n_elem;
+    if (n_slots) *n_slots = e->n_slots;
+    if (n_colors) *n_colors = e->n_colors;
+    return 0;
+}
+
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows)
 {
     if (!e) return set_error("null");
@@ -643,10 +705,15 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dx = e->scratch(0), *dy = e->scratch(1);
         e->be->h2d(dx, x, bytes);
-        if (pxy) e->be->begin_dot();
-        e->be->spmv(dx, dy, 0, e->n_slices, pxy != nullptr);
+        if (e->kind == 1) {
+            e->be->ebe_apply(dx, dy, 0, 2, true);
+            if (pxy) e->be->dot_w(dx, dy);
+        } else {
+            if (pxy) e->be->begin_dot();
+            e->be->spmv(dx, dy, 0, e->n_slices, pxy != nullptr);
+        }
         if (pxy) {
-            e->be->reduce_dot(e->d_st + ST_PQ);
+            e->reduce_apply_dot(e->d_st + ST_PQ);
             e->read_status();
             *pxy = e->h_st[ST_PQ];
         }

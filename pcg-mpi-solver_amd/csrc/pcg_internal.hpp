@@ -35,6 +35,32 @@ struct SellHost {
 void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
                  int64_t n_boundary_nodes, int32_t rows_per_lane, int n_threads, SellHost &out);
 
+// ---- matrix-free (element-by-element) operator ------------------------------------------------
+// The reference's own algorithm (pcg_solver.py:265-300): per element gather x, flip signs, multiply
+// by Ck_e * Ke[type], flip signs, scatter-add.  Elements are greedily coloured so that no two elements
+// of one colour share a node: a colour is one conflict-free launch (plain read-modify-write, no
+// atomics) and the colour order fixes the summation order -> bit-reproducible.  Elements touching
+// interface nodes form phase 0 (computed first, so the exchange overlaps phase 1 = the rest).
+struct EbeGroupHost {
+    int32_t nd = 0;
+    int64_t ne = 0;
+    std::vector<int32_t> dof;      // (nd, ne) element-minor, engine dof numbering, elements sorted by (phase, colour)
+    std::vector<uint8_t> sign;     // (nd, ne)
+    std::vector<double> ck;        // (ne)
+    std::vector<double> ke;        // (nd, nd)
+};
+struct EbeRange { int32_t group; int64_t lo, hi; };      // elements [lo,hi) of `group`: one launch
+struct EbeHost {
+    int64_t n_nodes = 0;
+    std::vector<EbeGroupHost> groups;
+    std::vector<EbeRange> ranges[2];                      // per phase, in colour order
+    int32_t n_colors[2] = {0, 0};
+    std::vector<double> diag;                             // local diag(A), length 3*n_nodes
+    int64_t n_elem = 0, n_slots = 0;                      // totals (sum nd*ne = NCountDof)
+};
+void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups, const int64_t *node_perm,
+               int64_t n_boundary_nodes, EbeHost &out);
+
 // ---- device back end ----------------------------------------------------------------------------
 // The product library implements this with hand-written HIP kernels (hip_backend.hip).  The ONLY
 // other implementation lives under tests/hostops/ (a plain-loop test double compiled into a
@@ -70,6 +96,9 @@ public:
     virtual void sync() = 0;
 
     virtual void upload_matrix(const SellHost &m) = 0;
+    virtual void upload_ebe(const EbeHost &m) = 0;
+    // y (+)= sum over the elements of phases [phase_lo, phase_hi) ; zero_first clears y before
+    virtual void ebe_apply(const double *x, double *y, int phase_lo, int phase_hi, bool zero_first) = 0;
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;
 

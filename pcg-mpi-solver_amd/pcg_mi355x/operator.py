@@ -24,9 +24,8 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def assemble_bsr3(groups, n_nodes, node_perm=None, n_threads=0):
-    """Run the native assembler on reference type groups -> (rowptr i64, cols i32, vals f64[nnzb,3,3])."""
-    L = _lib.lib()
+def _pack_groups(groups):
+    """ctypes view of SubDomainData['StrucDataList'] (the arrays calcMatVecProd reads, :267-276)."""
     keep = []
     arr = (_lib.ElemGroup * len(groups))()
     for k, g in enumerate(groups):
@@ -41,6 +40,13 @@ def assemble_bsr3(groups, n_nodes, node_perm=None, n_threads=0):
             raise ValueError("ElemStiffMat / ElemList_Ck shape mismatch")
         keep += [tbl, sign, ck, ke]
         arr[k] = _lib.ElemGroup(nd, ne, tbl.ctypes.data, sign.ctypes.data, ck.ctypes.data, ke.ctypes.data)
+    return arr, keep
+
+
+def assemble_bsr3(groups, n_nodes, node_perm=None, n_threads=0):
+    """Run the native assembler on reference type groups -> (rowptr i64, cols i32, vals f64[nnzb,3,3])."""
+    L = _lib.lib()
+    arr, keep = _pack_groups(groups)
     perm = None
     if node_perm is not None:
         perm = np.ascontiguousarray(node_perm, dtype=np.int64)
@@ -63,21 +69,32 @@ class Operator:
     """One part's operator on one GPU.  Vectors in/out are NumPy f64 of the part's local length
     (`NDOF`) in the REFERENCE's local numbering; the interface-first renumbering is internal."""
 
-    def __init__(self, n_nodes, rowptr, cols, vals, n_boundary_nodes=0, dof_new_of_old=None, device=0,
-                 rows_per_lane=0):
+    def __init__(self, n_nodes, rowptr=None, cols=None, vals=None, n_boundary_nodes=0, dof_new_of_old=None, device=0,
+                 rows_per_lane=0, ebe_groups=None, node_perm=None):
+        """Assembled operator from 3x3-block CSR (rowptr/cols/vals), or - with `ebe_groups` - the
+        matrix-free operator straight from the reference's type-group tables."""
         L = _lib.lib()
         self._L = L
         self.n_nodes = int(n_nodes)
         self.n = 3 * self.n_nodes
         self._map = None if dof_new_of_old is None else np.ascontiguousarray(dof_new_of_old, dtype=np.int64)
-        self.nnzb = int(rowptr[-1])
-        self.nnz = 9 * self.nnzb
         h = C.c_void_p()
-        rowptr = np.ascontiguousarray(rowptr, np.int64)
-        cols = np.ascontiguousarray(cols, np.int32)
-        vals = _f64(vals)
-        check(L.pcg_create(device, self.n_nodes, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data,
-                           int(n_boundary_nodes), int(rows_per_lane), C.byref(h)), "pcg_create")
+        if ebe_groups is not None:
+            self.kind = "ebe"
+            arr, keep = _pack_groups(ebe_groups)
+            perm = None if node_perm is None else np.ascontiguousarray(node_perm, np.int64)
+            check(L.pcg_create_ebe(device, self.n_nodes, len(ebe_groups), arr, perm.ctypes.data if perm is not None else None,
+                                   int(n_boundary_nodes), C.byref(h)), "pcg_create_ebe")
+            self.nnzb = self.nnz = 0
+        else:
+            self.kind = "sell"
+            self.nnzb = int(rowptr[-1])
+            self.nnz = 9 * self.nnzb
+            rowptr = np.ascontiguousarray(rowptr, np.int64)
+            cols = np.ascontiguousarray(cols, np.int32)
+            vals = _f64(vals)
+            check(L.pcg_create(device, self.n_nodes, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data,
+                               int(n_boundary_nodes), int(rows_per_lane), C.byref(h)), "pcg_create")
         self._h = h
         self._comm = None
         self._hooks = None
@@ -218,6 +235,11 @@ class Operator:
         check(self._L.pcg_bench_spmv(self._h, warmup, reps, ms.ctypes.data), "pcg_bench_spmv")
         return ms
 
+    def operator_info(self):
+        k, a, b, c = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+        check(self._L.pcg_operator_info(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c)), "pcg_operator_info")
+        return {"kind": "ebe" if k.value == 1 else "sell", "n_elem": a.value, "n_slots": b.value, "n_colors": c.value}
+
     def matrix_info(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         check(self._L.pcg_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_matrix_info")
@@ -235,8 +257,9 @@ class Operator:
             pass
 
 
-def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0):
-    """Build the GPU operator of one RefMeshPart (see module docstring for the keys read)."""
+def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell"):
+    """Build the GPU operator of one RefMeshPart (see module docstring for the keys read).
+    kind: "sell" = assembled SELL-BSR3 matrix (default), "ebe" = matrix-free element-by-element."""
     ndof = int(part["NDOF"])
     if ndof % 3:
         raise PcgError("NDOF must be a multiple of 3 (dof = 3*node + dir, partition_mesh.py:826)")
@@ -256,8 +279,13 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0):
         node_perm[order] = np.arange(n_nodes)
         n_bnd = int(is_b.sum())
         dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
-    rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
-    op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, rows_per_lane)
+    if kind == "ebe":
+        op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm)
+    elif kind == "sell":
+        rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
+        op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, rows_per_lane)
+    else:
+        raise ValueError(kind)
     w = np.asarray(part["DofWeightVector"], float)
     if not np.all((w == 0) | (w == 1)):
         raise PcgError("DofWeightVector must be 0/1 (partition_mesh.py:870-887)")

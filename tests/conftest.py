@@ -25,12 +25,12 @@ def build_hostops():
     """Compile the CPU test double (tests/hostops) + the product's back-end-agnostic C++ sources."""
     import subprocess
     csrc = os.path.join(ROOT, "pcg-mpi-solver_amd", "csrc")
-    srcs = [HOSTOPS_SRC] + [os.path.join(csrc, f) for f in ("pcg_driver.cpp", "assemble.cpp", "sell.cpp")]
+    srcs = [HOSTOPS_SRC] + [os.path.join(csrc, f) for f in ("pcg_driver.cpp", "assemble.cpp", "sell.cpp", "ebe.cpp")]
     deps = srcs + [os.path.join(csrc, "pcg_internal.hpp"), os.path.join(ROOT, "include", "pcg_mi355x.h")]
     if os.path.exists(HOSTOPS_LIB) and all(os.path.getmtime(HOSTOPS_LIB) >= os.path.getmtime(d) for d in deps):
         return HOSTOPS_LIB
     os.makedirs(os.path.dirname(HOSTOPS_LIB), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic",
            "-I" + os.path.join(ROOT, "include"), "-I" + csrc] + srcs + ["-o", HOSTOPS_LIB]
     subprocess.check_call(cmd)
     return HOSTOPS_LIB

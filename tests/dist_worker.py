@@ -20,6 +20,7 @@ import torch.distributed as dist
 
 def main():
     case, backend, libkind, outdir = sys.argv[1:5]
+    opkind = sys.argv[5] if len(sys.argv) > 5 else "sell"
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     from pcg_mi355x import _lib
@@ -40,7 +41,7 @@ def main():
     assert len(parts) == world, (len(parts), world)
     P = parts[rank]
     comm = TorchComm(device=device)
-    pm.configure(comm=comm, device=int(os.environ.get("LOCAL_RANK", 0)))
+    pm.configure(comm=comm, device=int(os.environ.get("LOCAL_RANK", 0)), operator=opkind)
     out = {"rank": rank}
     x = golden_cases.probe_vector(brick)[P["DofVector"]]
     out["y_probe"] = pm.calc_mpfint(x, P)

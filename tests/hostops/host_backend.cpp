@@ -17,6 +17,7 @@ namespace pcg {
 
 class HostBackend : public Backend {
     SellHost m_;
+    EbeHost ebe_;
     std::vector<uint8_t> flags_;
     HaloHost h_;
     double dot_spmv_ = 0, dot_fix_ = 0, dotw_ = 0;
@@ -36,6 +37,34 @@ public:
     void zero(void *d, size_t b) override { std::memset(d, 0, b); }
     void sync() override {}
     void upload_matrix(const SellHost &m) override { m_ = m; n_ = 3 * m.n_nodes; }
+    void upload_ebe(const EbeHost &m) override
+    {
+        ebe_ = m; n_ = 3 * m.n_nodes;
+        m_ = SellHost(); m_.n_nodes = m.n_nodes; m_.diag = m.diag;
+    }
+    void ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first) override
+    {
+        if (zero_first) std::memset(y, 0, sizeof(double) * n_);
+        std::vector<double> u;
+        for (int ph = plo; ph < phi; ++ph)
+            for (const auto &r : ebe_.ranges[ph]) {
+                const auto &G = ebe_.groups[r.group];
+                u.resize(G.nd);
+                for (int64_t e = r.lo; e < r.hi; ++e) {
+                    for (int b = 0; b < G.nd; ++b) {
+                        double v = x[G.dof[(size_t)b * G.ne + e]];
+                        if (G.sign[(size_t)b * G.ne + e]) v = -v;
+                        u[b] = G.ck[e] * v;
+                    }
+                    for (int a = 0; a < G.nd; ++a) {
+                        double acc = 0;
+                        for (int b = 0; b < G.nd; ++b) acc += G.ke[(size_t)a * G.nd + b] * u[b];
+                        if (G.sign[(size_t)a * G.ne + e]) acc = -acc;
+                        y[G.dof[(size_t)a * G.ne + e]] += acc;
+                    }
+                }
+            }
+    }
     void upload_masks(const uint8_t *f, int64_t n) override { flags_.assign(f, f + n); }
     void upload_halo(const HaloHost &h) override { h_ = h; }
 
@@ -76,7 +105,7 @@ public:
         }
         if (with_dot) {
             double acc = 0;
-            const int64_t nb = std::min<int64_t>(n_, m_.n_bnd_slices * m_.C * 3);
+            const int64_t nb = std::min<int64_t>(n_, (int64_t)m_.n_bnd_slices * m_.C * 3);
             for (int64_t d = 0; d < nb; ++d)
                 if (own_free(d)) acc += xdot[d] * y[d];
             dot_fix_ = acc;
@@ -151,7 +180,8 @@ public:
     void collect_profile(double *ms, int64_t *c) override { *ms = 0; *c = 0; }
     int bench_spmv(const double *x, double *y, int, int reps, float *ms) override
     {
-        spmv(x, y, 0, m_.n_slices, false);
+        if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true);
+        else spmv(x, y, 0, m_.n_slices, false);
         for (int k = 0; k < reps; ++k) ms[k] = 0.f;
         return 0;
     }

@@ -1,0 +1,77 @@
+"""Matrix-free (element-by-element) operator, SURVEY 8(f)-1: host set-up (colouring, phases, packing),
+the driver's EBE apply path and the N>1 exchange, on the CPU test double, against the reference
+fixtures and the oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+import golden_cases
+import pcg_oracle
+import pcg_mi355x as pm
+from util import golden, relerr, check_solution_against_golden, run_dist, make_super_part
+
+SINGLE = ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_zero_rhs"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_cfg():
+    yield
+    pm.configure(comm=None, operator="sell")
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_ebe_solve_matches_reference(hostops, name):
+    brick, parts = golden_cases.build_case(name)
+    g = golden(name)
+    P = parts[0]
+    pm.configure(comm=None, operator="ebe")
+    op = pm.get_operator(P)
+    info = op.operator_info()
+    assert info["kind"] == "ebe" and info["n_colors"] == 8 and info["n_elem"] == brick.n_elem
+    x = golden_cases.probe_vector(brick)
+    assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
+    assert np.array_equal(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"])      # same order as np.bincount (:300)
+    pm.update_bc(P); pm.update_preconditioner(P)
+    if str(g["raised"]):
+        with pytest.raises(Warning, match="TooSmallTolerance"):
+            pm.solve(P)
+        return
+    out = pm.solve(P, history=True)
+    if int(g["early"]):
+        assert out is not None and out[1] == int(g["early_flag"])
+        return
+    inf = P["_pcg_mi355x_info"]
+    check_solution_against_golden(g, inf.flag, inf.iter, inf.relres, P["Un"], inf.history, tol_iter=1,
+                                  tol_u=1e-8 if inf.flag == 0 else 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["ebe", "sell"])
+@pytest.mark.parametrize("N", [7, 8])
+def test_patterns_with_nd_36_and_mixed_groups(hostops, kind, N):
+    b, P = make_super_part(N)
+    R = copy.deepcopy(P)
+    pm.configure(comm=None, operator=kind)
+    x = np.random.default_rng(1).standard_normal(b.n_dof)
+    assert relerr(pm.calc_mpfint(x, P), pcg_oracle.matvec_local(R, x)) < 1e-14
+    assert relerr(pm.calc_matvec_prod(P, "Preconditioner"), pcg_oracle.matvec_local(R, None, "Preconditioner")) < 1e-14
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    out = pcg_oracle.solve_step([R])
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0
+    assert abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= 1
+    assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
+@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622)])
+def test_ebe_multi_rank(tmp_path, case, nproc, port):
+    import conftest
+    conftest.build_hostops()
+    outs = run_dist(case, nproc, "gloo", "hostops", tmp_path, port, extra=["ebe"])
+    g = golden(case)
+    n = len(g["Un"])
+    U = np.zeros(n); Y = np.zeros(n)
+    for o in reversed(outs):
+        U[o["dofs"]] = o["Un"]; Y[o["dofs"]] = o["y_probe"]
+    assert relerr(Y, g["y_probe"]) < 1e-14
+    o0 = outs[0]
+    check_solution_against_golden(g, int(o0["flag"]), int(o0["iter"]), float(o0["relres"]), U, o0["history"], tol_iter=1)

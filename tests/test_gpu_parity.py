@@ -13,7 +13,7 @@ import golden_cases
 import pcg_oracle
 import pcg_mi355x as pm
 from pcg_mi355x.brick import Brick, make_parts
-from util import golden, relerr, check_solution_against_golden, run_dist
+from util import golden, relerr, check_solution_against_golden, run_dist, make_super_part
 
 pytestmark = pytest.mark.gpu
 
@@ -224,6 +224,86 @@ def test_full_size_10m_properties(gpu_lib, oracle_c):
     nb = np.linalg.norm(P["Fext"][eff])
     assert abs(np.linalg.norm(r_true) / nb - res.relres) <= 1e-9 * res.relres + 1e-12
     assert res.relres < hist[0, 2] / nb
+
+
+# ---- matrix-free (element-by-element) operator, SURVEY 8(f)-1 -------------------------------------
+@pytest.fixture()
+def ebe_cfg():
+    pm.configure(comm=None, device=0, operator="ebe")
+    yield
+    pm.configure(comm=None, device=0, operator="sell")
+
+
+@pytest.mark.parametrize("n_types", [1, 3])
+def test_ebe_kernel_vs_oracle(gpu_lib, ebe_cfg, n_types):
+    b = Brick(21, n_types=n_types)
+    P = make_parts(b)[0]
+    op = pm.get_operator(P)
+    assert op.operator_info() == {"kind": "ebe", "n_elem": b.n_elem, "n_slots": 24 * b.n_elem, "n_colors": 8}
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(b.n_dof)
+    y = op.apply(x)
+    assert relerr(y, pcg_oracle.matvec_local(P, x)) < 1e-13
+    assert np.array_equal(y, op.apply(x))                                    # colour order fixed: bit-reproducible
+    assert np.array_equal(op.diag(), pcg_oracle.matvec_local(P, None, "Preconditioner"))
+
+
+@pytest.mark.parametrize("N", [8, 9])
+def test_ebe_generic_nd_kernel(gpu_lib, ebe_cfg, N):
+    b, P = make_super_part(N)                                                # nd = 36 (+ nd = 24 group when N-1 is odd)
+    R = copy.deepcopy(P)
+    x = np.random.default_rng(1).standard_normal(b.n_dof)
+    assert relerr(pm.calc_mpfint(x, P), pcg_oracle.matvec_local(R, x)) < 1e-13
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    out = pcg_oracle.solve_step([R])
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0
+    assert abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= 1
+    assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_good_x0"])
+def test_ebe_solve_matches_reference_fixture(gpu_lib, ebe_cfg, name):
+    brick, parts = golden_cases.build_case(name)
+    g = golden(name)
+    P = parts[0]
+    x = golden_cases.probe_vector(brick)
+    assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-13
+    pm.update_bc(P); pm.update_preconditioner(P)
+    assert relerr(P["Fext"], g["Fext"]) < 1e-13
+    if str(g["raised"]):
+        with pytest.raises(Warning, match="TooSmallTolerance"):
+            pm.solve(P)
+        return
+    out = pm.solve(P, history=True)
+    if int(g["early"]):
+        assert out is not None and out[1] == int(g["early_flag"])
+        return
+    info = P["_pcg_mi355x_info"]
+    check_solution_against_golden(g, info.flag, info.iter, info.relres, P["Un"], info.history, tol_iter=1,
+                                  tol_u=1e-8 if info.flag == 0 else 1e-6)
+
+
+def test_ebe_full_size_10m(gpu_lib, ebe_cfg, oracle_c):
+    b = Brick(150)
+    P = make_parts(b)[0]
+    op = pm.get_operator(P)
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(b.n_dof), rng.standard_normal(b.n_dof)
+    ax, ay = op.apply(x), op.apply(y)
+    assert relerr(ax, pcg_oracle.matvec_local(P, x, use_c=True)) < 1e-13
+    assert abs(np.dot(y, ax) - np.dot(x, ay)) <= 1e-12 * np.dot(np.abs(y), np.abs(ax))
+    t = np.zeros(b.n_dof); t[0::3] = 1.0
+    assert np.abs(op.apply(t)).max() < 1e-9
+    pm.update_bc(P); pm.update_preconditioner(P)
+    eff = P["LocDofEff"]
+    inv = np.zeros(b.n_dof); inv[eff] = P["InvDiagPreCondVector0"]
+    op.solve_begin(P["Fext"], None, inv, 1e-7, 200, P["GlobData"]["GlobNDofEff"])
+    op.solve_run(-1)
+    xk, res = op.solve_end()
+    assert res.flag == 1 and res.iters_done == 200
+    r_true = (P["Fext"] - pcg_oracle.matvec_local(P, xk, use_c=True))[eff]
+    nb = np.linalg.norm(P["Fext"][eff])
+    assert abs(np.linalg.norm(r_true) / nb - res.relres) <= 1e-9 * res.relres + 1e-12
 
 
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):

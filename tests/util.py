@@ -25,13 +25,13 @@ def to_global(brick, parts, key_or_list):
     return out
 
 
-def run_dist(case, nproc, backend, libkind, outdir, port, timeout=600):
+def run_dist(case, nproc, backend, libkind, outdir, port, timeout=600, extra=()):
     import subprocess
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), case, backend, libkind, str(outdir)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), case, backend, libkind, str(outdir)] + list(extra)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
     return [np.load(os.path.join(outdir, f"rank{k}.npz")) for k in range(nproc)]
@@ -44,7 +44,10 @@ def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol
     assert flag == int(g["flag"])
     assert abs(it - int(g["iter"])) <= tol_iter, (it, int(g["iter"]))
     assert relerr(Un, g["Un"]) < tol_u, relerr(Un, g["Un"])
-    assert abs(relres - float(g["relres"])) <= 0.1 * float(g["relres"]) + 1e-300
+    if it == int(g["iter"]):
+        assert abs(relres - float(g["relres"])) <= 0.1 * float(g["relres"]) + 1e-300
+    elif flag == 0:
+        assert relres <= 1e-7          # a +-1 iteration exit is a different iterate; it must still meet Tol
     if hist is not None:
         # The reference itself, run with 1 part vs 2 parts (tests/golden n9_p1 vs n9_p2), deviates by
         # 4e-13 at iteration 50, 6e-11 at 60 and 2e-2 at 100 of its 118 iterations: only the first ~30-40 %
@@ -53,3 +56,58 @@ def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol
         assert len(hist) == len(g["history"]) or tol_iter > 0
         d = np.abs(hist[:m, 2] / g["history"][:m, 2] - 1).max() if m else 0.0
         assert d < 1e-10, d
+
+
+def make_super_part(N, seed=0):
+    """A RefMeshPart whose elements are x-pairs of hex8 cells merged into ONE 12-node pattern
+    (nd = 36) plus, when N-1 is odd, a second group with the left-over hex8 cells (nd = 24): exercises
+    pattern types with nd != 24 (the reference's hanging-node octree patterns have such sizes,
+    partition_mesh.py:581) and mixed group sizes, with random sign masks."""
+    from pcg_mi355x.brick import Brick, make_parts, hex8_stiffness
+    b = Brick(N, seed=seed)
+    P = make_parts(b)[0]
+    n1 = N - 1
+    rng = np.random.default_rng(seed + 5)
+    Ke = hex8_stiffness()
+    # local node (px,dy,dz), px in 0..2 -> index px + 3*dy + 6*dz ; dof = 3*node + dir
+    Ks = np.zeros((36, 36))
+    for half in (0, 1):
+        loc = [((a & 1) + half) + 3 * ((a >> 1) & 1) + 6 * ((a >> 2) & 1) for a in range(8)]
+        idx = np.array([3 * l + d for l in loc for d in range(3)])
+        Ks[np.ix_(idx, idx)] += Ke
+    pairs, singles = [], []
+    for k in range(n1):
+        for j in range(n1):
+            for i in range(0, n1 - 1, 2):
+                pairs.append((i, j, k))
+            if n1 % 2:
+                singles.append((n1 - 1, j, k))
+
+    def node(i, j, k):
+        return (k * N + j) * N + i
+    tbl36 = np.empty((36, len(pairs)), np.int64)
+    for e, (i, j, k) in enumerate(pairs):
+        for dz in range(2):
+            for dy in range(2):
+                for px in range(3):
+                    l = px + 3 * dy + 6 * dz
+                    tbl36[3 * l:3 * l + 3, e] = 3 * node(i + px, j + dy, k + dz) + np.arange(3)
+    flip36 = rng.random(36) < 0.4
+    d36 = np.where(flip36, -1.0, 1.0)
+    groups = [{"ElemTypeId": 0, "ElemList_LocDofVector": tbl36, "ElemList_LocDofVector_Flat": tbl36.ravel(),
+               "ElemList_SignVector": np.ascontiguousarray(np.broadcast_to(flip36[:, None], tbl36.shape)),
+               "ElemList_Ck": np.where(rng.random(len(pairs)) < 0.5, 1.0, 3.0),
+               "ElemStiffMat": Ks * d36[:, None] * d36[None, :], "ElemDiagStiffMat": np.diag(Ks).copy(), "N_Elem": len(pairs)}]
+    if singles:
+        tbl24 = np.empty((24, len(singles)), np.int64)
+        for e, (i, j, k) in enumerate(singles):
+            for a in range(8):
+                tbl24[3 * a:3 * a + 3, e] = 3 * node(i + (a & 1), j + ((a >> 1) & 1), k + ((a >> 2) & 1)) + np.arange(3)
+        groups.append({"ElemTypeId": 1, "ElemList_LocDofVector": tbl24, "ElemList_LocDofVector_Flat": tbl24.ravel(),
+                       "ElemList_SignVector": np.zeros(tbl24.shape, bool),
+                       "ElemList_Ck": np.where(rng.random(len(singles)) < 0.5, 1.0, 3.0),
+                       "ElemStiffMat": Ke, "ElemDiagStiffMat": np.diag(Ke).copy(), "N_Elem": len(singles)})
+    P["SubDomainData"] = {"StrucDataList": groups, "MixedDataList": {}}
+    P["Flat_ElemLocDof"] = np.concatenate([g["ElemList_LocDofVector_Flat"] for g in groups])
+    P["NCountDof"] = len(P["Flat_ElemLocDof"])
+    return b, P
