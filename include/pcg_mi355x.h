@@ -76,8 +76,12 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
                const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
 /* Matrix-free variant: the operator stays in the reference's element-by-element form
  * (pcg_solver.py:265-300); nothing is assembled.  Same groups / numbering arguments as pcg_asm_create. */
+/* node_coords (n_nodes x 3, ORIGINAL node numbering, may be NULL: RefMeshPart['NodeCoordVec'],
+ * partition_mesh.py:357) only steers the spatial clustering of elements into workgroup chunks.
+ * flags bit0: disable the chunked (LDS-tiled) form and use one colour per launch for every group. */
 int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
-                   const int64_t *node_perm, int64_t n_boundary_nodes, pcg_engine **out);
+                   const int64_t *node_perm, int64_t n_boundary_nodes, const double *node_coords, int32_t flags,
+                   pcg_engine **out);
 void pcg_destroy(pcg_engine *e);
 
 /* flags[d]: bit0 = this part owns dof d (DofWeightVector == 1, partition_mesh.py:870-887),
@@ -145,7 +149,7 @@ int pcg_set_profiling(pcg_engine *e, int32_t on);
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
 int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free */, int64_t *n_elem, int64_t *n_slots,
-                      int32_t *n_colors);
+                      int32_t *n_colors, int64_t *n_chunks);
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
 /* single fused kernels on host vectors, for per-kernel parity tests */
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first);

@@ -1,6 +1,11 @@
-// Host-side set-up of the matrix-free operator: greedy element colouring, (phase, colour) sorting,
-// packing of the per-group tables, local diag(A).  See EbeHost in pcg_internal.hpp.
+// Host-side set-up of the matrix-free operator (EbeHost in pcg_internal.hpp):
+//   * hex8-like groups (nd == 24, node-blocked slots) -> spatially clustered 256-element chunks with
+//     LDS node tiles, sub-colours inside a chunk, chunk colours across launches (build_chunked);
+//   * every other pattern type -> greedy element colouring, one conflict-free launch per colour;
+//   * local diag(A) in the reference's own accumulation order (pcg_solver.py:282-300).
+// Everything is deterministic: orders depend only on the input tables.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
@@ -9,89 +14,284 @@
 
 namespace pcg {
 
+namespace {
+
+struct ElemRef { uint64_t key; int32_t g; int64_t e; };
+
+inline uint64_t spread21(uint64_t v)
+{
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+bool node_blocked24(const pcg_elem_group &g)
+{
+    if (g.nd != 24) return false;
+    for (int l = 0; l < 8; ++l) {
+        const int64_t *d0 = g.dof + (int64_t)(3 * l) * g.ne, *d1 = d0 + g.ne, *d2 = d1 + g.ne;
+        for (int64_t e = 0; e < g.ne; ++e)
+            if (d0[e] % 3 != 0 || d1[e] != d0[e] + 1 || d2[e] != d0[e] + 2) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
 void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, const int64_t *perm,
-               int64_t n_boundary_nodes, EbeHost &out)
+               int64_t n_boundary_nodes, const double *coords, bool allow_chunked, EbeHost &out)
 {
     out = EbeHost();
     out.n_nodes = n_nodes;
     out.groups.resize(n_groups);
     out.diag.assign((size_t)n_nodes * 3, 0.0);
-    // node -> bit mask of the colours already used by its elements (greedy, elements in (group, e) order)
-    std::vector<uint64_t> used((size_t)n_nodes, 0);
-    std::vector<std::vector<uint8_t>> color(n_groups), phase(n_groups);
-    std::vector<int64_t> nodes_of;
-    int maxc[2] = {-1, -1};
+
+    // ---- validation, totals, diag(A) (a-major then e: exactly np.bincount's order, :294-300) ---------
+    std::vector<char> chunkable(n_groups, 0);
     for (int g = 0; g < n_groups; ++g) {
         const auto &in = gs[g];
         if (in.nd <= 0 || in.nd > 255) throw std::runtime_error("ebe: nd out of range (1..255)");
-        color[g].resize((size_t)in.ne);
-        phase[g].resize((size_t)in.ne);
-        nodes_of.resize(in.nd);
-        for (int64_t e = 0; e < in.ne; ++e) {
-            uint64_t forbidden = 0;
-            bool bnd = false;
-            for (int a = 0; a < in.nd; ++a) {
-                int64_t d = in.dof[(int64_t)a * in.ne + e];
-                int64_t node = d / 3;
-                if (d < 0 || node >= n_nodes) throw std::runtime_error("ebe: dof index out of range");
-                if (perm) node = perm[node];
-                nodes_of[a] = node;
-                forbidden |= used[node];
-                bnd |= node < n_boundary_nodes;
-            }
-            if (~forbidden == 0) throw std::runtime_error("ebe: more than 64 colours needed");
-            int c = __builtin_ctzll(~forbidden);
-            for (int a = 0; a < in.nd; ++a) used[nodes_of[a]] |= (1ull << c);
-            color[g][e] = (uint8_t)c;
-            phase[g][e] = bnd ? 0 : 1;
-            maxc[bnd ? 0 : 1] = std::max(maxc[bnd ? 0 : 1], c);
-        }
-    }
-    const int n_col = std::max(maxc[0], maxc[1]) + 1;
-    out.n_colors[0] = maxc[0] + 1;
-    out.n_colors[1] = maxc[1] + 1;
-    // per group: stable sort by (phase, colour), pack
-    std::vector<std::vector<int64_t>> bucket_start(n_groups);
-    for (int g = 0; g < n_groups; ++g) {
-        const auto &in = gs[g];
-        auto &G = out.groups[g];
-        G.nd = in.nd; G.ne = in.ne;
-        G.ke.assign(in.ke, in.ke + (size_t)in.nd * in.nd);
-        std::vector<int64_t> cnt((size_t)2 * n_col + 1, 0);
-        for (int64_t e = 0; e < in.ne; ++e) cnt[(size_t)phase[g][e] * n_col + color[g][e] + 1]++;
-        for (size_t k = 0; k + 1 < cnt.size(); ++k) cnt[k + 1] += cnt[k];
-        bucket_start[g] = cnt;
-        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1), newpos((size_t)in.ne);
-        for (int64_t e = 0; e < in.ne; ++e) newpos[e] = cur[(size_t)phase[g][e] * n_col + color[g][e]]++;
-        G.dof.resize((size_t)in.nd * in.ne);
-        G.sign.resize((size_t)in.nd * in.ne);
-        G.ck.resize((size_t)in.ne);
-        for (int64_t e = 0; e < in.ne; ++e) G.ck[newpos[e]] = in.ck[e];
         for (int a = 0; a < in.nd; ++a) {
             const int64_t *src = in.dof + (int64_t)a * in.ne;
-            const uint8_t *ss = in.sign + (int64_t)a * in.ne;
-            int32_t *dd = &G.dof[(size_t)a * in.ne];
-            uint8_t *ds = &G.sign[(size_t)a * in.ne];
             const double kaa = in.ke[(size_t)a * in.nd + a];
             for (int64_t e = 0; e < in.ne; ++e) {
                 int64_t d = src[e], node = d / 3;
+                if (d < 0 || node >= n_nodes) throw std::runtime_error("ebe: dof index out of range");
                 if (perm) node = perm[node];
-                const int64_t nd_new = 3 * node + d % 3;
-                dd[newpos[e]] = (int32_t)nd_new;
-                ds[newpos[e]] = ss[e] ? 1 : 0;
-                out.diag[nd_new] += in.ck[e] * kaa;            // pcg_solver.py:282-287 (signs cancel on the diagonal)
+                out.diag[3 * node + d % 3] += in.ck[e] * kaa;      // signs cancel on the diagonal
             }
         }
         out.n_elem += in.ne;
         out.n_slots += (int64_t)in.nd * in.ne;
+        chunkable[g] = allow_chunked && node_blocked24(in);
     }
-    // launch ranges: per phase, colour-major, groups inside a colour
-    for (int ph = 0; ph < 2; ++ph)
-        for (int c = 0; c < n_col; ++c)
-            for (int g = 0; g < n_groups; ++g) {
-                const int64_t lo = bucket_start[g][(size_t)ph * n_col + c], hi = bucket_start[g][(size_t)ph * n_col + c + 1];
-                if (hi > lo) out.ranges[ph].push_back(EbeRange{g, lo, hi});
+
+    // ---- one global, spatially coherent element order (Morton code of the first node, or its id) ----
+    std::vector<ElemRef> order;
+    order.reserve((size_t)out.n_elem);
+    double lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    if (coords) {
+        double hi[3];
+        for (int d = 0; d < 3; ++d) { lo[d] = coords[d]; hi[d] = coords[d]; }
+        for (int64_t i = 0; i < n_nodes; ++i)
+            for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], coords[3 * i + d]); hi[d] = std::max(hi[d], coords[3 * i + d]); }
+        for (int d = 0; d < 3; ++d) inv[d] = hi[d] > lo[d] ? 2097151.0 / (hi[d] - lo[d]) : 0.0;
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        const auto &in = gs[g];
+        for (int64_t e = 0; e < in.ne; ++e) {
+            int64_t mn = in.dof[e] / 3;
+            for (int a = 1; a < in.nd; ++a) mn = std::min(mn, in.dof[(int64_t)a * in.ne + e] / 3);
+            uint64_t key;
+            if (coords) {
+                const double *c = coords + 3 * mn;
+                key = spread21((uint64_t)((c[0] - lo[0]) * inv[0])) | spread21((uint64_t)((c[1] - lo[1]) * inv[1])) << 1 |
+                      spread21((uint64_t)((c[2] - lo[2]) * inv[2])) << 2;
+            } else {
+                key = (uint64_t)mn;
             }
+            order.push_back(ElemRef{key, g, e});
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [](const ElemRef &a, const ElemRef &b) { return a.key < b.key; });
+
+    auto new_node = [&](int64_t d) { int64_t n = d / 3; return perm ? perm[n] : n; };
+
+    // ================= generic path: element colouring over the non-chunkable groups =================
+    {
+        std::vector<uint64_t> used((size_t)n_nodes, 0);
+        std::vector<std::vector<uint8_t>> color(n_groups), phase(n_groups);
+        for (int g = 0; g < n_groups; ++g)
+            if (!chunkable[g]) { color[g].resize((size_t)gs[g].ne); phase[g].resize((size_t)gs[g].ne); }
+        int maxc = -1;
+        std::vector<int64_t> nodes_of;
+        for (const auto &r : order) {
+            if (chunkable[r.g]) continue;
+            const auto &in = gs[r.g];
+            nodes_of.resize(in.nd);
+            uint64_t forbidden = 0;
+            bool bnd = false;
+            for (int a = 0; a < in.nd; ++a) {
+                nodes_of[a] = new_node(in.dof[(int64_t)a * in.ne + r.e]);
+                forbidden |= used[nodes_of[a]];
+                bnd |= nodes_of[a] < n_boundary_nodes;
+            }
+            if (~forbidden == 0) throw std::runtime_error("ebe: more than 64 colours needed");
+            const int c = __builtin_ctzll(~forbidden);
+            for (int a = 0; a < in.nd; ++a) used[nodes_of[a]] |= (1ull << c);
+            color[r.g][r.e] = (uint8_t)c;
+            phase[r.g][r.e] = bnd ? 0 : 1;
+            maxc = std::max(maxc, c);
+        }
+        const int n_col = maxc + 1;
+        out.n_colors[0] = out.n_colors[1] = n_col;
+        std::vector<std::vector<int64_t>> bucket_start(n_groups);
+        for (int g = 0; g < n_groups; ++g) {
+            const auto &in = gs[g];
+            auto &G = out.groups[g];
+            G.nd = in.nd;
+            if (chunkable[g]) { G.ne = 0; continue; }
+            G.ne = in.ne;
+            G.ke.assign(in.ke, in.ke + (size_t)in.nd * in.nd);
+            std::vector<int64_t> cnt((size_t)2 * n_col + 1, 0);
+            for (int64_t e = 0; e < in.ne; ++e) cnt[(size_t)phase[g][e] * n_col + color[g][e] + 1]++;
+            for (size_t k = 0; k + 1 < cnt.size(); ++k) cnt[k + 1] += cnt[k];
+            bucket_start[g] = cnt;
+            // inside a (phase, colour) bucket keep the spatial order
+            std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1), newpos((size_t)in.ne);
+            for (const auto &r : order)
+                if (r.g == g) newpos[r.e] = cur[(size_t)phase[g][r.e] * n_col + color[g][r.e]]++;
+            G.dof.resize((size_t)in.nd * in.ne);
+            G.sign.resize((size_t)in.nd * in.ne);
+            G.ck.resize((size_t)in.ne);
+            for (int64_t e = 0; e < in.ne; ++e) G.ck[newpos[e]] = in.ck[e];
+            for (int a = 0; a < in.nd; ++a) {
+                const int64_t *src = in.dof + (int64_t)a * in.ne;
+                const uint8_t *ss = in.sign + (int64_t)a * in.ne;
+                int32_t *dd = &G.dof[(size_t)a * in.ne];
+                uint8_t *ds = &G.sign[(size_t)a * in.ne];
+                for (int64_t e = 0; e < in.ne; ++e) {
+                    dd[newpos[e]] = (int32_t)(3 * new_node(src[e]) + src[e] % 3);
+                    ds[newpos[e]] = ss[e] ? 1 : 0;
+                }
+            }
+        }
+        for (int ph = 0; ph < 2; ++ph)
+            for (int c = 0; c < n_col; ++c)
+                for (int g = 0; g < n_groups; ++g) {
+                    if (chunkable[g]) continue;
+                    const int64_t lo_ = bucket_start[g][(size_t)ph * n_col + c], hi_ = bucket_start[g][(size_t)ph * n_col + c + 1];
+                    if (hi_ > lo_) out.ranges[ph].push_back(EbeRange{g, lo_, hi_});
+                }
+    }
+
+    // ================= chunked path ====================================================================
+    auto &C = out.chunked;
+    std::vector<int32_t> g24_of(n_groups, -1);
+    int n_g24 = 0;
+    for (int g = 0; g < n_groups; ++g)
+        if (chunkable[g]) {
+            g24_of[g] = n_g24++;
+            for (int b = 0; b < 24; ++b)
+                for (int a = 0; a < 24; ++a) C.ke_col.push_back(gs[g].ke[(size_t)a * 24 + b]);
+        }
+    if (n_g24 == 0) return;
+    std::vector<int32_t> stamp((size_t)n_nodes, -1);
+    std::vector<uint8_t> chunk_phase;
+    struct Open { std::vector<int64_t> elems; std::vector<int32_t> nodes; };
+    std::vector<int64_t> ln(8);
+    auto close_chunk = [&](int g, Open &o) {
+        if (o.elems.empty()) return;
+        const auto &in = gs[g];
+        const int32_t cid = (int32_t)C.n_chunks++;
+        std::sort(o.nodes.begin(), o.nodes.end());
+        o.nodes.erase(std::unique(o.nodes.begin(), o.nodes.end()), o.nodes.end());   // (see NOTE on the shared stamp array)
+        const int nn = (int)o.nodes.size();
+        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, 0, g24_of[g]});
+        C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
+        // sub-colouring (greedy, element order) on local node masks
+        std::vector<uint32_t> used(nn, 0);
+        const int ne = (int)o.elems.size();
+        std::vector<int> sc(ne);
+        std::vector<std::array<uint16_t, 8>> lids(ne);
+        int nsub = 0;
+        bool bnd = false;
+        for (int t = 0; t < ne; ++t) {
+            uint32_t forb = 0;
+            for (int l = 0; l < 8; ++l) {
+                const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + o.elems[t]]);
+                const int li = (int)(std::lower_bound(o.nodes.begin(), o.nodes.end(), (int32_t)node) - o.nodes.begin());
+                lids[t][l] = (uint16_t)li;
+                forb |= used[li];
+                bnd |= node < n_boundary_nodes;
+            }
+            if (~forb == 0) throw std::runtime_error("ebe: more than 32 sub-colours in a chunk");
+            const int c = __builtin_ctz(~forb);
+            for (int l = 0; l < 8; ++l) used[lids[t][l]] |= (1u << c);
+            sc[t] = c;
+            nsub = std::max(nsub, c + 1);
+        }
+        C.hdr[(size_t)cid * 4 + 2] = nsub;
+        C.max_subcolors = std::max(C.max_subcolors, nsub);
+        chunk_phase.push_back(bnd ? 0 : 1);
+        // lanes ordered by sub-colour (stable) so that whole waves share a phase
+        std::vector<int> lane_of(ne);
+        std::iota(lane_of.begin(), lane_of.end(), 0);
+        std::stable_sort(lane_of.begin(), lane_of.end(), [&](int a, int b) { return sc[a] < sc[b]; });
+        const size_t base = (size_t)cid * kChunkElems;
+        C.ck.resize(base + kChunkElems, 0.0);
+        C.sgn.resize(base + kChunkElems, 0xff000000u);
+        C.lid.resize(((size_t)cid + 1) * 8 * kChunkElems, 0);
+        for (int lane = 0; lane < ne; ++lane) {
+            const int t = lane_of[lane];
+            const int64_t e = o.elems[t];
+            C.ck[base + lane] = in.ck[e];
+            uint32_t bits = 0;
+            for (int a = 0; a < 24; ++a)
+                if (in.sign[(int64_t)a * in.ne + e]) bits |= (1u << a);
+            C.sgn[base + lane] = bits | ((uint32_t)sc[t] << 24);
+            for (int l = 0; l < 8; ++l) C.lid[((size_t)cid * 8 + l) * kChunkElems + lane] = lids[t][l];
+        }
+        o.elems.clear();
+        o.nodes.clear();
+    };
+    // group by group, elements in the global spatial order
+    {
+        std::vector<Open> open(n_groups);
+        std::vector<int32_t> open_id(n_groups, 0);           // stamp value of the group's open chunk
+        int32_t next_stamp = 0;
+        for (int g = 0; g < n_groups; ++g) open_id[g] = next_stamp++;
+        for (const auto &r : order) {
+            if (!chunkable[r.g]) continue;
+            const auto &in = gs[r.g];
+            Open &o = open[r.g];
+            int fresh = 0;
+            for (int l = 0; l < 8; ++l) {
+                ln[l] = new_node(in.dof[(int64_t)(3 * l) * in.ne + r.e]);
+                if (stamp[ln[l]] != open_id[r.g]) ++fresh;
+            }
+            if ((int)o.elems.size() == kChunkElems || (int)o.nodes.size() + fresh > kChunkMaxNodes) {
+                close_chunk(r.g, o);
+                open_id[r.g] = next_stamp++;
+            }
+            for (int l = 0; l < 8; ++l)
+                if (stamp[ln[l]] != open_id[r.g]) { stamp[ln[l]] = open_id[r.g]; o.nodes.push_back((int32_t)ln[l]); }
+            o.elems.push_back(r.e);
+        }
+        for (int g = 0; g < n_groups; ++g) close_chunk(g, open[g]);
+    }
+    // NOTE: one stamp array is shared by the open chunks of all groups; a node stamped by group A's
+    // chunk looks "fresh" to group B's chunk, which is what we want (sets are per chunk).
+    // ---- chunk colouring (greedy in creation order) ----------------------------------------------------
+    {
+        std::vector<uint64_t> used((size_t)n_nodes, 0);
+        std::vector<int> ccol((size_t)C.n_chunks);
+        int maxc = -1;
+        for (int64_t c = 0; c < C.n_chunks; ++c) {
+            const int32_t off = C.hdr[(size_t)c * 4], nn = C.hdr[(size_t)c * 4 + 1];
+            uint64_t forb = 0;
+            for (int k = 0; k < nn; ++k) forb |= used[C.nodes[off + k]];
+            if (~forb == 0) throw std::runtime_error("ebe: more than 64 chunk colours needed");
+            const int col = __builtin_ctzll(~forb);
+            for (int k = 0; k < nn; ++k) used[C.nodes[off + k]] |= (1ull << col);
+            ccol[c] = col;
+            maxc = std::max(maxc, col);
+        }
+        for (int ph = 0; ph < 2; ++ph) {
+            C.list_ptr[ph].push_back(0);
+            for (int col = 0; col <= maxc; ++col) {
+                for (int64_t c = 0; c < C.n_chunks; ++c)
+                    if (chunk_phase[c] == ph && ccol[c] == col) C.list[ph].push_back((int32_t)c);
+                if ((int32_t)C.list[ph].size() > C.list_ptr[ph].back()) C.list_ptr[ph].push_back((int32_t)C.list[ph].size());
+            }
+        }
+        out.n_colors[0] = std::max<int32_t>(out.n_colors[0], (int32_t)C.list_ptr[0].size() - 1);
+        out.n_colors[1] = std::max<int32_t>(out.n_colors[1], (int32_t)C.list_ptr[1].size() - 1);
+    }
 }
 
 }  // namespace pcg

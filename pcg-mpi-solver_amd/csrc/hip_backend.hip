@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "pcg_internal.hpp"
 
@@ -231,6 +232,66 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
             if ((sg >> (a0 + i)) & 1u) o = -o;               // :280
             y[d[a0 + i]] += o;                               // :300 (conflict-free inside a colour)
         }
+    }
+}
+
+// Chunked form (EbeChunkedHost): one workgroup = one chunk of <= 256 hex8-like elements.
+//   1. the chunk's unique nodes are staged into LDS (x tile) with node-contiguous global loads,
+//   2. each lane = one element: u_b from the LDS tile, 24 independent FMA chains acc[a] += Ke[a][b]*u_b
+//      with Ke (column-major, wave-uniform) streamed through SGPRs by scalar loads,
+//   3. LDS-staged partial sums: the lanes add their 24 outputs into the LDS y tile sub-colour by
+//      sub-colour (no two lanes of a sub-colour share a node; fixed order -> deterministic),
+//   4. the y tile is added to global y (chunks of one launch share no node -> no atomics).
+__global__ __launch_bounds__(kChunkElems) void k_ebe_chunk24(const int *__restrict__ chunk_list, const int4 *__restrict__ hdr,
+                                                             const int *__restrict__ nodes, const unsigned short *__restrict__ lid,
+                                                             const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+                                                             const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                             double *__restrict__ y)
+{
+    __shared__ double xs[3 * kChunkMaxNodes];
+    __shared__ double ys[3 * kChunkMaxNodes];
+    const int chunk = chunk_list[blockIdx.x];
+    const int4 h = hdr[chunk];                               // node_off, n_nodes, n_sub, group24
+    const int *nd = nodes + h.x;
+    for (int n = threadIdx.x; n < h.y; n += kChunkElems) {
+        const double *xp = x + 3 * (size_t)nd[n];
+        xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
+        ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
+    }
+    __syncthreads();
+    const size_t t = (size_t)chunk * kChunkElems + threadIdx.x;
+    const unsigned sg = __builtin_nontemporal_load(sgn + t);
+    const double c = __builtin_nontemporal_load(ck + t);
+    int l3[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + threadIdx.x);
+    const double *K = ke_col + (size_t)h.w * 576;
+    double acc[24];
+#pragma unroll
+    for (int a = 0; a < 24; ++a) acc[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 24; ++b) {
+        double u = xs[l3[b / 3] + b % 3];                    // :277 gather (from the LDS tile)
+        if ((sg >> b) & 1u) u = -u;                          // :278
+        u = c * u;                                           // :279 Ck * U
+#pragma unroll
+        for (int a = 0; a < 24; ++a) acc[a] = fma(K[b * 24 + a], u, acc[a]);   // :279 Ke @ (.)
+    }
+    const int mysc = (int)(sg >> 24);
+    for (int s = 0; s < h.z; ++s) {
+        if (mysc == s) {
+#pragma unroll
+            for (int a = 0; a < 24; ++a) {
+                double o = acc[a];
+                if ((sg >> a) & 1u) o = -o;                  // :280
+                ys[l3[a / 3] + a % 3] += o;                  // :300, LDS-staged partial sums
+            }
+        }
+        __syncthreads();
+    }
+    for (int n = threadIdx.x; n < h.y; n += kChunkElems) {
+        double *yp = y + 3 * (size_t)nd[n];
+        yp[0] += ys[3 * n]; yp[1] += ys[3 * n + 1]; yp[2] += ys[3 * n + 2];
     }
 }
 
@@ -464,6 +525,14 @@ class HipBackend : public Backend {
     std::vector<EbeGroupDev> ebe_groups_;
     std::vector<EbeRange> ebe_ranges_[2];
     bool ebe_ = false;
+    // chunked matrix-free operator
+    int *d_ch_list_[2] = {nullptr, nullptr};
+    std::vector<int> ch_list_ptr_[2];
+    int4 *d_ch_hdr_ = nullptr;
+    int *d_ch_nodes_ = nullptr;
+    unsigned short *d_ch_lid_ = nullptr;
+    double *d_ch_ck_ = nullptr, *d_ch_ke_ = nullptr;
+    unsigned *d_ch_sgn_ = nullptr;
     // halo
     int *d_send_idx_ = nullptr, *d_fptr_ = nullptr, *d_fpos_ = nullptr;
     int64_t halo_count_ = 0, nb_dofs_ = 0;
@@ -530,6 +599,9 @@ public:
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
+        for (void *p : {(void *)d_ch_list_[0], (void *)d_ch_list_[1], (void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_lid_,
+                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_})
+            if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
             for (void *p : {(void *)D.dof, (void *)D.sgn_bits, (void *)D.sgn_bytes, (void *)D.ck, (void *)D.ke})
                 if (p) (void)hipFree(p);
@@ -584,6 +656,7 @@ public:
         d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
         for (const auto &G : m.groups) {
             EbeGroupDev D{G.nd, G.ne, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (G.ne == 0) { ebe_groups_.push_back(D); continue; }      // handled by the chunked form
             D.dof = (int *)alloc(sizeof(int) * G.dof.size());
             h2d(D.dof, G.dof.data(), sizeof(int) * G.dof.size());
             D.ck = (double *)alloc(sizeof(double) * G.ck.size());
@@ -604,6 +677,21 @@ public:
             ebe_groups_.push_back(D);
         }
         for (int ph = 0; ph < 2; ++ph) ebe_ranges_[ph] = m.ranges[ph];
+        const auto &C = m.chunked;
+        if (C.n_chunks > 0) {
+            auto up = [&](auto *&dst, const auto &v) {
+                using T = std::remove_reference_t<decltype(*dst)>;
+                dst = (T *)alloc(sizeof(v[0]) * v.size());
+                h2d(dst, v.data(), sizeof(v[0]) * v.size());
+            };
+            d_ch_hdr_ = (int4 *)alloc(sizeof(int) * C.hdr.size());
+            h2d(d_ch_hdr_, C.hdr.data(), sizeof(int) * C.hdr.size());
+            up(d_ch_nodes_, C.nodes); up(d_ch_lid_, C.lid); up(d_ch_ck_, C.ck); up(d_ch_sgn_, C.sgn); up(d_ch_ke_, C.ke_col);
+            for (int ph = 0; ph < 2; ++ph) {
+                ch_list_ptr_[ph].assign(C.list_ptr[ph].begin(), C.list_ptr[ph].end());
+                if (!C.list[ph].empty()) up(d_ch_list_[ph], C.list[ph]);
+            }
+        }
     }
     void ebe_launch_range(const EbeRange &r, const double *x, double *y)
     {
@@ -620,7 +708,13 @@ public:
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         if (zero_first) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
-        for (int ph = plo; ph < phi; ++ph)
+        for (int ph = plo; ph < phi; ++ph)                      // chunked groups: one launch per chunk colour
+            for (size_t k = 0; k + 1 < ch_list_ptr_[ph].size(); ++k) {
+                const int lo = ch_list_ptr_[ph][k], cnt = ch_list_ptr_[ph][k + 1] - lo;
+                hipLaunchKernelGGL(k_ebe_chunk24, dim3(cnt), dim3(kChunkElems), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_, d_ch_nodes_,
+                                   d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
+            }
+        for (int ph = plo; ph < phi; ++ph)                      // other pattern types: one launch per element colour
             for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (phi == 2) ++ev_applies_; }

@@ -42,6 +42,7 @@ struct pcg_engine {
     int64_t n_bnd_dofs = 0;           // dofs [0, n_bnd_dofs) may receive interface contributions
     int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
     int32_t n_colors = 0;
+    int64_t n_chunks = 0;
     HaloHost halo;
     bool has_halo = false;
     bool has_masks = false;
@@ -330,7 +331,8 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
 }
 
 int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
-                   const int64_t *node_perm, int64_t n_boundary_nodes, pcg_engine **out)
+                   const int64_t *node_perm, int64_t n_boundary_nodes, const double *node_coords, int32_t flags,
+                   pcg_engine **out)
 {
     return guarded("pcg_create_ebe", [&]() -> int {
         if (!out || !groups || n_nodes <= 0 || n_groups <= 0 || n_nodes > INT32_MAX / 3)
@@ -339,7 +341,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);
         EbeHost m;
-        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, m);
+        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, node_coords, (flags & 1) == 0, m);
         e->kind = 1;
         e->n_nodes = n_nodes;
         e->n = 3 * n_nodes;
@@ -347,6 +349,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         e->n_elem = m.n_elem;
         e->n_slots = m.n_slots;
         e->n_colors = std::max(m.n_colors[0], m.n_colors[1]);
+        e->n_chunks = m.chunked.n_chunks;
         e->be->upload_ebe(m);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
@@ -628,9 +631,10 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
     });
 }
 
-int pcg_operator_info(pcg_engine *e, int32_t *kind, int64_t *n_elem, int64_t *n_slots, int32_t *n_colors)
+int pcg_operator_info(pcg_engine *e, int32_t *kind, int64_t *n_elem, int64_t *n_slots, int32_t *n_colors, int64_t *n_chunks)
 {
     if (!e) return set_error("null");
+    if (n_chunks) *n_chunks = e->n_chunks;
     if (kind) *kind = e->kind;
     if (n_elem) *n_elem = e->n_elem;
     if (n_slots) *n_slots = e->n_slots;

@@ -216,6 +216,8 @@ def make_parts(brick: Brick, elem_part: np.ndarray | None = None, tol: float = 1
             "NDOF": 3 * n_node, "NNode": n_node, "NElem": len(eids),
             "DofVector": dof_ids, "NodeIdVector": node_ids, "ElemIdVector": eids,
             "RefLoadVector": F[dof_ids], "Ud": np.zeros(3 * n_node), "Vd": np.zeros(3 * n_node),
+            "NodeCoordVec": np.stack([node_ids % brick.N, (node_ids // brick.N) % brick.N, node_ids // (brick.N * brick.N)],
+                                     1).astype(float).ravel(),                      # partition_mesh.py:357
             "DofEff": dof_ids[loc_eff], "LocDofEff": loc_eff.astype(np.int64),
             "LocFixedDof": loc_fixed.astype(np.int64),
             "Flat_ElemLocDof": flat, "NCountDof": len(flat),

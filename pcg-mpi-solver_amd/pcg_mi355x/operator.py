@@ -70,7 +70,7 @@ class Operator:
     (`NDOF`) in the REFERENCE's local numbering; the interface-first renumbering is internal."""
 
     def __init__(self, n_nodes, rowptr=None, cols=None, vals=None, n_boundary_nodes=0, dof_new_of_old=None, device=0,
-                 rows_per_lane=0, ebe_groups=None, node_perm=None):
+                 rows_per_lane=0, ebe_groups=None, node_perm=None, node_coords=None, ebe_chunked=True):
         """Assembled operator from 3x3-block CSR (rowptr/cols/vals), or - with `ebe_groups` - the
         matrix-free operator straight from the reference's type-group tables."""
         L = _lib.lib()
@@ -83,8 +83,10 @@ class Operator:
             self.kind = "ebe"
             arr, keep = _pack_groups(ebe_groups)
             perm = None if node_perm is None else np.ascontiguousarray(node_perm, np.int64)
+            xyz = None if node_coords is None else _f64(np.asarray(node_coords).reshape(self.n_nodes, 3))
             check(L.pcg_create_ebe(device, self.n_nodes, len(ebe_groups), arr, perm.ctypes.data if perm is not None else None,
-                                   int(n_boundary_nodes), C.byref(h)), "pcg_create_ebe")
+                                   int(n_boundary_nodes), xyz.ctypes.data if xyz is not None else None,
+                                   0 if ebe_chunked else 1, C.byref(h)), "pcg_create_ebe")
             self.nnzb = self.nnz = 0
         else:
             self.kind = "sell"
@@ -236,9 +238,10 @@ class Operator:
         return ms
 
     def operator_info(self):
-        k, a, b, c = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
-        check(self._L.pcg_operator_info(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c)), "pcg_operator_info")
-        return {"kind": "ebe" if k.value == 1 else "sell", "n_elem": a.value, "n_slots": b.value, "n_colors": c.value}
+        k, a, b, c, d = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
+        check(self._L.pcg_operator_info(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_operator_info")
+        return {"kind": "ebe" if k.value == 1 else "sell", "n_elem": a.value, "n_slots": b.value, "n_colors": c.value,
+                "n_chunks": d.value}
 
     def matrix_info(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
@@ -257,7 +260,7 @@ class Operator:
             pass
 
 
-def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell"):
+def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell", ebe_chunked=True):
     """Build the GPU operator of one RefMeshPart (see module docstring for the keys read).
     kind: "sell" = assembled SELL-BSR3 matrix (default), "ebe" = matrix-free element-by-element."""
     ndof = int(part["NDOF"])
@@ -280,7 +283,9 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
         n_bnd = int(is_b.sum())
         dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
     if kind == "ebe":
-        op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm)
+        xyz = part.get("NodeCoordVec")          # (3*NNode,) x,y,z per node (partition_mesh.py:357); optional
+        op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm,
+                      node_coords=xyz, ebe_chunked=ebe_chunked)
     elif kind == "sell":
         rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
         op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, rows_per_lane)

@@ -30,13 +30,13 @@ __all__ = ["configure", "get_operator", "solve", "PCG", "update_bc", "updateBC",
            "updatePreconditioner", "calc_matvec_prod", "calc_mpfint", "solve_system", "SolveInfo"]
 
 _OP_KEY = "_pcg_mi355x_operator"
-_cfg = {"comm": None, "device": 0, "rows_per_lane": 0, "operator": "sell"}
+_cfg = {"comm": None, "device": 0, "rows_per_lane": 0, "operator": "sell", "ebe_chunked": True}
 
 
-def configure(comm=None, device=0, rows_per_lane=0, operator="sell"):
+def configure(comm=None, device=0, rows_per_lane=0, operator="sell", ebe_chunked=True):
     """Set the process-wide communicator / device (the reference's module globals Comm, Rank :968-970)
     and the operator kind ("sell" = assembled matrix, "ebe" = matrix-free like the reference)."""
-    _cfg.update(comm=comm, device=device, rows_per_lane=rows_per_lane, operator=operator)
+    _cfg.update(comm=comm, device=device, rows_per_lane=rows_per_lane, operator=operator, ebe_chunked=ebe_chunked)
 
 
 def get_operator(RefMeshPart) -> Operator:
@@ -45,7 +45,7 @@ def get_operator(RefMeshPart) -> Operator:
     op = RefMeshPart.get(_OP_KEY)
     if op is None:
         op = from_refmeshpart(RefMeshPart, device=_cfg["device"], comm=_cfg["comm"],
-                              rows_per_lane=_cfg["rows_per_lane"], kind=_cfg["operator"])
+                              rows_per_lane=_cfg["rows_per_lane"], kind=_cfg["operator"], ebe_chunked=_cfg["ebe_chunked"])
         RefMeshPart[_OP_KEY] = op
     return op
 

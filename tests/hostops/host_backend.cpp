@@ -46,6 +46,39 @@ public:
     {
         if (zero_first) std::memset(y, 0, sizeof(double) * n_);
         std::vector<double> u;
+        const auto &C = ebe_.chunked;
+        std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc(24 * kChunkElems);
+        for (int ph = plo; ph < phi; ++ph)
+            for (int32_t cid : C.list[ph]) {                  // launch (chunk-colour) major order
+                const int32_t off = C.hdr[(size_t)cid * 4], nn = C.hdr[(size_t)cid * 4 + 1], nsub = C.hdr[(size_t)cid * 4 + 2];
+                const double *K = &C.ke_col[(size_t)C.hdr[(size_t)cid * 4 + 3] * 576];
+                for (int n = 0; n < nn; ++n)
+                    for (int d = 0; d < 3; ++d) { xs[3 * n + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
+                for (int lane = 0; lane < kChunkElems; ++lane) {
+                    const uint32_t sg = C.sgn[(size_t)cid * kChunkElems + lane];
+                    const double c = C.ck[(size_t)cid * kChunkElems + lane];
+                    double *a = &acc[(size_t)lane * 24];
+                    for (int k = 0; k < 24; ++k) a[k] = 0.0;
+                    for (int b = 0; b < 24; ++b) {
+                        double v = xs[3 * C.lid[((size_t)cid * 8 + b / 3) * kChunkElems + lane] + b % 3];
+                        if ((sg >> b) & 1u) v = -v;
+                        v = c * v;
+                        for (int k = 0; k < 24; ++k) a[k] += K[b * 24 + k] * v;
+                    }
+                }
+                for (int s = 0; s < nsub; ++s)
+                    for (int lane = 0; lane < kChunkElems; ++lane) {
+                        const uint32_t sg = C.sgn[(size_t)cid * kChunkElems + lane];
+                        if ((int)(sg >> 24) != s) continue;
+                        for (int k = 0; k < 24; ++k) {
+                            double o = acc[(size_t)lane * 24 + k];
+                            if ((sg >> k) & 1u) o = -o;
+                            ys[3 * C.lid[((size_t)cid * 8 + k / 3) * kChunkElems + lane] + k % 3] += o;
+                        }
+                    }
+                for (int n = 0; n < nn; ++n)
+                    for (int d = 0; d < 3; ++d) y[3 * (int64_t)C.nodes[off + n] + d] += ys[3 * n + d];
+            }
         for (int ph = plo; ph < phi; ++ph)
             for (const auto &r : ebe_.ranges[ph]) {
                 const auto &G = ebe_.groups[r.group];

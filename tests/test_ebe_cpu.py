@@ -28,7 +28,7 @@ def test_ebe_solve_matches_reference(hostops, name):
     pm.configure(comm=None, operator="ebe")
     op = pm.get_operator(P)
     info = op.operator_info()
-    assert info["kind"] == "ebe" and info["n_colors"] == 8 and info["n_elem"] == brick.n_elem
+    assert info["kind"] == "ebe" and info["n_elem"] == brick.n_elem and info["n_chunks"] == -(-brick.n_elem // 256)
     x = golden_cases.probe_vector(brick)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
     assert np.array_equal(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"])      # same order as np.bincount (:300)
@@ -44,6 +44,23 @@ def test_ebe_solve_matches_reference(hostops, name):
     inf = P["_pcg_mi355x_info"]
     check_solution_against_golden(g, inf.flag, inf.iter, inf.relres, P["Un"], inf.history, tol_iter=1,
                                   tol_u=1e-8 if inf.flag == 0 else 1e-6)
+
+
+@pytest.mark.parametrize("chunked", [True, False])
+def test_chunked_and_per_colour_forms_agree_with_oracle(hostops, chunked):
+    """3 pattern types with sign masks, 2 parts worth of structure in one part: both EBE forms."""
+    from pcg_mi355x.brick import Brick, make_parts
+    b = Brick(12, n_types=3)
+    P = make_parts(b)[0]
+    pm.configure(comm=None, operator="ebe", ebe_chunked=chunked)
+    op = pm.get_operator(P)
+    info = op.operator_info()
+    assert (info["n_chunks"] > 0) == chunked
+    if not chunked:
+        assert info["n_colors"] == 8          # global spatial order keeps the 2x2x2 parity colouring across groups
+    x = np.random.default_rng(2).standard_normal(b.n_dof)
+    assert relerr(op.apply(x), pcg_oracle.matvec_local(P, x)) < 1e-14
+    pm.configure(comm=None, operator="sell")
 
 
 @pytest.mark.parametrize("kind", ["ebe", "sell"])

@@ -234,12 +234,16 @@ def ebe_cfg():
     pm.configure(comm=None, device=0, operator="sell")
 
 
+@pytest.mark.parametrize("chunked", [True, False])
 @pytest.mark.parametrize("n_types", [1, 3])
-def test_ebe_kernel_vs_oracle(gpu_lib, ebe_cfg, n_types):
+def test_ebe_kernel_vs_oracle(gpu_lib, n_types, chunked):
     b = Brick(21, n_types=n_types)
     P = make_parts(b)[0]
+    pm.configure(comm=None, device=0, operator="ebe", ebe_chunked=chunked)
     op = pm.get_operator(P)
-    assert op.operator_info() == {"kind": "ebe", "n_elem": b.n_elem, "n_slots": 24 * b.n_elem, "n_colors": 8}
+    pm.configure(comm=None, device=0, operator="sell")
+    info = op.operator_info()
+    assert info["kind"] == "ebe" and info["n_elem"] == b.n_elem and (info["n_chunks"] > 0) == chunked
     rng = np.random.default_rng(12)
     x = rng.standard_normal(b.n_dof)
     y = op.apply(x)
