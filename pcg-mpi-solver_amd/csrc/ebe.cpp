@@ -75,11 +75,31 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     order.reserve((size_t)out.n_elem);
     double lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
     if (coords) {
+        // lattice units: the smallest element edge (octree meshes have power-of-two multiples of it), so that
+        // Morton cells line up with the element lattice; fall back to stretching the box over 21 bits.
         double hi[3];
         for (int d = 0; d < 3; ++d) { lo[d] = coords[d]; hi[d] = coords[d]; }
         for (int64_t i = 0; i < n_nodes; ++i)
             for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], coords[3 * i + d]); hi[d] = std::max(hi[d], coords[3 * i + d]); }
-        for (int d = 0; d < 3; ++d) inv[d] = hi[d] > lo[d] ? 2097151.0 / (hi[d] - lo[d]) : 0.0;
+        double hmin = 0.0;
+        for (int g = 0; g < n_groups; ++g) {
+            const auto &in = gs[g];
+            for (int64_t e = 0; e < in.ne; ++e) {
+                double a0[3], a1[3];
+                for (int d = 0; d < 3; ++d) { a0[d] = 1e300; a1[d] = -1e300; }
+                for (int a = 0; a < in.nd; a += 3) {
+                    const double *c = coords + 3 * (in.dof[(int64_t)a * in.ne + e] / 3);
+                    for (int d = 0; d < 3; ++d) { a0[d] = std::min(a0[d], c[d]); a1[d] = std::max(a1[d], c[d]); }
+                }
+                for (int d = 0; d < 3; ++d)
+                    if (a1[d] > a0[d] && (hmin == 0.0 || a1[d] - a0[d] < hmin)) hmin = a1[d] - a0[d];
+            }
+        }
+        for (int d = 0; d < 3; ++d) {
+            const double ext = hi[d] - lo[d];
+            if (hmin > 0.0 && ext / hmin < 2097151.0) inv[d] = 1.0 / hmin;
+            else inv[d] = ext > 0 ? 2097151.0 / ext : 0.0;
+        }
     }
     for (int g = 0; g < n_groups; ++g) {
         const auto &in = gs[g];
@@ -89,8 +109,8 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             uint64_t key;
             if (coords) {
                 const double *c = coords + 3 * mn;
-                key = spread21((uint64_t)((c[0] - lo[0]) * inv[0])) | spread21((uint64_t)((c[1] - lo[1]) * inv[1])) << 1 |
-                      spread21((uint64_t)((c[2] - lo[2]) * inv[2])) << 2;
+                key = spread21((uint64_t)((c[0] - lo[0]) * inv[0] + 1e-6)) | spread21((uint64_t)((c[1] - lo[1]) * inv[1] + 1e-6)) << 1 |
+                      spread21((uint64_t)((c[2] - lo[2]) * inv[2] + 1e-6)) << 2;
             } else {
                 key = (uint64_t)mn;
             }
@@ -189,7 +209,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         const auto &in = gs[g];
         const int32_t cid = (int32_t)C.n_chunks++;
         std::sort(o.nodes.begin(), o.nodes.end());
-        o.nodes.erase(std::unique(o.nodes.begin(), o.nodes.end()), o.nodes.end());   // (see NOTE on the shared stamp array)
+        o.nodes.erase(std::unique(o.nodes.begin(), o.nodes.end()), o.nodes.end());
         const int nn = (int)o.nodes.size();
         C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, 0, g24_of[g]});
         C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
@@ -239,33 +259,65 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         o.elems.clear();
         o.nodes.clear();
     };
-    // group by group, elements in the global spatial order
+    // Chunks = octree-like cells: the spatially sorted element list of a group is split recursively at
+    // Morton-bit boundaries until a cell holds <= 256 elements and <= kChunkMaxNodes nodes.  On a uniform
+    // region the cells form a regular lattice of boxes, which the greedy chunk colouring below resolves
+    // with 8 colours.  Without coordinates (keys = node ids) cells are plain runs of <= 256 elements.
     {
-        std::vector<Open> open(n_groups);
-        std::vector<int32_t> open_id(n_groups, 0);           // stamp value of the group's open chunk
         int32_t next_stamp = 0;
-        for (int g = 0; g < n_groups; ++g) open_id[g] = next_stamp++;
-        for (const auto &r : order) {
-            if (!chunkable[r.g]) continue;
-            const auto &in = gs[r.g];
-            Open &o = open[r.g];
-            int fresh = 0;
-            for (int l = 0; l < 8; ++l) {
-                ln[l] = new_node(in.dof[(int64_t)(3 * l) * in.ne + r.e]);
-                if (stamp[ln[l]] != open_id[r.g]) ++fresh;
+        std::vector<std::vector<ElemRef>> per_group(n_groups);
+        for (const auto &r : order)
+            if (chunkable[r.g]) per_group[r.g].push_back(r);
+        for (int g = 0; g < n_groups; ++g) {
+            const auto &in = gs[g];
+            const auto &L = per_group[g];
+            Open o;
+            auto count_nodes = [&](size_t lo_, size_t hi_) {
+                const int32_t id = next_stamp++;
+                int cnt = 0;
+                for (size_t k = lo_; k < hi_; ++k)
+                    for (int l = 0; l < 8; ++l) {
+                        const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
+                        if (stamp[node] != id) { stamp[node] = id; ++cnt; }
+                    }
+                return cnt;
+            };
+            auto emit = [&](size_t lo_, size_t hi_) {
+                const int32_t id = next_stamp++;
+                for (size_t k = lo_; k < hi_; ++k) {
+                    for (int l = 0; l < 8; ++l) {
+                        const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
+                        if (stamp[node] != id) { stamp[node] = id; o.nodes.push_back((int32_t)node); }
+                    }
+                    o.elems.push_back(L[k].e);
+                }
+                close_chunk(g, o);
+            };
+            // explicit stack: (lo, hi, bit)
+            struct Cell { size_t lo, hi; int bit; };
+            std::vector<Cell> stack;
+            if (!L.empty()) stack.push_back(Cell{0, L.size(), coords ? 62 : -1});
+            while (!stack.empty()) {
+                Cell cdesc = stack.back();
+                stack.pop_back();
+                const size_t n_el = cdesc.hi - cdesc.lo;
+                if (n_el <= (size_t)kChunkElems && count_nodes(cdesc.lo, cdesc.hi) <= kChunkMaxNodes) { emit(cdesc.lo, cdesc.hi); continue; }
+                int bit = cdesc.bit;
+                size_t mid = cdesc.lo;
+                while (bit >= 0) {                          // first Morton bit that actually splits the cell
+                    const uint64_t m = 1ull << bit;
+                    mid = (size_t)(std::partition_point(L.begin() + cdesc.lo, L.begin() + cdesc.hi,
+                                                        [&](const ElemRef &r) { return (r.key & m) == 0; }) - L.begin());
+                    if (mid > cdesc.lo && mid < cdesc.hi) break;
+                    --bit;
+                }
+                if (bit < 0) mid = cdesc.lo + std::min<size_t>(n_el / 2, (size_t)kChunkElems);      // no spatial key left: cut the run
+                if (mid == cdesc.lo) mid = cdesc.lo + 1;
+                stack.push_back(Cell{mid, cdesc.hi, bit - 1});                                   // right half later
+                stack.push_back(Cell{cdesc.lo, mid, bit - 1});                                   // left half first (keeps order)
             }
-            if ((int)o.elems.size() == kChunkElems || (int)o.nodes.size() + fresh > kChunkMaxNodes) {
-                close_chunk(r.g, o);
-                open_id[r.g] = next_stamp++;
-            }
-            for (int l = 0; l < 8; ++l)
-                if (stamp[ln[l]] != open_id[r.g]) { stamp[ln[l]] = open_id[r.g]; o.nodes.push_back((int32_t)ln[l]); }
-            o.elems.push_back(r.e);
         }
-        for (int g = 0; g < n_groups; ++g) close_chunk(g, open[g]);
     }
-    // NOTE: one stamp array is shared by the open chunks of all groups; a node stamped by group A's
-    // chunk looks "fresh" to group B's chunk, which is what we want (sets are per chunk).
     // ---- chunk colouring (greedy in creation order) ----------------------------------------------------
     {
         std::vector<uint64_t> used((size_t)n_nodes, 0);

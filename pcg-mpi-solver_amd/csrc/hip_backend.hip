@@ -248,23 +248,38 @@ __global__ __launch_bounds__(kChunkElems) void k_ebe_chunk24(const int *__restri
                                                              const double *__restrict__ ke_col, const double *__restrict__ x,
                                                              double *__restrict__ y)
 {
+    constexpr int NPT = kChunkMaxNodes / kChunkElems;        // tile nodes per thread (3)
     __shared__ double xs[3 * kChunkMaxNodes];
     __shared__ double ys[3 * kChunkMaxNodes];
     const int chunk = chunk_list[blockIdx.x];
     const int4 h = hdr[chunk];                               // node_off, n_nodes, n_sub, group24
     const int *nd = nodes + h.x;
-    for (int n = threadIdx.x; n < h.y; n += kChunkElems) {
-        const double *xp = x + 3 * (size_t)nd[n];
-        xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
-        ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
-    }
-    __syncthreads();
+    // ---- issue every global load of this chunk up front: element data, node ids, x tile, y tile -------
     const size_t t = (size_t)chunk * kChunkElems + threadIdx.x;
     const unsigned sg = __builtin_nontemporal_load(sgn + t);
     const double c = __builtin_nontemporal_load(ck + t);
     int l3[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + threadIdx.x);
+    int gnode[NPT];
+    double yold[NPT][3];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkElems;
+        gnode[j] = n < h.y ? nd[n] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkElems;
+        if (gnode[j] >= 0) {
+            const double *xp = x + 3 * (size_t)gnode[j];
+            const double *yp = y + 3 * (size_t)gnode[j];
+            xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
+            ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
+            yold[j][0] = yp[0]; yold[j][1] = yp[1]; yold[j][2] = yp[2];      // consumed only at the very end
+        }
+    }
+    __syncthreads();
     const double *K = ke_col + (size_t)h.w * 576;
     double acc[24];
 #pragma unroll
@@ -289,9 +304,13 @@ __global__ __launch_bounds__(kChunkElems) void k_ebe_chunk24(const int *__restri
         }
         __syncthreads();
     }
-    for (int n = threadIdx.x; n < h.y; n += kChunkElems) {
-        double *yp = y + 3 * (size_t)nd[n];
-        yp[0] += ys[3 * n]; yp[1] += ys[3 * n + 1]; yp[2] += ys[3 * n + 2];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkElems;
+        if (gnode[j] >= 0) {
+            double *yp = y + 3 * (size_t)gnode[j];
+            yp[0] = yold[j][0] + ys[3 * n]; yp[1] = yold[j][1] + ys[3 * n + 1]; yp[2] = yold[j][2] + ys[3 * n + 2];
+        }
     }
 }
 

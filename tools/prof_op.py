@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""Run a few stand-alone operator applies (for rocprofv3 PMC passes).  usage: prof_op.py [sell|ebe] [N] [reps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
+import numpy as np
+from pcg_mi355x.brick import Brick, make_parts
+from pcg_mi355x.operator import from_refmeshpart
+kind = sys.argv[1] if len(sys.argv) > 1 else "ebe"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+P = make_parts(Brick(N))[0]
+op = from_refmeshpart(P, kind=kind)
+ms = op.bench_spmv(3, reps)
+print(kind, N, op.operator_info(), "median ms", float(np.median(ms)), "min", float(ms.min()))
