@@ -78,7 +78,8 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
  * (pcg_solver.py:265-300); nothing is assembled.  Same groups / numbering arguments as pcg_asm_create. */
 /* node_coords (n_nodes x 3, ORIGINAL node numbering, may be NULL: RefMeshPart['NodeCoordVec'],
  * partition_mesh.py:357) only steers the spatial clustering of elements into workgroup chunks.
- * flags bit0: disable the chunked (LDS-tiled) form and use one colour per launch for every group. */
+ * flags bit0: disable the chunked (LDS-tiled) form and use one colour per launch for every group;
+ *       bit1: one element per thread (256-element chunks) instead of two (512-element chunks). */
 int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
                    const int64_t *node_perm, int64_t n_boundary_nodes, const double *node_coords, int32_t flags,
                    pcg_engine **out);

@@ -43,9 +43,12 @@ bool node_blocked24(const pcg_elem_group &g)
 }  // namespace
 
 void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, const int64_t *perm,
-               int64_t n_boundary_nodes, const double *coords, bool allow_chunked, EbeHost &out)
+               int64_t n_boundary_nodes, const double *coords, bool allow_chunked, int ept, EbeHost &out)
 {
+    if (ept != 1 && ept != 2) throw std::runtime_error("ebe: elements per thread must be 1 or 2");
+    const int kChunkElems = kChunkThreads * ept;
     out = EbeHost();
+    out.chunked.ept = ept;
     out.n_nodes = n_nodes;
     out.groups.resize(n_groups);
     out.diag.assign((size_t)n_nodes * 3, 0.0);

@@ -235,42 +235,50 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
     }
 }
 
-// Chunked form (EbeChunkedHost): one workgroup = one chunk of <= 256 hex8-like elements.
+// Chunked form (EbeChunkedHost): one workgroup (256 threads, 2 elements each) = one chunk of <= 512 hex8-like elements.
 //   1. the chunk's unique nodes are staged into LDS (x tile) with node-contiguous global loads,
 //   2. each lane = one element: u_b from the LDS tile, 24 independent FMA chains acc[a] += Ke[a][b]*u_b
 //      with Ke (column-major, wave-uniform) streamed through SGPRs by scalar loads,
 //   3. LDS-staged partial sums: the lanes add their 24 outputs into the LDS y tile sub-colour by
 //      sub-colour (no two lanes of a sub-colour share a node; fixed order -> deterministic),
 //   4. the y tile is added to global y (chunks of one launch share no node -> no atomics).
-__global__ __launch_bounds__(kChunkElems) void k_ebe_chunk24(const int *__restrict__ chunk_list, const int4 *__restrict__ hdr,
-                                                             const int *__restrict__ nodes, const unsigned short *__restrict__ lid,
-                                                             const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-                                                             const double *__restrict__ ke_col, const double *__restrict__ x,
-                                                             double *__restrict__ y)
+template <int EPT>
+__global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk24(const int *__restrict__ chunk_list, const int4 *__restrict__ hdr,
+                                                               const int *__restrict__ nodes, const unsigned short *__restrict__ lid,
+                                                               const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+                                                               const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                               double *__restrict__ y)
 {
-    constexpr int NPT = kChunkMaxNodes / kChunkElems;        // tile nodes per thread (3)
+    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
+    constexpr int kChunkElems = kChunkThreads * EPT;         // EPT elements per thread: one Ke stream feeds all of them
     __shared__ double xs[3 * kChunkMaxNodes];
     __shared__ double ys[3 * kChunkMaxNodes];
     const int chunk = chunk_list[blockIdx.x];
     const int4 h = hdr[chunk];                               // node_off, n_nodes, n_sub, group24
     const int *nd = nodes + h.x;
     // ---- issue every global load of this chunk up front: element data, node ids, x tile, y tile -------
-    const size_t t = (size_t)chunk * kChunkElems + threadIdx.x;
-    const unsigned sg = __builtin_nontemporal_load(sgn + t);
-    const double c = __builtin_nontemporal_load(ck + t);
-    int l3[8];
+    unsigned sg[EPT];
+    double c[EPT];
+    int l3[EPT][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + threadIdx.x);
+    for (int j = 0; j < EPT; ++j) {
+        const size_t t = (size_t)chunk * kChunkElems + j * kChunkThreads + threadIdx.x;
+        sg[j] = __builtin_nontemporal_load(sgn + t);
+        c[j] = __builtin_nontemporal_load(ck + t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + j * kChunkThreads + threadIdx.x);
+    }
     int gnode[NPT];
     double yold[NPT][3];
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkElems;
+        const int n = threadIdx.x + j * kChunkThreads;
         gnode[j] = n < h.y ? nd[n] : -1;
     }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkElems;
+        const int n = threadIdx.x + j * kChunkThreads;
         if (gnode[j] >= 0) {
             const double *xp = x + 3 * (size_t)gnode[j];
             const double *yp = y + 3 * (size_t)gnode[j];
@@ -281,32 +289,43 @@ __global__ __launch_bounds__(kChunkElems) void k_ebe_chunk24(const int *__restri
     }
     __syncthreads();
     const double *K = ke_col + (size_t)h.w * 576;
-    double acc[24];
+    double acc[EPT][24];
 #pragma unroll
-    for (int a = 0; a < 24; ++a) acc[a] = 0.0;
+    for (int j = 0; j < EPT; ++j)
+#pragma unroll
+        for (int a = 0; a < 24; ++a) acc[j][a] = 0.0;
 #pragma unroll
     for (int b = 0; b < 24; ++b) {
-        double u = xs[l3[b / 3] + b % 3];                    // :277 gather (from the LDS tile)
-        if ((sg >> b) & 1u) u = -u;                          // :278
-        u = c * u;                                           // :279 Ck * U
+        double u[EPT];
 #pragma unroll
-        for (int a = 0; a < 24; ++a) acc[a] = fma(K[b * 24 + a], u, acc[a]);   // :279 Ke @ (.)
-    }
-    const int mysc = (int)(sg >> 24);
-    for (int s = 0; s < h.z; ++s) {
-        if (mysc == s) {
-#pragma unroll
-            for (int a = 0; a < 24; ++a) {
-                double o = acc[a];
-                if ((sg >> a) & 1u) o = -o;                  // :280
-                ys[l3[a / 3] + a % 3] += o;                  // :300, LDS-staged partial sums
-            }
+        for (int j = 0; j < EPT; ++j) {
+            double v = xs[l3[j][b / 3] + b % 3];             // :277 gather (from the LDS tile)
+            if ((sg[j] >> b) & 1u) v = -v;                   // :278
+            u[j] = c[j] * v;                                 // :279 Ck * U
         }
+#pragma unroll
+        for (int a = 0; a < 24; ++a) {
+            const double k = K[b * 24 + a];                  // wave-uniform -> SGPR pair, shared by both elements
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
+        }
+    }
+    for (int s = 0; s < h.z; ++s) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            if ((int)(sg[j] >> 24) == s) {
+#pragma unroll
+                for (int a = 0; a < 24; ++a) {
+                    double o = acc[j][a];
+                    if ((sg[j] >> a) & 1u) o = -o;           // :280
+                    ys[l3[j][a / 3] + a % 3] += o;           // :300, LDS-staged partial sums
+                }
+            }
         __syncthreads();
     }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkElems;
+        const int n = threadIdx.x + j * kChunkThreads;
         if (gnode[j] >= 0) {
             double *yp = y + 3 * (size_t)gnode[j];
             yp[0] = yold[j][0] + ys[3 * n]; yp[1] = yold[j][1] + ys[3 * n + 1]; yp[2] = yold[j][2] + ys[3 * n + 2];
@@ -548,6 +567,7 @@ class HipBackend : public Backend {
     int *d_ch_list_[2] = {nullptr, nullptr};
     std::vector<int> ch_list_ptr_[2];
     int4 *d_ch_hdr_ = nullptr;
+    int ch_ept_ = 1;
     int *d_ch_nodes_ = nullptr;
     unsigned short *d_ch_lid_ = nullptr;
     double *d_ch_ck_ = nullptr, *d_ch_ke_ = nullptr;
@@ -697,6 +717,7 @@ public:
         }
         for (int ph = 0; ph < 2; ++ph) ebe_ranges_[ph] = m.ranges[ph];
         const auto &C = m.chunked;
+        ch_ept_ = C.ept;
         if (C.n_chunks > 0) {
             auto up = [&](auto *&dst, const auto &v) {
                 using T = std::remove_reference_t<decltype(*dst)>;
@@ -730,8 +751,12 @@ public:
         for (int ph = plo; ph < phi; ++ph)                      // chunked groups: one launch per chunk colour
             for (size_t k = 0; k + 1 < ch_list_ptr_[ph].size(); ++k) {
                 const int lo = ch_list_ptr_[ph][k], cnt = ch_list_ptr_[ph][k + 1] - lo;
-                hipLaunchKernelGGL(k_ebe_chunk24, dim3(cnt), dim3(kChunkElems), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_, d_ch_nodes_,
-                                   d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
+                if (ch_ept_ == 1)
+                    hipLaunchKernelGGL((k_ebe_chunk24<1>), dim3(cnt), dim3(kChunkThreads), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_,
+                                       d_ch_nodes_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
+                else
+                    hipLaunchKernelGGL((k_ebe_chunk24<2>), dim3(cnt), dim3(kChunkThreads), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_,
+                                       d_ch_nodes_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
             }
         for (int ph = plo; ph < phi; ++ph)                      // other pattern types: one launch per element colour
             for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);

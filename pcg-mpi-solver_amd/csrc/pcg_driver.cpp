@@ -341,7 +341,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);
         EbeHost m;
-        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, node_coords, (flags & 1) == 0, m);
+        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, node_coords, (flags & 1) == 0, (flags & 2) ? 1 : 2, m);
         e->kind = 1;
         e->n_nodes = n_nodes;
         e->n = 3 * n_nodes;

@@ -52,19 +52,20 @@ struct EbeGroupHost {
 struct EbeRange { int32_t group; int64_t lo, hi; };      // elements [lo,hi) of `group`: one launch
 
 // Chunked form for hex8-like groups (nd == 24, slots 3l..3l+2 = the three dofs of local node l):
-// a chunk = up to 256 spatially clustered elements of one group = one workgroup.  The chunk's unique
+// a chunk = up to 512 spatially clustered elements of one group = one workgroup.  The chunk's unique
 // nodes are staged in LDS (x tile in, y tile out); elements of a chunk are sub-coloured and add into
 // the LDS y tile phase by phase; chunks are coloured so that the chunks of one launch share no node.
 // Every global x / y entry is then touched ~1.5x per apply instead of 8x, in node-contiguous runs.
-constexpr int kChunkElems = 256;
-constexpr int kChunkMaxNodes = 768;
+constexpr int kChunkThreads = 256;                 // workgroup size
+constexpr int kChunkMaxNodes = 768;                // 8x8x8 hex cells -> 729 nodes (LDS x + y tiles = 36.9 KB)
 struct EbeChunkedHost {
+    int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (1 or 2; 2 amortises the Ke stream)
     int64_t n_chunks = 0;
     std::vector<int32_t> hdr;          // (n_chunks, 4): node_off, n_nodes, n_subcolors, group24 index
     std::vector<int32_t> nodes;        // concatenated unique node ids (engine numbering, ascending per chunk)
-    std::vector<uint16_t> lid;         // (n_chunks, 8, 256) local node index of element-node l
-    std::vector<double> ck;            // (n_chunks, 256)   (0 for padding lanes)
-    std::vector<uint32_t> sgn;         // (n_chunks, 256)   bits 0..23 sign mask, bits 24..31 sub-colour (255 = padding)
+    std::vector<uint16_t> lid;         // (n_chunks, 8, 256*ept) local node index of element-node l
+    std::vector<double> ck;            // (n_chunks, 256*ept)   (0 for padding slots)
+    std::vector<uint32_t> sgn;         // (n_chunks, 256*ept)   bits 0..23 sign mask, bits 24..31 sub-colour (255 = padding)
     std::vector<double> ke_col;        // (n_group24, 24 b, 24 a) column-major element matrices
     std::vector<int32_t> list[2];      // per phase: chunk ids, launch (= chunk colour) major
     std::vector<int32_t> list_ptr[2];  // per phase: offsets of the launches in `list`
@@ -80,7 +81,7 @@ struct EbeHost {
     int64_t n_elem = 0, n_slots = 0;                      // totals (sum nd*ne = NCountDof)
 };
 void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups, const int64_t *node_perm,
-               int64_t n_boundary_nodes, const double *node_coords, bool allow_chunked, EbeHost &out);
+               int64_t n_boundary_nodes, const double *node_coords, bool allow_chunked, int ept, EbeHost &out);
 
 // ---- device back end ----------------------------------------------------------------------------
 // The product library implements this with hand-written HIP kernels (hip_backend.hip).  The ONLY

@@ -86,7 +86,8 @@ class Operator:
             xyz = None if node_coords is None else _f64(np.asarray(node_coords).reshape(self.n_nodes, 3))
             check(L.pcg_create_ebe(device, self.n_nodes, len(ebe_groups), arr, perm.ctypes.data if perm is not None else None,
                                    int(n_boundary_nodes), xyz.ctypes.data if xyz is not None else None,
-                                   0 if ebe_chunked else 1, C.byref(h)), "pcg_create_ebe")
+                                   (0 if ebe_chunked else 1) | (2 if os.environ.get("PCG_EBE_EPT", "2") == "1" else 0),
+                                   C.byref(h)), "pcg_create_ebe")
             self.nnzb = self.nnz = 0
         else:
             self.kind = "sell"

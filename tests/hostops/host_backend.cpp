@@ -47,7 +47,8 @@ public:
         if (zero_first) std::memset(y, 0, sizeof(double) * n_);
         std::vector<double> u;
         const auto &C = ebe_.chunked;
-        std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc(24 * kChunkElems);
+        const int kChunkElems = kChunkThreads * C.ept;
+        std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc(24 * (size_t)kChunkElems);
         for (int ph = plo; ph < phi; ++ph)
             for (int32_t cid : C.list[ph]) {                  // launch (chunk-colour) major order
                 const int32_t off = C.hdr[(size_t)cid * 4], nn = C.hdr[(size_t)cid * 4 + 1], nsub = C.hdr[(size_t)cid * 4 + 2];

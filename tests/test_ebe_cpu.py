@@ -28,7 +28,7 @@ def test_ebe_solve_matches_reference(hostops, name):
     pm.configure(comm=None, operator="ebe")
     op = pm.get_operator(P)
     info = op.operator_info()
-    assert info["kind"] == "ebe" and info["n_elem"] == brick.n_elem and info["n_chunks"] >= -(-brick.n_elem // 256)
+    assert info["kind"] == "ebe" and info["n_elem"] == brick.n_elem and info["n_chunks"] >= -(-brick.n_elem // 512)
     x = golden_cases.probe_vector(brick)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
     assert np.array_equal(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"])      # same order as np.bincount (:300)
@@ -47,8 +47,10 @@ def test_ebe_solve_matches_reference(hostops, name):
 
 
 @pytest.mark.parametrize("chunked", [True, False])
-def test_chunked_and_per_colour_forms_agree_with_oracle(hostops, chunked):
-    """3 pattern types with sign masks, 2 parts worth of structure in one part: both EBE forms."""
+@pytest.mark.parametrize("ept", ["1", "2"])
+def test_chunked_and_per_colour_forms_agree_with_oracle(hostops, chunked, ept, monkeypatch):
+    """3 pattern types with sign masks: per-colour form and chunked form (1 and 2 elements per thread)."""
+    monkeypatch.setenv("PCG_EBE_EPT", ept)
     from pcg_mi355x.brick import Brick, make_parts
     b = Brick(12, n_types=3)
     P = make_parts(b)[0]
