@@ -321,31 +321,48 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             }
         }
     }
-    // ---- chunk colouring (greedy in creation order) ----------------------------------------------------
+    // ---- exclusive / shared tile nodes, boundary slots, per-phase fix-up lists ----------------------------
     {
-        std::vector<uint64_t> used((size_t)n_nodes, 0);
-        std::vector<int> ccol((size_t)C.n_chunks);
-        int maxc = -1;
+        std::vector<int32_t> cnt((size_t)n_nodes, 0);
+        for (int32_t nd : C.nodes) cnt[nd]++;
+        for (int64_t i = 0; i < n_nodes; ++i)
+            if (cnt[i] == 0) { C.needs_zero = true; break; }
+        // phase in which a shared node becomes final = max phase of the chunks that contain it
+        std::vector<uint8_t> final_phase((size_t)n_nodes, 0);
         for (int64_t c = 0; c < C.n_chunks; ++c) {
             const int32_t off = C.hdr[(size_t)c * 4], nn = C.hdr[(size_t)c * 4 + 1];
-            uint64_t forb = 0;
-            for (int k = 0; k < nn; ++k) forb |= used[C.nodes[off + k]];
-            if (~forb == 0) throw std::runtime_error("ebe: more than 64 chunk colours needed");
-            const int col = __builtin_ctzll(~forb);
-            for (int k = 0; k < nn; ++k) used[C.nodes[off + k]] |= (1ull << col);
-            ccol[c] = col;
-            maxc = std::max(maxc, col);
+            for (int k = 0; k < nn; ++k) final_phase[C.nodes[off + k]] = std::max(final_phase[C.nodes[off + k]], chunk_phase[c]);
         }
+        std::vector<int32_t> sh_index((size_t)n_nodes, -1);           // index into sh_node of its final phase
+        for (int64_t i = 0; i < n_nodes; ++i)
+            if (cnt[i] > 1) {
+                const int ph = final_phase[i];
+                sh_index[i] = (int32_t)C.sh_node[ph].size();
+                C.sh_node[ph].push_back((int32_t)i);
+            }
         for (int ph = 0; ph < 2; ++ph) {
-            C.list_ptr[ph].push_back(0);
-            for (int col = 0; col <= maxc; ++col) {
-                for (int64_t c = 0; c < C.n_chunks; ++c)
-                    if (chunk_phase[c] == ph && ccol[c] == col) C.list[ph].push_back((int32_t)c);
-                if ((int32_t)C.list[ph].size() > C.list_ptr[ph].back()) C.list_ptr[ph].push_back((int32_t)C.list[ph].size());
+            C.sh_ptr[ph].assign(C.sh_node[ph].size() + 1, 0);
+            for (size_t k = 0; k < C.sh_node[ph].size(); ++k) C.sh_ptr[ph][k + 1] = C.sh_ptr[ph][k] + cnt[C.sh_node[ph][k]];
+            C.sh_slot[ph].assign((size_t)C.sh_ptr[ph].back(), 0);
+        }
+        std::vector<int32_t> fill[2];
+        for (int ph = 0; ph < 2; ++ph) fill[ph].assign(C.sh_ptr[ph].begin(), C.sh_ptr[ph].end() - 1);
+        C.dst.resize(C.nodes.size());
+        for (int64_t c = 0; c < C.n_chunks; ++c) {                     // ascending chunk id = summation order
+            const int32_t off = C.hdr[(size_t)c * 4], nn = C.hdr[(size_t)c * 4 + 1];
+            for (int k = 0; k < nn; ++k) {
+                const int32_t nd = C.nodes[off + k];
+                if (cnt[nd] == 1) { C.dst[off + k] = 3 * nd; continue; }
+                const int32_t slot = (int32_t)C.n_slots++;
+                C.dst[off + k] = -(slot + 1);
+                const int ph = final_phase[nd];
+                C.sh_slot[ph][fill[ph][sh_index[nd]]++] = slot;
             }
         }
-        out.n_colors[0] = std::max<int32_t>(out.n_colors[0], (int32_t)C.list_ptr[0].size() - 1);
-        out.n_colors[1] = std::max<int32_t>(out.n_colors[1], (int32_t)C.list_ptr[1].size() - 1);
+        for (int64_t c = 0; c < C.n_chunks; ++c) C.list[chunk_phase[c]].push_back((int32_t)c);
+        out.n_colors[0] = std::max<int32_t>(out.n_colors[0], C.list[0].empty() ? 0 : 1);
+        out.n_colors[1] = std::max<int32_t>(out.n_colors[1], C.list[1].empty() ? 0 : 1);
+        if (!out.ranges[0].empty() || !out.ranges[1].empty()) C.needs_zero = true;   // other groups accumulate with +=
     }
 }
 

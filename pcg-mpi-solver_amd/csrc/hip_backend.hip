@@ -235,28 +235,28 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
     }
 }
 
-// Chunked form (EbeChunkedHost): one workgroup (256 threads, 2 elements each) = one chunk of <= 512 hex8-like elements.
+// Chunked form (EbeChunkedHost): one workgroup (256 threads, EPT elements each) = one chunk of hex8-like elements.
 //   1. the chunk's unique nodes are staged into LDS (x tile) with node-contiguous global loads,
 //   2. each lane = one element: u_b from the LDS tile, 24 independent FMA chains acc[a] += Ke[a][b]*u_b
 //      with Ke (column-major, wave-uniform) streamed through SGPRs by scalar loads,
 //   3. LDS-staged partial sums: the lanes add their 24 outputs into the LDS y tile sub-colour by
 //      sub-colour (no two lanes of a sub-colour share a node; fixed order -> deterministic),
-//   4. the y tile is added to global y (chunks of one launch share no node -> no atomics).
+//   4. tile nodes owned by this chunk alone are stored straight to y; nodes shared with other chunks go
+//      to this chunk's slots of the boundary buffer, summed afterwards by k_ebe_shared in chunk order.
+// All chunks of a phase are ONE launch (no colour-by-colour launches, no read-modify-write of y).
 template <int EPT>
-__global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk24(const int *__restrict__ chunk_list, const int4 *__restrict__ hdr,
-                                                               const int *__restrict__ nodes, const unsigned short *__restrict__ lid,
-                                                               const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-                                                               const double *__restrict__ ke_col, const double *__restrict__ x,
-                                                               double *__restrict__ y)
+__global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk24(
+    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
+    const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf)
 {
     constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
-    constexpr int kChunkElems = kChunkThreads * EPT;         // EPT elements per thread: one Ke stream feeds all of them
+    constexpr int kChunkElems = kChunkThreads * EPT;
     __shared__ double xs[3 * kChunkMaxNodes];
     __shared__ double ys[3 * kChunkMaxNodes];
     const int chunk = chunk_list[blockIdx.x];
     const int4 h = hdr[chunk];                               // node_off, n_nodes, n_sub, group24
-    const int *nd = nodes + h.x;
-    // ---- issue every global load of this chunk up front: element data, node ids, x tile, y tile -------
+    // ---- issue every global load of this chunk up front: element data, node ids, x tile ---------------
     unsigned sg[EPT];
     double c[EPT];
     int l3[EPT][8];
@@ -269,22 +269,17 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
         for (int k = 0; k < 8; ++k)
             l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + j * kChunkThreads + threadIdx.x);
     }
-    int gnode[NPT];
-    double yold[NPT][3];
+    int dst[NPT];
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int n = threadIdx.x + j * kChunkThreads;
-        gnode[j] = n < h.y ? nd[n] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        if (gnode[j] >= 0) {
-            const double *xp = x + 3 * (size_t)gnode[j];
-            const double *yp = y + 3 * (size_t)gnode[j];
+        int g = -1;
+        dst[j] = 0;
+        if (n < h.y) { g = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n); }
+        if (g >= 0) {
+            const double *xp = x + 3 * (size_t)g;
             xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
             ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
-            yold[j][0] = yp[0]; yold[j][1] = yp[1]; yold[j][2] = yp[2];      // consumed only at the very end
         }
     }
     __syncthreads();
@@ -305,7 +300,7 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
         }
 #pragma unroll
         for (int a = 0; a < 24; ++a) {
-            const double k = K[b * 24 + a];                  // wave-uniform -> SGPR pair, shared by both elements
+            const double k = K[b * 24 + a];                  // wave-uniform -> SGPR pair
 #pragma unroll
             for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
         }
@@ -313,12 +308,15 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
     for (int s = 0; s < h.z; ++s) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
-            if ((int)(sg[j] >> 24) == s) {
+            if ((int)(sg[j] >> 24) == s) {                   // the 24 targets of one element are distinct: batch the reads
+                double old[24];
+#pragma unroll
+                for (int a = 0; a < 24; ++a) old[a] = ys[l3[j][a / 3] + a % 3];
 #pragma unroll
                 for (int a = 0; a < 24; ++a) {
                     double o = acc[j][a];
                     if ((sg[j] >> a) & 1u) o = -o;           // :280
-                    ys[l3[j][a / 3] + a % 3] += o;           // :300, LDS-staged partial sums
+                    ys[l3[j][a / 3] + a % 3] = old[a] + o;   // :300, LDS-staged partial sums
                 }
             }
         __syncthreads();
@@ -326,11 +324,27 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int n = threadIdx.x + j * kChunkThreads;
-        if (gnode[j] >= 0) {
-            double *yp = y + 3 * (size_t)gnode[j];
-            yp[0] = yold[j][0] + ys[3 * n]; yp[1] = yold[j][1] + ys[3 * n + 1]; yp[2] = yold[j][2] + ys[3 * n + 2];
+        if (n < h.y) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            out[0] = ys[3 * n]; out[1] = ys[3 * n + 1]; out[2] = ys[3 * n + 2];
         }
     }
+}
+
+// nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id
+__global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
+                                                       const int *__restrict__ sh_slot, const double *__restrict__ buf,
+                                                       double *__restrict__ y, int count)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = sh_ptr[k]; q < sh_ptr[k + 1]; ++q) {
+        const double *b = buf + 3 * (size_t)sh_slot[q];
+        s0 += b[0]; s1 += b[1]; s2 += b[2];
+    }
+    double *yp = y + 3 * (size_t)sh_node[k];
+    yp[0] = s0; yp[1] = s1; yp[2] = s2;
 }
 
 // any nd (hanging-node patterns): same algorithm, x re-gathered per block of 4 output rows
@@ -565,7 +579,11 @@ class HipBackend : public Backend {
     bool ebe_ = false;
     // chunked matrix-free operator
     int *d_ch_list_[2] = {nullptr, nullptr};
-    std::vector<int> ch_list_ptr_[2];
+    int ch_count_[2] = {0, 0}, sh_count_[2] = {0, 0};
+    int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr}, *d_sh_slot_[2] = {nullptr, nullptr};
+    int *d_ch_dst_ = nullptr;
+    double *d_ch_buf_ = nullptr;
+    bool ch_needs_zero_ = true;
     int4 *d_ch_hdr_ = nullptr;
     int ch_ept_ = 1;
     int *d_ch_nodes_ = nullptr;
@@ -639,7 +657,8 @@ public:
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)d_ch_list_[0], (void *)d_ch_list_[1], (void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_lid_,
-                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_})
+                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_sh_node_[0],
+                        (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1], (void *)d_sh_slot_[0], (void *)d_sh_slot_[1]})
             if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
             for (void *p : {(void *)D.dof, (void *)D.sgn_bits, (void *)D.sgn_bytes, (void *)D.ck, (void *)D.ke})
@@ -726,10 +745,15 @@ public:
             };
             d_ch_hdr_ = (int4 *)alloc(sizeof(int) * C.hdr.size());
             h2d(d_ch_hdr_, C.hdr.data(), sizeof(int) * C.hdr.size());
-            up(d_ch_nodes_, C.nodes); up(d_ch_lid_, C.lid); up(d_ch_ck_, C.ck); up(d_ch_sgn_, C.sgn); up(d_ch_ke_, C.ke_col);
+            up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst); up(d_ch_lid_, C.lid); up(d_ch_ck_, C.ck); up(d_ch_sgn_, C.sgn);
+            up(d_ch_ke_, C.ke_col);
+            d_ch_buf_ = (double *)alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(1, C.n_slots));
+            ch_needs_zero_ = C.needs_zero;
             for (int ph = 0; ph < 2; ++ph) {
-                ch_list_ptr_[ph].assign(C.list_ptr[ph].begin(), C.list_ptr[ph].end());
-                if (!C.list[ph].empty()) up(d_ch_list_[ph], C.list[ph]);
+                ch_count_[ph] = (int)C.list[ph].size();
+                if (ch_count_[ph]) up(d_ch_list_[ph], C.list[ph]);
+                sh_count_[ph] = (int)C.sh_node[ph].size();
+                if (sh_count_[ph]) { up(d_sh_node_[ph], C.sh_node[ph]); up(d_sh_ptr_[ph], C.sh_ptr[ph]); up(d_sh_slot_[ph], C.sh_slot[ph]); }
             }
         }
     }
@@ -747,17 +771,20 @@ public:
     {
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
-        if (zero_first) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
-        for (int ph = plo; ph < phi; ++ph)                      // chunked groups: one launch per chunk colour
-            for (size_t k = 0; k + 1 < ch_list_ptr_[ph].size(); ++k) {
-                const int lo = ch_list_ptr_[ph][k], cnt = ch_list_ptr_[ph][k + 1] - lo;
+        if (zero_first && ch_needs_zero_) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
+        for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
+            if (ch_count_[ph]) {
                 if (ch_ept_ == 1)
-                    hipLaunchKernelGGL((k_ebe_chunk24<1>), dim3(cnt), dim3(kChunkThreads), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_,
-                                       d_ch_nodes_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
+                    hipLaunchKernelGGL((k_ebe_chunk24<1>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
+                                       d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_);
                 else
-                    hipLaunchKernelGGL((k_ebe_chunk24<2>), dim3(cnt), dim3(kChunkThreads), 0, st_, d_ch_list_[ph] + lo, d_ch_hdr_,
-                                       d_ch_nodes_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y);
+                    hipLaunchKernelGGL((k_ebe_chunk24<2>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
+                                       d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_);
             }
+            if (sh_count_[ph])
+                hipLaunchKernelGGL(k_ebe_shared, dim3((sh_count_[ph] + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, d_sh_node_[ph],
+                                   d_sh_ptr_[ph], d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph]);
+        }
         for (int ph = plo; ph < phi; ++ph)                      // other pattern types: one launch per element colour
             for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);
         HIP_CHECK(hipGetLastError());

@@ -18,6 +18,7 @@ namespace pcg {
 class HostBackend : public Backend {
     SellHost m_;
     EbeHost ebe_;
+    std::vector<double> ebuf_;
     std::vector<uint8_t> flags_;
     HaloHost h_;
     double dot_spmv_ = 0, dot_fix_ = 0, dotw_ = 0;
@@ -44,13 +45,14 @@ public:
     }
     void ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first) override
     {
-        if (zero_first) std::memset(y, 0, sizeof(double) * n_);
-        std::vector<double> u;
         const auto &C = ebe_.chunked;
+        if (zero_first && (C.n_chunks == 0 || C.needs_zero)) std::memset(y, 0, sizeof(double) * n_);
+        std::vector<double> u;
         const int kChunkElems = kChunkThreads * C.ept;
         std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc(24 * (size_t)kChunkElems);
-        for (int ph = plo; ph < phi; ++ph)
-            for (int32_t cid : C.list[ph]) {                  // launch (chunk-colour) major order
+        if (ebuf_.size() < (size_t)C.n_slots * 3) ebuf_.assign((size_t)C.n_slots * 3, 0.0);
+        for (int ph = plo; ph < phi; ++ph) {
+            for (int32_t cid : C.list[ph]) {
                 const int32_t off = C.hdr[(size_t)cid * 4], nn = C.hdr[(size_t)cid * 4 + 1], nsub = C.hdr[(size_t)cid * 4 + 2];
                 const double *K = &C.ke_col[(size_t)C.hdr[(size_t)cid * 4 + 3] * 576];
                 for (int n = 0; n < nn; ++n)
@@ -77,9 +79,19 @@ public:
                             ys[3 * C.lid[((size_t)cid * 8 + k / 3) * kChunkElems + lane] + k % 3] += o;
                         }
                     }
-                for (int n = 0; n < nn; ++n)
-                    for (int d = 0; d < 3; ++d) y[3 * (int64_t)C.nodes[off + n] + d] += ys[3 * n + d];
+                for (int n = 0; n < nn; ++n) {
+                    const int32_t dst = C.dst[off + n];
+                    double *out = dst >= 0 ? y + dst : &ebuf_[(size_t)(-dst - 1) * 3];
+                    for (int d = 0; d < 3; ++d) out[d] = ys[3 * n + d];
+                }
             }
+            for (size_t k = 0; k < C.sh_node[ph].size(); ++k)          // shared nodes: slots in chunk order
+                for (int d = 0; d < 3; ++d) {
+                    double sum = 0.0;
+                    for (int32_t q = C.sh_ptr[ph][k]; q < C.sh_ptr[ph][k + 1]; ++q) sum += ebuf_[(size_t)C.sh_slot[ph][q] * 3 + d];
+                    y[3 * (int64_t)C.sh_node[ph][k] + d] = sum;
+                }
+        }
         for (int ph = plo; ph < phi; ++ph)
             for (const auto &r : ebe_.ranges[ph]) {
                 const auto &G = ebe_.groups[r.group];
