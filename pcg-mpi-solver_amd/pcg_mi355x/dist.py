@@ -47,6 +47,7 @@ class TorchComm:
         self.on_gpu = self.backend == "nccl"
         self.device = device
         self._views = {}
+        self._streams = {}
         self._exc = None
         self._work = None
         self.t_comm = 0.0
@@ -66,11 +67,17 @@ class TorchComm:
             self._views[key] = t
         return t
 
-    def _stream_ctx(self, stream_ptr):
-        if self.on_gpu:
-            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream_ptr or 0)))
-        import contextlib
-        return contextlib.nullcontext()
+    def _use_stream(self, stream_ptr):
+        """Make the engine's HIP stream torch's current stream (sticky: one switch per solve, not one
+        context manager per hook call - the hooks run 3-4 times per PCG iteration)."""
+        if not self.on_gpu:
+            return
+        key = int(stream_ptr or 0)
+        ext = self._streams.get(key)
+        if ext is None:
+            ext = self._streams[key] = torch.cuda.ExternalStream(key)
+        if torch.cuda.current_stream().cuda_stream != key:
+            torch.cuda.set_stream(ext)
 
     def reraise(self):
         if self._exc is not None:
@@ -94,8 +101,8 @@ class TorchComm:
                 t0 = time.perf_counter()
                 send = self._tensor(send_p, count)
                 recv = self._tensor(recv_p, count)
-                with self._stream_ctx(stream_p):
-                    self._work = dist.all_to_all_single(recv, send, splits, splits, group=self.group, async_op=True)
+                self._use_stream(stream_p)
+                self._work = dist.all_to_all_single(recv, send, splits, splits, group=self.group, async_op=True)
                 self.n_halo += 1
                 self.t_comm += time.perf_counter() - t0
                 return 0
@@ -106,8 +113,8 @@ class TorchComm:
         def halo_end(ctx, stream_p):
             try:
                 t0 = time.perf_counter()
-                with self._stream_ctx(stream_p):
-                    self._work.wait()
+                self._use_stream(stream_p)
+                self._work.wait()
                 self._work = None
                 self.t_comm += time.perf_counter() - t0
                 return 0
@@ -119,8 +126,8 @@ class TorchComm:
             try:
                 t0 = time.perf_counter()
                 t = self._tensor(buf_p, count)
-                with self._stream_ctx(stream_p):
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self._use_stream(stream_p)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 self.n_allreduce += 1
                 self.t_comm += time.perf_counter() - t0
                 return 0
