@@ -124,7 +124,7 @@ typedef struct {
     int32_t flag;          /* 0 converged, 1 MaxIter, 2 inf in M^-1 r, 3 stagnation, 4 breakdown  */
     int32_t status;        /* PCG_STATUS_*; TOO_SMALL_TOL = the reference's raise Warning (:549)  */
     int64_t iter;          /* as the reference stores it (loop index + 1, :584)                   */
-    int64_t iters_done;    /* loop iterations executed so far                                      */
+    int64_t iters_done;    /* loop iterations completed so far (= rows written to hist)            */
     int64_t n_matvec;
     double relres;
     double norm_b;         /* sqrt(sum Fext^2 w)                                                   */

@@ -19,6 +19,9 @@ CASES = {
     "n9_stagnate":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-15, max_iter=1500, ud=0.0),      # Flag 3 via :560-562
     "n9_raise":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-15, max_iter=10000, ud=0.0),     # MaxMSteps<0 -> raise Warning (:549)
     "n9_p2_raise":  dict(N=9,  grid=(1, 1, 2), n_types=1, tol=1e-15, max_iter=10000, ud=0.0),
+    "n9_flag4":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, negate_ck=True),       # pq <= 0 (:492)
+    "n9_p2_flag4":  dict(N=9,  grid=(1, 1, 2), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, negate_ck=True),
+    "n9_flag2":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, isolated_node=True),   # inf in M^-1 r (:448)
     "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
     "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
 }
@@ -38,6 +41,23 @@ def build_case(name, golden_dir=None):
             zf = fixed[fixed % 3 == 2]
             ud[zf] = c["ud"] * (1.0 + 0.25 * np.sin(p["DofVector"][zf].astype(float)))
             p["Ud"] = ud
+        if c.get("negate_ck"):                       # negative-definite operator -> p.Ap <= 0 -> Flag 4
+            for g in p["SubDomainData"]["StrucDataList"]:
+                g["ElemList_Ck"] = -g["ElemList_Ck"]
+        if c.get("isolated_node"):                   # a loaded free node that no element touches: diag 0 -> 1/0 = inf -> Flag 2
+            n0 = p["NDOF"]
+            p["NDOF"] = n0 + 3
+            p["NNode"] += 1
+            for key in ("RefLoadVector", "Ud", "Vd", "Un", "DofWeightVector"):
+                p[key] = np.concatenate([p[key], np.array([0.0, 0.0, -1.0]) if key == "RefLoadVector" else
+                                         (np.ones(3) if key == "DofWeightVector" else np.zeros(3))])
+            p["DofVector"] = np.concatenate([p["DofVector"], p["DofVector"][-1] + 1 + np.arange(3)])
+            p["NodeIdVector"] = np.concatenate([p["NodeIdVector"], [p["NodeIdVector"][-1] + 1]])
+            p["NodeCoordVec"] = np.concatenate([p["NodeCoordVec"], [0.0, 0.0, float(c["N"])]])
+            p["LocDofEff"] = np.concatenate([p["LocDofEff"], n0 + np.arange(3)])
+            p["DofWeightVector_Eff"] = p["DofWeightVector"][p["LocDofEff"]]
+            p["GlobData"]["GlobNDof"] += 3
+            p["GlobData"]["GlobNDofEff"] += 3
         if c.get("zero_rhs"):
             p["RefLoadVector"] = np.zeros(p["NDOF"])
         if c.get("good_x0"):
@@ -50,3 +70,9 @@ def build_case(name, golden_dir=None):
 def probe_vector(brick, seed=7):
     """Seeded global vector used for the mat-vec probe of every case."""
     return np.random.default_rng(seed).standard_normal(brick.n_dof)
+
+
+def probe_for(brick, parts, seed=7):
+    """Probe vector covering every global dof id of the parts (the isolated-node case has 3 extra dofs)."""
+    ng = max(brick.n_dof, max(int(p["DofVector"].max()) + 1 for p in parts))
+    return np.concatenate([probe_vector(brick, seed), np.ones(ng - brick.n_dof)])

@@ -34,7 +34,7 @@ import ref_shim  # noqa: E402
 def glob_vec(brick, parts, key):
     """Scatter a per-part local vector to a global one (duplicates agree up to rounding; the
     lowest part id that OWNS the dof wins, i.e. weight 1)."""
-    out = np.zeros(brick.n_dof)
+    out = np.zeros(max(brick.n_dof, max(int(p["DofVector"].max()) + 1 for p in parts)))
     for p in reversed(parts):
         out[p["DofVector"]] = p[key]
     return out
@@ -47,7 +47,8 @@ def run_case(name, outdir):
     n = len(parts_ref)
 
     # --- mat-vec probe -------------------------------------------------------------------------
-    xg = golden_cases.probe_vector(brick)
+    ng = max(brick.n_dof, max(int(p["DofVector"].max()) + 1 for p in parts_ref))
+    xg = np.concatenate([golden_cases.probe_vector(brick), np.ones(ng - brick.n_dof)])
     xs = [xg[p["DofVector"]] for p in parts_ref]
     y_ref = ref_shim.ref_matvec(parts_ref, [x.copy() for x in xs])
     y_orc = pcg_oracle.calc_matvec(parts_orc, [x.copy() for x in xs])
@@ -71,7 +72,7 @@ def run_case(name, outdir):
         out_orc = None
     assert raised_ref == raised_orc, (name, raised_ref, raised_orc)
 
-    fx = {"case": name, "y_probe": np.zeros(brick.n_dof), "diag": np.zeros(brick.n_dof)}
+    fx = {"case": name, "y_probe": np.zeros(ng), "diag": np.zeros(ng)}
     for p, y, d in zip(reversed(parts_ref), reversed(y_ref), reversed(d_ref)):
         fx["y_probe"][p["DofVector"]] = y
         fx["diag"][p["DofVector"]] = d
@@ -89,7 +90,7 @@ def run_case(name, outdir):
             fx["early"] = np.array(1)
             fx["early_flag"] = np.array(early[1]); fx["early_relres"] = np.array(float(early[2]))
             fx["early_iter"] = np.array(early[3])
-            xe = np.zeros(brick.n_dof)
+            xe = np.zeros(ng)
             for p, e in zip(reversed(parts_ref), reversed(out_ref["early"])):
                 xe[p["DofVector"]] = e[0]
             fx["early_x"] = xe

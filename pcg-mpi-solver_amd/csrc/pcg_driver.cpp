@@ -268,7 +268,7 @@ void fill_result(pcg_engine *e, pcg_result *res)
     res->flag = s.flag;
     res->status = s.status;
     res->iter = s.iter;
-    res->iters_done = s.last_i + 1;
+    res->iters_done = s.i;                 // iterations that reached the norms all-reduce (:507) = history rows
     res->n_matvec = s.n_matvec;
     res->relres = s.relres;
     res->norm_b = s.n2b;

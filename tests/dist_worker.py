@@ -43,7 +43,7 @@ def main():
     comm = TorchComm(device=device)
     pm.configure(comm=comm, device=int(os.environ.get("LOCAL_RANK", 0)), operator=opkind)
     out = {"rank": rank}
-    x = golden_cases.probe_vector(brick)[P["DofVector"]]
+    x = golden_cases.probe_for(brick, parts)[P["DofVector"]]
     out["y_probe"] = pm.calc_mpfint(x, P)
     out["diag"] = pm.calc_matvec_prod(P, "Preconditioner")
     pm.update_bc(P)

@@ -17,7 +17,7 @@ def test_single_part_solve_matches_reference(hostops, name):
     g = golden(name)
     P = parts[0]
     pm.configure(comm=None)
-    x = golden_cases.probe_vector(brick)
+    x = golden_cases.probe_for(brick, parts)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
     assert relerr(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"]) < 1e-14
     pm.update_bc(P)

@@ -29,7 +29,7 @@ def test_ebe_solve_matches_reference(hostops, name):
     op = pm.get_operator(P)
     info = op.operator_info()
     assert info["kind"] == "ebe" and info["n_elem"] == brick.n_elem and info["n_chunks"] >= -(-brick.n_elem // 512)
-    x = golden_cases.probe_vector(brick)
+    x = golden_cases.probe_for(brick, parts)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
     assert np.array_equal(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"])      # same order as np.bincount (:300)
     pm.update_bc(P); pm.update_preconditioner(P)

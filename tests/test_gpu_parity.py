@@ -104,7 +104,7 @@ def test_solve_matches_reference_fixture(gpu_lib, name):
     g = golden(name)
     P = parts[0]
     pm.configure(comm=None, device=0)
-    x = golden_cases.probe_vector(brick)
+    x = golden_cases.probe_for(brick, parts)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-13
     assert relerr(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"]) < 1e-14
     pm.update_bc(P)
@@ -270,7 +270,7 @@ def test_ebe_solve_matches_reference_fixture(gpu_lib, ebe_cfg, name):
     brick, parts = golden_cases.build_case(name)
     g = golden(name)
     P = parts[0]
-    x = golden_cases.probe_vector(brick)
+    x = golden_cases.probe_for(brick, parts)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-13
     pm.update_bc(P); pm.update_preconditioner(P)
     assert relerr(P["Fext"], g["Fext"]) < 1e-13

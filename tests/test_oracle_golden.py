@@ -17,7 +17,7 @@ CASES = list(golden_cases.CASES)
 def test_oracle_matches_reference_fixture(name):
     brick, parts = golden_cases.build_case(name)
     g = golden(name)
-    xg = golden_cases.probe_vector(brick)
+    xg = golden_cases.probe_for(brick, parts)
     ys = pcg_oracle.calc_matvec(parts, [xg[p["DofVector"]] for p in parts])
     assert relerr(to_global(brick, parts, ys), g["y_probe"]) < 1e-13
     ds = pcg_oracle.calc_matvec(parts, None, "Preconditioner")
@@ -40,12 +40,14 @@ def test_oracle_matches_reference_fixture(name):
     assert out["iter"] == int(g["iter"])
     assert relerr(to_global(brick, parts, "Un"), g["Un"]) < 1e-9
     m = min(100, len(g["history"]))
-    assert np.abs(out["history"][:m, 2] / g["history"][:m, 2] - 1).max() < 1e-10
+    assert len(out["history"]) == len(g["history"])
+    if m:
+        assert np.abs(out["history"][:m, 2] / g["history"][:m, 2] - 1).max() < 1e-10
 
 
 def test_oracle_c_kernel_matches_numpy(oracle_c):
     brick, parts = golden_cases.build_case("n13_t3_p4_ud")
-    xg = golden_cases.probe_vector(brick)
+    xg = golden_cases.probe_for(brick, parts)
     for p in parts:
         x = xg[p["DofVector"]]
         a = pcg_oracle.matvec_local(p, x)

@@ -18,7 +18,7 @@ def relerr(a, b):
 
 
 def to_global(brick, parts, key_or_list):
-    out = np.zeros(brick.n_dof)
+    out = np.zeros(max(brick.n_dof, max(int(p["DofVector"].max()) + 1 for p in parts)))
     for k in range(len(parts) - 1, -1, -1):
         v = parts[k][key_or_list] if isinstance(key_or_list, str) else key_or_list[k]
         out[parts[k]["DofVector"]] = v
