@@ -244,11 +244,12 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
 //   4. tile nodes owned by this chunk alone are stored straight to y; nodes shared with other chunks go
 //      to this chunk's slots of the boundary buffer, summed afterwards by k_ebe_shared in chunk order.
 // All chunks of a phase are ONE launch (no colour-by-colour launches, no read-modify-write of y).
-template <int EPT>
+template <int EPT, bool DOT>
 __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk24(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
     const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf)
+    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
+    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
 {
     constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
     constexpr int kChunkElems = kChunkThreads * EPT;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
             l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + j * kChunkThreads + threadIdx.x);
     }
     int dst[NPT];
+    double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int n = threadIdx.x + j * kChunkThreads;
@@ -327,24 +329,55 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
         if (n < h.y) {
             double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
             out[0] = ys[3 * n]; out[1] = ys[3 * n + 1]; out[2] = ys[3 * n + 2];
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                const uint8_t *fp = flags + dst[j];
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if ((fp[d] & 3) == 3) dot += xs[3 * n + d] * ys[3 * n + d];
+            }
         }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
     }
 }
 
 // nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id
+template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
                                                        const int *__restrict__ sh_slot, const double *__restrict__ buf,
-                                                       double *__restrict__ y, int count)
+                                                       double *__restrict__ y, int count, const double *__restrict__ x,
+                                                       const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                       long long dot_lo)
 {
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= count) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int q = sh_ptr[k]; q < sh_ptr[k + 1]; ++q) {
-        const double *b = buf + 3 * (size_t)sh_slot[q];
-        s0 += b[0]; s1 += b[1]; s2 += b[2];
+    double dot = 0.0;
+    if (k < count) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int q = sh_ptr[k]; q < sh_ptr[k + 1]; ++q) {
+            const double *b = buf + 3 * (size_t)sh_slot[q];
+            s0 += b[0]; s1 += b[1]; s2 += b[2];
+        }
+        const size_t d0 = 3 * (size_t)sh_node[k];
+        double *yp = y + d0;
+        yp[0] = s0; yp[1] = s1; yp[2] = s2;
+        if (DOT && (long long)d0 >= dot_lo) {
+            const uint8_t *fp = flags + d0;
+            const double *xp = x + d0;
+            if ((fp[0] & 3) == 3) dot += xp[0] * s0;
+            if ((fp[1] & 3) == 3) dot += xp[1] * s1;
+            if ((fp[2] & 3) == 3) dot += xp[2] * s2;
+        }
     }
-    double *yp = y + 3 * (size_t)sh_node[k];
-    yp[0] = s0; yp[1] = s1; yp[2] = s2;
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
 }
 
 // any nd (hanging-node patterns): same algorithm, x re-gathered per block of 4 output rows
@@ -583,6 +616,8 @@ class HipBackend : public Backend {
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr}, *d_sh_slot_[2] = {nullptr, nullptr};
     int *d_ch_dst_ = nullptr;
     double *d_ch_buf_ = nullptr;
+    double *d_part_ebe_ = nullptr;    // fused-dot partials of the chunk / shared launches of one apply
+    int cnt_ebe_ = 0;
     bool ch_needs_zero_ = true;
     int4 *d_ch_hdr_ = nullptr;
     int ch_ept_ = 1;
@@ -657,7 +692,7 @@ public:
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)d_ch_list_[0], (void *)d_ch_list_[1], (void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_lid_,
-                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_sh_node_[0],
+                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
                         (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1], (void *)d_sh_slot_[0], (void *)d_sh_slot_[1]})
             if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
@@ -748,6 +783,11 @@ public:
             up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst); up(d_ch_lid_, C.lid); up(d_ch_ck_, C.ck); up(d_ch_sgn_, C.sgn);
             up(d_ch_ke_, C.ke_col);
             d_ch_buf_ = (double *)alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(1, C.n_slots));
+            {
+                size_t np = 8;
+                for (int ph = 0; ph < 2; ++ph) np += C.list[ph].size() + (C.sh_node[ph].size() + kBlock - 1) / kBlock;
+                d_part_ebe_ = (double *)alloc(sizeof(double) * np);
+            }
             ch_needs_zero_ = C.needs_zero;
             for (int ph = 0; ph < 2; ++ph) {
                 ch_count_[ph] = (int)C.list[ph].size();
@@ -767,28 +807,47 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
-    void ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first) override
+    template <int EPT>
+    void launch_chunks(int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_chunk24<EPT, true>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        else
+            hipLaunchKernelGGL((k_ebe_chunk24<EPT, false>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+    }
+    bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
+    {
+        // the fused dot needs every dof to be finalised by the chunk / shared kernels
+        const bool fuse = with_dot && ebe_ranges_[0].empty() && ebe_ranges_[1].empty() && (ch_count_[0] + ch_count_[1]) > 0;
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         if (zero_first && ch_needs_zero_) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
             if (ch_count_[ph]) {
-                if (ch_ept_ == 1)
-                    hipLaunchKernelGGL((k_ebe_chunk24<1>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
-                                       d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_);
-                else
-                    hipLaunchKernelGGL((k_ebe_chunk24<2>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
-                                       d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_);
+                double *part = d_part_ebe_ + cnt_ebe_;
+                if (ch_ept_ == 1) launch_chunks<1>(ph, x, y, fuse, part, dot_lo);
+                else launch_chunks<2>(ph, x, y, fuse, part, dot_lo);
+                if (fuse) cnt_ebe_ += ch_count_[ph];
             }
-            if (sh_count_[ph])
-                hipLaunchKernelGGL(k_ebe_shared, dim3((sh_count_[ph] + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, d_sh_node_[ph],
-                                   d_sh_ptr_[ph], d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph]);
+            if (sh_count_[ph]) {
+                const int grid = (sh_count_[ph] + kBlock - 1) / kBlock;
+                double *part = d_part_ebe_ + cnt_ebe_;
+                if (fuse)
+                    hipLaunchKernelGGL((k_ebe_shared<true>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
+                                       d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
+                else
+                    hipLaunchKernelGGL((k_ebe_shared<false>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
+                                       d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
+                if (fuse) cnt_ebe_ += grid;
+            }
         }
         for (int ph = plo; ph < phi; ++ph)                      // other pattern types: one launch per element colour
             for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (phi == 2) ++ev_applies_; }
+        return fuse;
     }
     void upload_masks(const uint8_t *f, int64_t n) override { h2d(d_flags_, f, (size_t)n); }
     void upload_halo(const HaloHost &h) override
@@ -850,11 +909,14 @@ public:
         HIP_CHECK(hipGetLastError());
         if (with_dot) cnt_fix_ = grid;
     }
-    void begin_dot() override { cnt_spmv_ = cnt_fix_ = 0; }
+    void begin_dot() override { cnt_spmv_ = cnt_fix_ = cnt_ebe_ = 0; }
     void reduce_dot(double *red) override
     {
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                           cnt_fix_, red);
+        if (ebe_)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, red);
+        else
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
+                               cnt_fix_, red);
         HIP_CHECK(hipGetLastError());
     }
     void scalar_alpha(double *st, double rho) override
@@ -941,12 +1003,13 @@ public:
     int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
     {
         if (ebe_) {
-            for (int k = 0; k < warmup; ++k) ebe_apply(x, y, 0, 2, true);
+            for (int k = 0; k < warmup; ++k) { cnt_ebe_ = 0; ebe_apply(x, y, 0, 2, true, bench_dot_, 0); }
             hipEvent_t a, b;
             HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
             for (int k = 0; k < reps; ++k) {
                 HIP_CHECK(hipEventRecord(a, st_));
-                ebe_apply(x, y, 0, 2, true);
+                cnt_ebe_ = 0;
+                ebe_apply(x, y, 0, 2, true, bench_dot_, 0);
                 HIP_CHECK(hipEventRecord(b, st_));
                 HIP_CHECK(hipEventSynchronize(b));
                 HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));

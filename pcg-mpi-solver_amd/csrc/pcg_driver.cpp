@@ -121,17 +121,20 @@ struct pcg_engine {
     void apply(const double *x, double *y, bool with_dot)
     {
         if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
+            if (with_dot) be->begin_dot();
+            bool fused;
             if (!has_halo) {
-                be->ebe_apply(x, y, 0, 2, true);
+                fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0);
             } else {
-                be->ebe_apply(x, y, 0, 1, true);
+                fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs);
                 be->halo_pack(y, d_send);
                 halo_begin();
-                be->ebe_apply(x, y, 1, 2, false);
+                be->ebe_apply(x, y, 1, 2, false, with_dot, n_bnd_dofs);
                 halo_end();
-                be->boundary_fixup(y, d_recv, nullptr, false);
+                be->boundary_fixup(y, d_recv, x, with_dot && fused);   // interface dofs: + neighbours, their dot
             }
-            if (with_dot) be->dot_w(x, y);                    // :487 (y is complete only after the last colour)
+            ebe_dot_fused = with_dot && fused;
+            if (with_dot && !fused) be->dot_w(x, y);          // :487 (pattern types without the fused epilogue)
             return;
         }
         if (with_dot) be->begin_dot();
@@ -154,9 +157,10 @@ struct pcg_engine {
         halo_end();
         be->boundary_fixup(y, d_recv, nullptr, false);
     }
+    bool ebe_dot_fused = false;
     void reduce_apply_dot(double *out)
     {
-        if (kind == 1) be->reduce_dotw(out);
+        if (kind == 1 && !ebe_dot_fused) be->reduce_dotw(out);
         else be->reduce_dot(out);
     }
     void read_status() { be->d2h(h_st, d_st, sizeof(double) * ST_COUNT); }
@@ -710,8 +714,9 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
         double *dx = e->scratch(0), *dy = e->scratch(1);
         e->be->h2d(dx, x, bytes);
         if (e->kind == 1) {
-            e->be->ebe_apply(dx, dy, 0, 2, true);
-            if (pxy) e->be->dot_w(dx, dy);
+            if (pxy) e->be->begin_dot();
+            e->ebe_dot_fused = e->be->ebe_apply(dx, dy, 0, 2, true, pxy != nullptr, 0) && pxy;
+            if (pxy && !e->ebe_dot_fused) e->be->dot_w(dx, dy);
         } else {
             if (pxy) e->be->begin_dot();
             e->be->spmv(dx, dy, 0, e->n_slices, pxy != nullptr);

@@ -127,7 +127,11 @@ public:
     virtual void upload_matrix(const SellHost &m) = 0;
     virtual void upload_ebe(const EbeHost &m) = 0;
     // y (+)= sum over the elements of phases [phase_lo, phase_hi) ; zero_first clears y before
-    virtual void ebe_apply(const double *x, double *y, int phase_lo, int phase_hi, bool zero_first) = 0;
+    // with_dot: also accumulate partials of sum x[d]*y[d]*own_free(d) over the dofs d >= dot_lo that become
+    // final in these phases (interface dofs < dot_lo get theirs from boundary_fixup); returns false when the
+    // operator cannot fuse the dot (then the caller runs dot_w).  reduce with reduce_dot().
+    virtual bool ebe_apply(const double *x, double *y, int phase_lo, int phase_hi, bool zero_first, bool with_dot,
+                           int64_t dot_lo) = 0;
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;
 

@@ -43,8 +43,9 @@ public:
         ebe_ = m; n_ = 3 * m.n_nodes;
         m_ = SellHost(); m_.n_nodes = m.n_nodes; m_.diag = m.diag;
     }
-    void ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first) override
+    bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
+        const bool fuse = with_dot && ebe_.ranges[0].empty() && ebe_.ranges[1].empty() && ebe_.chunked.n_chunks > 0;
         const auto &C = ebe_.chunked;
         if (zero_first && (C.n_chunks == 0 || C.needs_zero)) std::memset(y, 0, sizeof(double) * n_);
         std::vector<double> u;
@@ -82,14 +83,19 @@ public:
                 for (int n = 0; n < nn; ++n) {
                     const int32_t dst = C.dst[off + n];
                     double *out = dst >= 0 ? y + dst : &ebuf_[(size_t)(-dst - 1) * 3];
-                    for (int d = 0; d < 3; ++d) out[d] = ys[3 * n + d];
+                    for (int d = 0; d < 3; ++d) {
+                        out[d] = ys[3 * n + d];
+                        if (fuse && dst >= 0 && dst + d >= dot_lo && own_free(dst + d)) dot_spmv_ += xs[3 * n + d] * ys[3 * n + d];
+                    }
                 }
             }
             for (size_t k = 0; k < C.sh_node[ph].size(); ++k)          // shared nodes: slots in chunk order
                 for (int d = 0; d < 3; ++d) {
                     double sum = 0.0;
                     for (int32_t q = C.sh_ptr[ph][k]; q < C.sh_ptr[ph][k + 1]; ++q) sum += ebuf_[(size_t)C.sh_slot[ph][q] * 3 + d];
-                    y[3 * (int64_t)C.sh_node[ph][k] + d] = sum;
+                    const int64_t dd = 3 * (int64_t)C.sh_node[ph][k] + d;
+                    y[dd] = sum;
+                    if (fuse && dd >= dot_lo && own_free(dd)) dot_spmv_ += x[dd] * sum;
                 }
         }
         for (int ph = plo; ph < phi; ++ph)
@@ -110,6 +116,7 @@ public:
                     }
                 }
             }
+        return fuse;
     }
     void upload_masks(const uint8_t *f, int64_t n) override { flags_.assign(f, f + n); }
     void upload_halo(const HaloHost &h) override { h_ = h; }
@@ -151,7 +158,8 @@ public:
         }
         if (with_dot) {
             double acc = 0;
-            const int64_t nb = std::min<int64_t>(n_, (int64_t)m_.n_bnd_slices * m_.C * 3);
+            const int64_t nb = !ebe_.groups.empty() ? (h_.fix_dof.empty() ? 0 : (int64_t)h_.fix_dof.back() + 1)
+                                                     : std::min<int64_t>(n_, (int64_t)m_.n_bnd_slices * m_.C * 3);
             for (int64_t d = 0; d < nb; ++d)
                 if (own_free(d)) acc += xdot[d] * y[d];
             dot_fix_ = acc;
@@ -226,7 +234,7 @@ public:
     void collect_profile(double *ms, int64_t *c) override { *ms = 0; *c = 0; }
     int bench_spmv(const double *x, double *y, int, int reps, float *ms) override
     {
-        if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true);
+        if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true, false, 0);
         else spmv(x, y, 0, m_.n_slices, false);
         for (int k = 0; k < reps; ++k) ms[k] = 0.f;
         return 0;
