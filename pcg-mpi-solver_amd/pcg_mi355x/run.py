@@ -1,0 +1,132 @@
+"""Load-step driver: the solver stage of the reference pipeline on the MI355X engine.
+
+Restates the `__main__` block of src/solver/pcg_solver.py (:965-1031): read this rank's part of the
+partition (:980), read the solver settings (:981, GlobSettings.zpkl written as in
+examples/run_basic_script.bash:30-49), then for every load step updateBC -> updatePreconditioner ->
+PCG -> export (:1002-1008), and store Flag / RelRes / Iter and the calc/comm time split (:1020).
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pcg_mi355x.run ...`)
+replaces `mpiexec -np N python3 src/solver/pcg_solver.py <Run> <SpeedTestFlag>`.
+
+    python -m pcg_mi355x.run --partition-prefix <PyDataPath_Part> --n-parts N \\
+           --settings __pycache__/GlobSettings.zpkl --results <ScratchPath>/Results_Run1 [--operator ebe]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import solver
+from .io import importz, read_partition, ResultExporter
+
+__all__ = ["init_glob_data", "apply_settings", "run_load_steps", "main"]
+
+
+def init_glob_data():
+    """The timer / bookkeeping entries initGlobData creates (pcg_solver.py:45-52)."""
+    return {"MP_TimeRecData": {"dT_FileRead": 0.0, "dT_Calc": 0.0, "dT_CommWait": 0.0, "dT_CalcList": [],
+                               "dT_CommWaitList": [], "TimeStepCountList": [], "t0": time.time()}}
+
+
+def apply_settings(glob_data, settings, speed_test=False):
+    """readGlobalSettings (pcg_solver.py:113-139)."""
+    th, sp = settings["TimeHistoryParam"], settings["SolverParam"]
+    glob_data["FintCalcMode"] = "outbin"
+    glob_data["ExportVars"] = th["ExportVars"]
+    glob_data["PlotFlag"] = th["PlotFlag"]
+    glob_data["ExportFlag"] = th["ExportFlag"]
+    glob_data["ExportKeyFrm"] = th["ExportFrmRate"]
+    glob_data["ExportFrms"] = th["ExportFrms"]
+    glob_data["TimeStepDelta"] = th["TimeStepDelta"]
+    glob_data["RefMaxTimeStepCount"] = len(th["TimeStepDelta"])
+    glob_data["MaxIter"] = sp["MaxIter"]
+    glob_data["Tol"] = sp["Tol"]
+    if speed_test:                                                     # :138-139
+        glob_data["PlotFlag"] = 0
+        glob_data["ExportFlag"] = 0
+
+
+def run_load_steps(part, res_vec_path=None, comm=None):
+    """pcg_solver.py:996-1008 for one part.  Returns rank-0 style lists (Flag, RelRes, Iter per step)."""
+    gd = part["GlobData"]
+    n_steps = int(gd.get("RefMaxTimeStepCount", len(gd["TimeStepDelta"])))
+    part["Un"] = np.zeros(part["NDOF"])                               # :996 (1e-200*rand there: numerically zero)
+    part["DofWeightVector_Eff"] = np.asarray(part["DofWeightVector"])[np.asarray(part["LocDofEff"], np.int64)]   # :997
+    gd["TimeList_Flag"] = np.zeros(n_steps)                           # initExportData :162-165
+    gd["TimeList_RelRes"] = np.zeros(n_steps)
+    gd["TimeList_Iter"] = np.zeros(n_steps)
+    dt = gd.get("dt", 1.0)
+    time_list = [i * dt for i in range(n_steps)]                      # :167-168
+    gd["TimeStepCount"] = 0
+    exporter = None
+    key_frm = int(gd.get("ExportKeyFrm", 0) or 0)
+    frames = np.array(gd.get("ExportFrms", []), dtype=int)
+    frames = frames[0] - 1 if len(frames) > 0 else frames             # :155-157
+    if gd.get("ExportFlag") and res_vec_path and "U" in str(gd.get("ExportVars", "U")):
+        exporter = ResultExporter(part, res_vec_path, comm)
+        exporter.export(time_list[0])                                  # initial frame (:209)
+    for step in range(1, n_steps):                                     # :1002
+        gd["TimeStepCount"] = step                                     # updateTimeStep :213-216
+        solver.update_bc(part)                                         # :1004
+        solver.update_preconditioner(part)                             # :1005
+        solver.solve(part)                                             # :1006
+        if exporter is not None:                                       # exportContourData :853-858
+            now = (key_frm > 0 and step % key_frm == 0) or (step in np.atleast_1d(frames))
+            if now:
+                exporter.export(time_list[step])
+    return gd["TimeList_Flag"], gd["TimeList_RelRes"], gd["TimeList_Iter"]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--partition-prefix", required=True, help="PyDataPath_Part: files <prefix><N>_<id>.mpidat")
+    ap.add_argument("--n-parts", type=int, default=None, help="defaults to WORLD_SIZE")
+    ap.add_argument("--settings", default="__pycache__/GlobSettings.zpkl")
+    ap.add_argument("--results", required=True, help="result directory (Results_Run<R>)")
+    ap.add_argument("--operator", choices=["sell", "ebe"], default="sell")
+    ap.add_argument("--speed-test", action="store_true")
+    args = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_parts = args.n_parts or world
+    if n_parts != world:
+        raise SystemExit("one process (GPU) per mesh part: launch with --nproc-per-node <n_parts> (pcg_solver.py:91)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from .dist import TorchComm
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+    solver.configure(comm=comm, device=local_rank, operator=args.operator)
+
+    gd = init_glob_data()
+    t0 = time.time()
+    part = read_partition(args.partition_prefix, n_parts, rank, gd)   # :980
+    apply_settings(gd, importz(args.settings), args.speed_test)       # :981
+    gd["MP_TimeRecData"]["dT_FileRead"] += time.time() - t0
+    res_vec = os.path.join(args.results, "ResVecData") + os.sep
+    t_start = time.time()
+    flag, relres, it = run_load_steps(part, res_vec, comm)
+    total = time.time() - t_start
+    if rank == 0:
+        os.makedirs(os.path.join(args.results, "PlotData"), exist_ok=True)
+        rec = gd["MP_TimeRecData"]
+        np.savez_compressed(os.path.join(args.results, "PlotData", "TimeData"), Flag=flag, RelRes=relres, Iter=it,
+                            FileReadTime=rec["dT_FileRead"], CalcTime=rec["dT_Calc"], CommWaitTime=rec["dT_CommWait"],
+                            TotalTime=total)
+        print(f">file read time:     {rec['dT_FileRead']:.1f} sec\n>calculation time:   {rec['dT_Calc']:.1f} sec\n"
+              f">communication time: {rec['dT_CommWait']:.1f} sec\n>total runtime:      {total:.1f} sec\n"
+              f">flag {flag[1:]}, iterations {it[1:]}, relres {relres[1:]}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,10 @@ def main():
     out["dofs"] = P["DofVector"]
     out["t_comm"] = gd["MP_TimeRecData"]["dT_CommWait"]
     out["t_calc"] = gd["MP_TimeRecData"]["dT_Calc"]
+    if not out["raised"] and ret is None:      # result export in the reference's layout (exportContourData :866-868)
+        from pcg_mi355x.io import ResultExporter
+        ex = ResultExporter(P, os.path.join(outdir, "ResVecData") + os.sep, comm)
+        ex.export(1.0)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()

