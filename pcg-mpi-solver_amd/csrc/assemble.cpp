@@ -24,8 +24,8 @@ struct Assembler {
         int nd;
         int64_t ne;
         std::vector<int32_t> node;   // (ne, nd) element-major: NEW node index of slot a
-        std::vector<uint8_t> dir;    // (nd)   : direction of slot a is NOT constant in general -> (ne, nd)
-        std::vector<uint8_t> sgn;    // (ne, nd)
+        std::vector<uint8_t> dir;    // (ne, nd) direction (dof % 3) of slot a - not assumed constant per slot
+        std::vector<uint8_t> sgn;    // (ne, nd) sign mask
         const double *ck;
         std::vector<double> ke;      // (nd, nd)
     };
