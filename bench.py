@@ -234,7 +234,10 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": n_spmv,
                      "impl_bytes_per_launch": impl_bytes, "impl_achieved": impl_bytes / (spmv_ms * 1e-3) / 1e9,
                      "impl_frac": impl_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "standalone_spmv": standalone},
+                     "standalone_spmv": standalone,
+                     "note": "achieved/frac use SURVEY 8(d)'s CSR-algorithmic bytes (12*nnz + 20*n); the stored SELL-BSR3 operator moves "
+                             "fewer bytes (impl_*, one i32 column per 3x3 block), so frac can exceed 1; impl_frac and the PMC traffic are "
+                             "the physical HBM utilisation"},
         "solve": final,
         "matrix_free": matrix_free,
     }
