@@ -126,27 +126,43 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
 
     // ================= generic path: element colouring over the non-chunkable groups =================
     {
+        // per node: bit mask of the colours used by its elements, W 64-bit words (grown on demand, so a
+        // hub node of any valence is fine: it just costs as many launches as it has elements)
+        int W = 1;
         std::vector<uint64_t> used((size_t)n_nodes, 0);
-        std::vector<std::vector<uint8_t>> color(n_groups), phase(n_groups);
+        std::vector<std::vector<int32_t>> color(n_groups);
+        std::vector<std::vector<uint8_t>> phase(n_groups);
         for (int g = 0; g < n_groups; ++g)
             if (!chunkable[g]) { color[g].resize((size_t)gs[g].ne); phase[g].resize((size_t)gs[g].ne); }
         int maxc = -1;
         std::vector<int64_t> nodes_of;
+        std::vector<uint64_t> forb;
         for (const auto &r : order) {
             if (chunkable[r.g]) continue;
             const auto &in = gs[r.g];
             nodes_of.resize(in.nd);
-            uint64_t forbidden = 0;
             bool bnd = false;
             for (int a = 0; a < in.nd; ++a) {
                 nodes_of[a] = new_node(in.dof[(int64_t)a * in.ne + r.e]);
-                forbidden |= used[nodes_of[a]];
                 bnd |= nodes_of[a] < n_boundary_nodes;
             }
-            if (~forbidden == 0) throw std::runtime_error("ebe: more than 64 colours needed");
-            const int c = __builtin_ctzll(~forbidden);
-            for (int a = 0; a < in.nd; ++a) used[nodes_of[a]] |= (1ull << c);
-            color[r.g][r.e] = (uint8_t)c;
+            int c = -1;
+            while (c < 0) {
+                forb.assign(W, 0);
+                for (int a = 0; a < in.nd; ++a)
+                    for (int w = 0; w < W; ++w) forb[w] |= used[(size_t)nodes_of[a] * W + w];
+                for (int w = 0; w < W && c < 0; ++w)
+                    if (~forb[w] != 0) c = 64 * w + __builtin_ctzll(~forb[w]);
+                if (c < 0) {                                  // all 64*W colours taken: widen the masks
+                    std::vector<uint64_t> wide((size_t)n_nodes * 2 * W, 0);
+                    for (int64_t i = 0; i < n_nodes; ++i)
+                        for (int w = 0; w < W; ++w) wide[(size_t)i * 2 * W + w] = used[(size_t)i * W + w];
+                    used.swap(wide);
+                    W *= 2;
+                }
+            }
+            for (int a = 0; a < in.nd; ++a) used[(size_t)nodes_of[a] * W + c / 64] |= (1ull << (c % 64));
+            color[r.g][r.e] = c;
             phase[r.g][r.e] = bnd ? 0 : 1;
             maxc = std::max(maxc, c);
         }
@@ -207,24 +223,16 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     std::vector<uint8_t> chunk_phase;
     struct Open { std::vector<int64_t> elems; std::vector<int32_t> nodes; };
     std::vector<int64_t> ln(8);
-    auto close_chunk = [&](int g, Open &o) {
-        if (o.elems.empty()) return;
+    // sub-colour the elements of a candidate chunk (greedy, element order); false if > 63 colours are needed
+    auto sub_colour = [&](int g, const Open &o, std::vector<int> &sc, std::vector<std::array<uint16_t, 8>> &lids, int &nsub,
+                          bool &bnd) {
         const auto &in = gs[g];
-        const int32_t cid = (int32_t)C.n_chunks++;
-        std::sort(o.nodes.begin(), o.nodes.end());
-        o.nodes.erase(std::unique(o.nodes.begin(), o.nodes.end()), o.nodes.end());
-        const int nn = (int)o.nodes.size();
-        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, 0, g24_of[g]});
-        C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
-        // sub-colouring (greedy, element order) on local node masks
-        std::vector<uint32_t> used(nn, 0);
-        const int ne = (int)o.elems.size();
-        std::vector<int> sc(ne);
-        std::vector<std::array<uint16_t, 8>> lids(ne);
-        int nsub = 0;
-        bool bnd = false;
+        const int nn = (int)o.nodes.size(), ne = (int)o.elems.size();
+        std::vector<uint64_t> used(nn, 0);
+        sc.resize(ne); lids.resize(ne);
+        nsub = 0; bnd = false;
         for (int t = 0; t < ne; ++t) {
-            uint32_t forb = 0;
+            uint64_t forb = 0;
             for (int l = 0; l < 8; ++l) {
                 const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + o.elems[t]]);
                 const int li = (int)(std::lower_bound(o.nodes.begin(), o.nodes.end(), (int32_t)node) - o.nodes.begin());
@@ -232,12 +240,23 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 forb |= used[li];
                 bnd |= node < n_boundary_nodes;
             }
-            if (~forb == 0) throw std::runtime_error("ebe: more than 32 sub-colours in a chunk");
-            const int c = __builtin_ctz(~forb);
-            for (int l = 0; l < 8; ++l) used[lids[t][l]] |= (1u << c);
+            forb |= 1ull << 63;                               // keep the code below 255 (= padding marker) and 64 bits
+            if (~forb == 0) return false;
+            const int c = __builtin_ctzll(~forb);
+            for (int l = 0; l < 8; ++l) used[lids[t][l]] |= (1ull << c);
             sc[t] = c;
             nsub = std::max(nsub, c + 1);
         }
+        return true;
+    };
+    auto close_chunk = [&](int g, Open &o, std::vector<int> &sc, std::vector<std::array<uint16_t, 8>> &lids, int nsub, bool bnd) {
+        if (o.elems.empty()) return;
+        const auto &in = gs[g];
+        const int32_t cid = (int32_t)C.n_chunks++;
+        const int nn = (int)o.nodes.size();
+        const int ne = (int)o.elems.size();
+        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, 0, g24_of[g]});
+        C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
         C.hdr[(size_t)cid * 4 + 2] = nsub;
         C.max_subcolors = std::max(C.max_subcolors, nsub);
         chunk_phase.push_back(bnd ? 0 : 1);
@@ -275,18 +294,13 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             const auto &in = gs[g];
             const auto &L = per_group[g];
             Open o;
-            auto count_nodes = [&](size_t lo_, size_t hi_) {
+            std::vector<int> sc;
+            std::vector<std::array<uint16_t, 8>> lids;
+            // build the candidate chunk [lo_, hi_); emit it if it respects every limit (elements, nodes, sub-colours)
+            auto try_emit = [&](size_t lo_, size_t hi_) {
+                if (hi_ - lo_ > (size_t)kChunkElems) return false;
                 const int32_t id = next_stamp++;
-                int cnt = 0;
-                for (size_t k = lo_; k < hi_; ++k)
-                    for (int l = 0; l < 8; ++l) {
-                        const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
-                        if (stamp[node] != id) { stamp[node] = id; ++cnt; }
-                    }
-                return cnt;
-            };
-            auto emit = [&](size_t lo_, size_t hi_) {
-                const int32_t id = next_stamp++;
+                o.elems.clear(); o.nodes.clear();
                 for (size_t k = lo_; k < hi_; ++k) {
                     for (int l = 0; l < 8; ++l) {
                         const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
@@ -294,7 +308,13 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     }
                     o.elems.push_back(L[k].e);
                 }
-                close_chunk(g, o);
+                if ((int)o.nodes.size() > kChunkMaxNodes) return false;
+                std::sort(o.nodes.begin(), o.nodes.end());
+                int nsub = 0;
+                bool bnd = false;
+                if (!sub_colour(g, o, sc, lids, nsub, bnd)) return false;
+                close_chunk(g, o, sc, lids, nsub, bnd);
+                return true;
             };
             // explicit stack: (lo, hi, bit)
             struct Cell { size_t lo, hi; int bit; };
@@ -304,7 +324,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 Cell cdesc = stack.back();
                 stack.pop_back();
                 const size_t n_el = cdesc.hi - cdesc.lo;
-                if (n_el <= (size_t)kChunkElems && count_nodes(cdesc.lo, cdesc.hi) <= kChunkMaxNodes) { emit(cdesc.lo, cdesc.hi); continue; }
+                if (try_emit(cdesc.lo, cdesc.hi)) continue;
                 int bit = cdesc.bit;
                 size_t mid = cdesc.lo;
                 while (bit >= 0) {                          // first Morton bit that actually splits the cell

@@ -310,6 +310,33 @@ def test_ebe_full_size_10m(gpu_lib, ebe_cfg, oracle_c):
     assert abs(np.linalg.norm(r_true) / nb - res.relres) <= 1e-9 * res.relres + 1e-12
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_irregular_meshes_on_gpu(gpu_lib, kind):
+    """Random unstructured connectivity, pattern sizes nd = 12/18/24/27, direction-major slot layouts, a hub
+    node of valence > 64, many sub-colours per chunk: operator and full solve against the oracle."""
+    from test_irregular_meshes import random_part, SPECS
+    from pcg_mi355x.operator import from_refmeshpart
+    for k, (spec, hub) in enumerate(SPECS):
+        P = random_part(97, spec, seed=len(spec) * 7 + hub, hub=hub)
+        P["DofWeightVector_Eff"] = P["DofWeightVector"][P["LocDofEff"]]
+        R = copy.deepcopy(P)
+        op = from_refmeshpart(P, kind=kind)
+        x = np.random.default_rng(3).standard_normal(P["NDOF"])
+        assert relerr(op.apply(x), pcg_oracle.matvec_local(R, x)) < 1e-13, (kind, k)
+        assert relerr(op.diag(), pcg_oracle.matvec_local(R, None, "Preconditioner")) < 1e-13
+        op.close()
+    P = random_part(60, [(8, 150), (4, 80)], seed=11)
+    P["DofWeightVector_Eff"] = P["DofWeightVector"][P["LocDofEff"]]
+    R = copy.deepcopy(P)
+    pm.configure(comm=None, device=0, operator=kind)
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    pm.configure(comm=None, device=0, operator="sell")
+    out = pcg_oracle.solve_step([R])
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0
+    assert abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= 1
+    assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     """The RCCL comm hooks on the GPU (world_size 1 on the 1-GPU box): device-pointer views, the
     engine stream as ExternalStream, all_reduce in place.  Must equal the hook-free run."""
