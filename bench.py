@@ -192,7 +192,13 @@ def main():
     matrix_free = None
     if args.operator in ("both", "ebe"):
         op.close()
-        e = measure("ebe")
+        try:
+            e = measure("ebe")
+        except Exception as ex:              # the headline line must survive a failure of the optional second measurement
+            log(f"matrix-free measurement failed: {ex!r}")
+            e = None
+            matrix_free = {"error": repr(ex)}
+    if args.operator in ("both", "ebe") and e is not None:
         oi = e["op"].operator_info()
         matrix_free = {"note": "SURVEY 8(f)-1: the reference's element-by-element operator kept matrix-free (k_ebe, colour-ordered, "
                                "deterministic); same PCG driver, same inputs", "value": args.steps / e["elapsed"],

@@ -71,8 +71,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* NV * k
 // out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x.
 // One block per value; every thread keeps 4 independent partial sums (loads in flight), then a
 // fixed wave/LDS tree -> deterministic.
+// alpha_mode: out is the status block: st[PQ] = sum, then alpha / stop exactly like k_scalar_alpha (:492-498).
+// mirror (may be null): host-visible copy of the words written, so the host needs no device->host copy.
 __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
-                                                   const double *__restrict__ pb, int count_b, double *out)
+                                                   const double *__restrict__ pb, int count_b, double *out,
+                                                   double *mirror, int alpha_mode, double rho)
 {
     __shared__ double lds[kWavesPerBlock];
     const int k = blockIdx.x;
@@ -87,7 +90,19 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa
         for (int c = threadIdx.x; c < count_b; c += kBlock) s1 += pb[c];
     double v[1] = {(s0 + s1) + (s2 + s3)};
     block_sum<1>(v, lds);
-    if (threadIdx.x == 0) out[k] = v[0];
+    if (threadIdx.x == 0) {
+        if (!alpha_mode) {
+            out[k] = v[0];
+            if (mirror) mirror[k] = v[0];
+        } else {
+            const double pq = v[0];
+            double stop = 0.0, alpha = out[ST_ALPHA];
+            if (pq <= 0.0 || isinf(pq)) stop = 1.0;
+            else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
+            out[ST_RHO] = rho; out[ST_PQ] = pq; out[ST_ALPHA] = alpha; out[ST_STOP] = stop;
+            if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
 // ------------------------------------------------------------------------------------------------
 // vector kernels (grid-stride, 16 B per lane, scalar tail)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_scalar_alpha(double *st, double rho)
+__global__ void k_scalar_alpha(double *st, double rho, double *mirror)
 {
     const double pq = st[ST_PQ];
     st[ST_RHO] = rho;
@@ -455,6 +470,7 @@ __global__ void k_scalar_alpha(double *st, double rho)
     else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }      // :495-498
     st[ST_ALPHA] = alpha;
     st[ST_STOP] = stop;
+    if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ p, const double *__restrict__ r,
@@ -700,6 +716,7 @@ public:
                 if (p) (void)hipFree(p);
         for (auto e : ev0_) (void)hipEventDestroy(e);
         for (auto e : ev1_) (void)hipEventDestroy(e);
+        if (h_mirror_) (void)hipHostFree(h_mirror_);
         if (st_) (void)hipStreamDestroy(st_);
     }
     const char *name() const override { return "hip-gfx950"; }
@@ -913,15 +930,48 @@ public:
     void reduce_dot(double *red) override
     {
         if (ebe_)
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, red);
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, red,
+                               mirror_of(red), 0, 0.0);
         else
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                               cnt_fix_, red);
+                               cnt_fix_, red, mirror_of(red), 0, 0.0);
         HIP_CHECK(hipGetLastError());
+    }
+    void reduce_dot_alpha(double *st, double rho) override
+    {
+        if (ebe_)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, st,
+                               mirror_of(st), 1, rho);
+        else
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
+                               cnt_fix_, st, mirror_of(st), 1, rho);
+        HIP_CHECK(hipGetLastError());
+    }
+    // ---- status block mirror in host-visible (pinned, mapped) memory -------------------------------
+    double *d_st_base_ = nullptr, *h_mirror_ = nullptr, *d_mirror_ = nullptr;
+    double *mirror_of(double *p) const
+    {
+        return (d_mirror_ && p >= d_st_base_ && p < d_st_base_ + ST_COUNT) ? d_mirror_ + (p - d_st_base_) : nullptr;
+    }
+    void set_status_block(double *st) override
+    {
+        d_st_base_ = st;
+        if (!h_mirror_) {
+            HIP_CHECK(hipHostMalloc((void **)&h_mirror_, sizeof(double) * ST_COUNT, hipHostMallocMapped));
+            for (int k = 0; k < ST_COUNT; ++k) h_mirror_[k] = 0.0;
+            HIP_CHECK(hipHostGetDevicePointer((void **)&d_mirror_, h_mirror_, 0));
+        }
+    }
+    bool read_status(double *host_out) override
+    {
+        if (!h_mirror_) return false;
+        HIP_CHECK(hipStreamSynchronize(st_));
+        for (int k = 0; k < ST_COUNT; ++k) host_out[k] = ((volatile double *)h_mirror_)[k];
+        return true;
     }
     void scalar_alpha(double *st, double rho) override
     {
-        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, rho);
+        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, rho, mirror_of(st));
         HIP_CHECK(hipGetLastError());
     }
     void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
@@ -938,7 +988,8 @@ public:
     }
     void reduce_update(double *red5) override
     {
-        hipLaunchKernelGGL(k_reduce, dim3(5), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5);
+        hipLaunchKernelGGL(k_reduce, dim3(5), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5,
+                           mirror_of(red5), 0, 0.0);
         HIP_CHECK(hipGetLastError());
     }
     void residual(const double *b, const double *ax, double *r, const double *minv) override
@@ -949,7 +1000,8 @@ public:
     }
     void reduce_residual(double *red3) override
     {
-        hipLaunchKernelGGL(k_reduce, dim3(3), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3);
+        hipLaunchKernelGGL(k_reduce, dim3(3), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3,
+                           mirror_of(red3), 0, 0.0);
         HIP_CHECK(hipGetLastError());
     }
     void dot_w(const double *a, const double *b) override
@@ -960,7 +1012,8 @@ public:
     }
     void reduce_dotw(double *red1) override
     {
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1,
+                           mirror_of(red1), 0, 0.0);
         HIP_CHECK(hipGetLastError());
     }
     void copy_diag(double *d) override { d2d(d, d_diag_, sizeof(double) * (size_t)n_); }

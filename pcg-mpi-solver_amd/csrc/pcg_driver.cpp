@@ -163,7 +163,11 @@ struct pcg_engine {
         if (kind == 1 && !ebe_dot_fused) be->reduce_dotw(out);
         else be->reduce_dot(out);
     }
-    void read_status() { be->d2h(h_st, d_st, sizeof(double) * ST_COUNT); }
+    void read_status()
+    {
+        // with hooks the all-reduce rewrites the device block after the kernels mirrored it: copy then
+        if (has_hooks || !be->read_status(h_st)) be->d2h(h_st, d_st, sizeof(double) * ST_COUNT);
+    }
 
     // r = b - A x, then [sum r^2 w, rho_next, ninf] -> h_st[SQR..NINF]   (:412-416, :528-533, :569-574)
     void true_residual(const double *x)
@@ -214,9 +218,13 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
     be.update_p(e->v_p, e->v_r, s.minv, beta, i == 0);
     e->apply(e->v_p, e->v_q, true);                            // :482-484
     s.n_matvec++;
-    e->reduce_apply_dot(e->d_st + ST_PQ);                      // :487
-    e->allreduce(e->d_st + ST_PQ, 1);                          // :488
-    be.scalar_alpha(e->d_st, s.rho);                           // :492-498 (device side)
+    if (!e->has_hooks && !(e->kind == 1 && !e->ebe_dot_fused)) {
+        be.reduce_dot_alpha(e->d_st, s.rho);                   // :487-498, one launch (no all-reduce in between)
+    } else {
+        e->reduce_apply_dot(e->d_st + ST_PQ);                  // :487
+        e->allreduce(e->d_st + ST_PQ, 1);                      // :488
+        be.scalar_alpha(e->d_st, s.rho);                       // :492-498 (device side)
+    }
     const int nx = e->pick_new_x();
     be.fused_update(e->d_st, e->v_p, e->v_q, e->v_r, e->v_x[s.cur], e->v_x[nx], s.minv);   // :501-516 (+ :447-462 of i+1)
     be.reduce_update(e->d_st + ST_SQP);
@@ -325,6 +333,7 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->be->upload_matrix(m);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+        e->be->set_status_block(e->d_st);
         e->v_minv = e->vec();
         // default masks: every dof owned and free
         std::vector<uint8_t> f((size_t)e->n, 3);
@@ -357,6 +366,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         e->be->upload_ebe(m);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+        e->be->set_status_block(e->d_st);
         e->v_minv = e->vec();
         std::vector<uint8_t> f((size_t)e->n, 3);
         e->be->upload_masks(f.data(), e->n);

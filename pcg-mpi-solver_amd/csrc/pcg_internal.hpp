@@ -147,6 +147,13 @@ public:
     virtual void reduce_dot(double *red) = 0;
     // st[RHO] = rho ; st[ALPHA] = rho / st[PQ] ; st[STOP] per pcg_solver.py:492-498
     virtual void scalar_alpha(double *st, double rho) = 0;
+    // single part (no all-reduce between the two): reduce_dot(st + ST_PQ) and scalar_alpha(st, rho) in one launch
+    virtual void reduce_dot_alpha(double *st, double rho) = 0;
+    // Status block: `st` is the device block the reduce/scalar kernels write into.  A back end may mirror
+    // those writes into host-visible memory so that read_status() is a stream sync instead of a copy;
+    // it returns false when it has no mirror (the caller then copies).
+    virtual void set_status_block(double *st) = 0;
+    virtual bool read_status(double *host_out) = 0;
     // p = first ? M^-1 r : M^-1 r + beta p                                (:447,:472-479)
     virtual void update_p(double *p, const double *r, const double *minv, double beta, bool first) = 0;
     // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r -= alpha q ; sum r^2 w ; x_new = x_old + alpha p ;

@@ -176,6 +176,9 @@ public:
         st[ST_ALPHA] = rho / pq;
         if (std::isinf(st[ST_ALPHA])) st[ST_STOP] = 1;
     }
+    void reduce_dot_alpha(double *st, double rho) override { reduce_dot(st + ST_PQ); scalar_alpha(st, rho); }
+    void set_status_block(double *) override {}
+    bool read_status(double *) override { return false; }
     void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
     {
         for (int64_t i = 0; i < n_; ++i) {
