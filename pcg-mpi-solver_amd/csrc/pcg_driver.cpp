@@ -12,6 +12,7 @@
 //   * the alpha/flag-4 tests on pq (:492-498) run on the device and freeze the update kernel, the
 //     host sees them in the one status read-back per iteration;
 //   * XMin (:555-558) is tracked by rotating three x buffers instead of copying.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -340,6 +341,42 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->be->upload_masks(f.data(), e->n);
         *out = e.release();
         return 0;
+    });
+}
+
+// Scalar CSR in (the literal "CSR SpMV" input of an already assembled system): rows/cols are grouped into
+// 3x3 node blocks (dof = 3*node + dir), missing entries of a touched block are explicit zeros, then the
+// same SELL-BSR3 path as pcg_create.  Duplicate (row, col) entries are summed in input order.
+int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val,
+                   int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out)
+{
+    return guarded("pcg_create_csr", [&]() -> int {
+        if (!out || !rowptr || !col || !val || n <= 0) return set_error("pcg_create_csr: bad argument");
+        if (n % 3) return set_error("pcg_create_csr: n must be a multiple of 3 (dof = 3*node + dir)");
+        const int64_t nn = n / 3;
+        std::vector<int64_t> brow((size_t)nn + 1, 0);
+        std::vector<int32_t> bcol;
+        std::vector<double> bval;
+        std::vector<int32_t> cand;
+        for (int64_t i = 0; i < nn; ++i) {
+            cand.clear();
+            for (int64_t k = rowptr[3 * i]; k < rowptr[3 * i + 3]; ++k) {
+                if (col[k] < 0 || col[k] >= n) return set_error("pcg_create_csr: column index out of range");
+                cand.push_back(col[k] / 3);
+            }
+            std::sort(cand.begin(), cand.end());
+            cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+            const size_t base = bcol.size();
+            bcol.insert(bcol.end(), cand.begin(), cand.end());
+            bval.resize((base + cand.size()) * 9, 0.0);
+            for (int a = 0; a < 3; ++a)
+                for (int64_t k = rowptr[3 * i + a]; k < rowptr[3 * i + a + 1]; ++k) {
+                    const size_t pos = base + (size_t)(std::lower_bound(cand.begin(), cand.end(), col[k] / 3) - cand.begin());
+                    bval[pos * 9 + a * 3 + col[k] % 3] += val[k];
+                }
+            brow[i + 1] = (int64_t)bcol.size();
+        }
+        return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, rows_per_lane, out);
     });
 }
 

@@ -124,3 +124,25 @@ def test_sell_spmv_and_interface_lists_on_test_double(hostops, rpl, grid):
         w = np.zeros(P["NDOF"]); w[P["LocDofEff"]] = P["DofWeightVector_Eff"]
         assert abs(pxy.value - np.dot(xl, ref * w)) <= 1e-12 * abs(np.dot(np.abs(xl), np.abs(ref)))
         op.close()
+
+
+def test_operator_from_scalar_csr(hostops):
+    """pcg_create_csr: an already assembled scipy CSR matrix in, same engine (SELL-BSR3) behind it."""
+    from pcg_mi355x.operator import assemble_bsr3, Operator
+    b = Brick(6, n_types=2)
+    P = make_parts(b)[0]
+    A = bsr(*assemble_bsr3(P["SubDomainData"]["StrucDataList"], b.n_node), b.n_node)
+    A.eliminate_zeros()                                     # ragged blocks: some 3x3 blocks lose entries
+    op = Operator.from_csr(A.indptr, A.indices, A.data)
+    x = np.random.default_rng(9).standard_normal(b.n_dof)
+    assert relerr(op.apply(x), pcg_oracle.matvec_local(P, x)) < 1e-14
+    assert relerr(op.diag(), A.diagonal()) < 1e-15
+    free = np.zeros(b.n_dof, bool); free[P["LocDofEff"]] = True
+    op.set_masks(np.ones(b.n_dof, bool), free)
+    inv = op.build_jacobi()
+    xs, res, _ = op.solve(P["RefLoadVector"], None, inv, 1e-7, 5000, int(free.sum()))
+    assert res.flag == 0
+    r = (P["RefLoadVector"] - A @ xs)[free]
+    assert np.linalg.norm(r) / np.linalg.norm(P["RefLoadVector"][free]) < 1.01e-7
+    with pytest.raises(Exception):
+        Operator.from_csr(np.array([0, 1, 2]), np.array([0, 1]), np.array([1.0, 1.0]))     # n not a multiple of 3
