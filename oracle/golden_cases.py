@@ -22,6 +22,10 @@ CASES = {
     "n9_flag4":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, negate_ck=True),       # pq <= 0 (:492)
     "n9_p2_flag4":  dict(N=9,  grid=(1, 1, 2), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, negate_ck=True),
     "n9_flag2":     dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, isolated_node=True),   # inf in M^-1 r (:448)
+    # two-level octree mesh with hanging nodes: pattern types hex8 (two sizes) + 13-node transition (nd = 39)
+    "oct_p1":       dict(octree=(8, 8, 4, 3), parts=1, axis=0, sign_seed=3, tol=1e-7, max_iter=10000),
+    "oct_p3":       dict(octree=(8, 6, 3, 2), parts=3, axis=0, sign_seed=5, tol=1e-7, max_iter=10000),
+    "oct_p2_z":     dict(octree=(6, 6, 4, 2), parts=2, axis=2, sign_seed=None, tol=1e-7, max_iter=10000),   # interface = the transition layer
     "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
     "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
 }
@@ -32,6 +36,10 @@ def build_case(name, golden_dir=None):
     import os
     from pcg_mi355x.brick import Brick, make_parts, block_partition
     c = CASES[name]
+    if "octree" in c:
+        from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
+        mesh = TwoLevelMesh(*c["octree"], seed=0)
+        return mesh, make_octree_parts(mesh, c["parts"], c["axis"], c["tol"], c["max_iter"], c["sign_seed"])
     b = Brick(c["N"], seed=0, n_types=c["n_types"])
     parts = make_parts(b, block_partition(b, *c["grid"]), tol=c["tol"], max_iter=c["max_iter"])
     for p in parts:
@@ -68,7 +76,7 @@ def build_case(name, golden_dir=None):
 
 
 def probe_vector(brick, seed=7):
-    """Seeded global vector used for the mat-vec probe of every case."""
+    """Seeded global vector used for the mat-vec probe of every case (brick or octree mesh: .n_dof)."""
     return np.random.default_rng(seed).standard_normal(brick.n_dof)
 
 

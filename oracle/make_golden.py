@@ -117,7 +117,10 @@ def run_case(name, outdir):
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    only = sys.argv[1:]
     for name in golden_cases.CASES:
+        if only and name not in only:
+            continue
         run_case(name, outdir)
 
 

@@ -11,7 +11,7 @@ import pcg_oracle
 import pcg_mi355x as pm
 from util import golden, relerr, check_solution_against_golden, run_dist, make_super_part
 
-SINGLE = ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_zero_rhs"]
+SINGLE = ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_zero_rhs", "oct_p1"]
 
 
 @pytest.fixture(autouse=True)
@@ -28,7 +28,9 @@ def test_ebe_solve_matches_reference(hostops, name):
     pm.configure(comm=None, operator="ebe")
     op = pm.get_operator(P)
     info = op.operator_info()
-    assert info["kind"] == "ebe" and info["n_elem"] == brick.n_elem and info["n_chunks"] >= -(-brick.n_elem // 512)
+    assert info["kind"] == "ebe" and info["n_chunks"] >= 1
+    if hasattr(brick, "n_elem"):
+        assert info["n_elem"] == brick.n_elem and info["n_chunks"] >= -(-brick.n_elem // 512)
     x = golden_cases.probe_for(brick, parts)
     assert relerr(pm.calc_mpfint(x, P), g["y_probe"]) < 1e-14
     assert np.array_equal(pm.calc_matvec_prod(P, "Preconditioner"), g["diag"])      # same order as np.bincount (:300)
@@ -81,7 +83,7 @@ def test_patterns_with_nd_36_and_mixed_groups(hostops, kind, N):
     assert relerr(P["Un"], R["Un"]) < 1e-8
 
 
-@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622)])
+@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622), ("oct_p3", 3, 29623)])
 def test_ebe_multi_rank(tmp_path, case, nproc, port):
     import conftest
     conftest.build_hostops()

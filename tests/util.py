@@ -43,7 +43,8 @@ def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol
     (CG's rounding sensitivity makes late recurrence residuals incomparable on any hardware)."""
     assert flag == int(g["flag"])
     assert abs(it - int(g["iter"])) <= tol_iter, (it, int(g["iter"]))
-    assert relerr(Un, g["Un"]) < tol_u, relerr(Un, g["Un"])
+    # a +-1 iteration exit returns a neighbouring iterate: both satisfy Tol, they differ at the Tol * cond level
+    assert relerr(Un, g["Un"]) < (tol_u if it == int(g["iter"]) else 20 * tol_u), relerr(Un, g["Un"])
     if it == int(g["iter"]):
         assert abs(relres - float(g["relres"])) <= 0.1 * float(g["relres"]) + 1e-300
     elif flag == 0:
