@@ -339,10 +339,10 @@ def test_irregular_meshes_on_gpu(gpu_lib, kind):
 
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 def test_octree_mesh_with_hanging_nodes(gpu_lib, oracle_c, kind):
-    """Two-level 2:1 graded mesh, 131 072 fine + 12 288 coarse hex8 cells + 1 024 transition cells with 5 hanging
-    nodes each (nd = 39), sign-framed patterns: operator and solve against the oracle (~455 k dof)."""
+    """Two-level 2:1 graded mesh: 55 296 fine + 2 880 coarse hex8 cells + 576 transition cells with 5 hanging
+    nodes each (nd = 39), sign-framed patterns: operator and solve against the oracle (~190 k dof)."""
     from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
-    mesh = TwoLevelMesh(64, 64, 32, 8)
+    mesh = TwoLevelMesh(48, 48, 24, 6)
     P = make_octree_parts(mesh, 1, sign_seed=3)[0]
     R = copy.deepcopy(P)
     pm.configure(comm=None, device=0, operator=kind)
