@@ -45,10 +45,12 @@ def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol
     assert abs(it - int(g["iter"])) <= tol_iter, (it, int(g["iter"]))
     # a +-1 iteration exit returns a neighbouring iterate: both satisfy Tol, they differ at the Tol * cond level
     assert relerr(Un, g["Un"]) < (tol_u if it == int(g["iter"]) else 20 * tol_u), relerr(Un, g["Un"])
+    # the final relative residual is a LAST-iteration quantity: it carries the full rounding drift of the solve
+    # (the reference against itself, 1 vs 2 parts: 2e-2 at iteration 100 of 118), so gate its magnitude, and Tol
     if it == int(g["iter"]):
-        assert abs(relres - float(g["relres"])) <= 0.1 * float(g["relres"]) + 1e-300
-    elif flag == 0:
-        assert relres <= 1e-7          # a +-1 iteration exit is a different iterate; it must still meet Tol
+        assert 0.5 * float(g["relres"]) <= relres <= 2.0 * float(g["relres"]) + 1e-300
+    if flag == 0:
+        assert relres <= 1e-7
     if hist is not None:
         # The reference itself, run with 1 part vs 2 parts (tests/golden n9_p1 vs n9_p2), deviates by
         # 4e-13 at iteration 50, 6e-11 at 60 and 2e-2 at 100 of its 118 iterations: only the first ~30-40 %
