@@ -17,7 +17,9 @@
  *   Isend/Recv/Waitall interface sums     :318-334        pcg_comm_hooks.halo_begin/halo_end
  *   np.dot(a, b*w)                        :381,415,462..  pcg_dot_w()
  *   element tables -> operator            (partition_mesh.py:443-491,576-581 data contract)
- *                                                          pcg_asm_*()
+ *                                                          pcg_asm_*() + pcg_create()   assembled, SELL over 3x3 blocks
+ *                                                          pcg_create_ebe()             matrix-free, as the reference
+ *                                                          pcg_create_csr()             from a scalar CSR matrix
  *
  * Conventions: every function returns int (0 = OK, <0 = engine error; text via
  * pcg_last_error()).  Solver outcome flags 0-4 keep the reference's meaning and are DATA

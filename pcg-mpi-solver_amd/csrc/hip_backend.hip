@@ -3,11 +3,14 @@
 // Everything here is HBM-bandwidth bound (SpMV arithmetic intensity ~0.2 flop/B), so the design
 // rules are: every wave-level load is lane-contiguous (SELL layout: 8 or 16 B per lane, 512 B /
 // 1 KiB per wave instruction), matrix data is streamed once with non-temporal loads so it does not
-// evict the x vector from L2/MALL, blocks are mapped XCD-aware (block b runs on XCD b%8: each XCD
-// walks one contiguous eighth of the matrix so that the x entries its waves gather stay in that
-// XCD's private L2), reductions are wave64 shuffles -> LDS -> one partial per block -> a fixed
-// tree (no float atomics: bit-reproducible run to run), and the vector part of an iteration is
-// fused into two streaming kernels.  No MFMA: there is no dense contraction on this path.
+// evict the x vector from L2/MALL, slices are dealt round-robin to all waves of the chip (an
+// XCD-partitioned mapping - block b & 7 = XCD owns one contiguous eighth - is kept behind
+// PCG_SPMV_XCD=1; it measured 2.5 % slower: one matrix stream beats eight, x comes from MALL),
+// reductions are wave64 shuffles -> LDS -> one partial per block -> a fixed tree (no float
+// atomics: bit-reproducible run to run), and the vector part of an iteration is fused into two
+// streaming kernels.  No MFMA: MI355X's f64 matrix rate equals its vector rate and the assembled
+// path is HBM-bound; the matrix-free operator (k_ebe_*) runs its 24x24 contraction on the vector
+// FMA pipe with the element matrix as SGPR operands.
 //
 // Reference semantics implemented (src/solver/pcg_solver.py): k_spmv = calcMatVecProd :265-300 on
 // the assembled operator (+ fused p.Ap.w :487); k_fixup = :332-334; k_update_p = :447,:472-479;
@@ -139,8 +142,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     using DV = typename VecT<RPL>::d;
     using IV = typename VecT<RPL>::i;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // XCD-aware slice assignment: block b runs on XCD b & 7 (observed; speed only, never correctness).
-    // Each XCD owns one contiguous eighth of the slice range and its waves sweep it together.
+    // Slice -> wave mapping.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
+    // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
+    // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
     const int64_t S = slice_hi - slice_lo;
     const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
     const int64_t lb = xcd_aware ? (blockIdx.x >> 3) : blockIdx.x;
