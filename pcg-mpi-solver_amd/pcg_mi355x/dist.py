@@ -79,6 +79,16 @@ class TorchComm:
         if torch.cuda.current_stream().cuda_stream != key:
             torch.cuda.set_stream(ext)
 
+    def release_stream(self, stream_ptr):
+        """Called before an engine (and its HIP stream) is destroyed: never leave torch's current stream
+        pointing at a dead handle, and drop the cached views of that engine's buffers."""
+        key = int(stream_ptr or 0)
+        if self.on_gpu and key in self._streams:
+            if torch.cuda.current_stream().cuda_stream == key:
+                torch.cuda.set_stream(torch.cuda.default_stream())
+            del self._streams[key]
+        self._views.clear()
+
     def reraise(self):
         if self._exc is not None:
             e, self._exc = self._exc, None
