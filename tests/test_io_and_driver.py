@@ -80,3 +80,29 @@ def test_result_vector_multi_rank_layout(tmp_path):
     assert np.array_equal(pio.read_result_vector(str(tmp_path / "U_0")), np.concatenate([a, b]))
     md = np.load(str(tmp_path / "U_0_metadat.npy"), allow_pickle=True).item()
     assert md["NfData"][0] == 12 and md["OffsetData"][0] == 0
+
+
+def test_multiple_load_steps_reuse_previous_solution_as_x0(hostops):
+    """TimeStepDelta with three steps: every PCG call starts from the previous Un (pcg_solver.py:358,378,1002-1008),
+    the operator is assembled once, the preconditioner is rebuilt per step (:1005)."""
+    import copy
+    import pcg_oracle
+    brick, parts = golden_cases.build_case("n13_t3_p4_ud")          # non-zero Dirichlet data, 3 pattern types
+    from pcg_mi355x.brick import Brick, make_parts
+    b = Brick(11, n_types=2)
+    P = make_parts(b)[0]
+    fixed = P["LocFixedDof"]; P["Ud"][fixed[fixed % 3 == 2]] = 0.03
+    P["GlobData"]["TimeStepDelta"] = [0, 0.4, 1.0]
+    P["GlobData"]["RefMaxTimeStepCount"] = 3
+    R = copy.deepcopy(P)
+    pm.configure(comm=None)
+    flag, relres, it = prun.run_load_steps(P)
+    its = []
+    R["GlobData"]["TimeList_Flag"] = np.zeros(3); R["GlobData"]["TimeList_RelRes"] = np.zeros(3); R["GlobData"]["TimeList_Iter"] = np.zeros(3)
+    for step in (1, 2):
+        R["GlobData"]["TimeStepCount"] = step
+        out = pcg_oracle.solve_step([R])
+        its.append(out["iter"])
+    assert list(flag[1:]) == [0, 0] and [int(v) for v in it[1:]] == its
+    assert its[1] < its[0]                                              # the warm start pays off: x0 matters
+    assert relerr(P["Un"], R["Un"]) < 1e-8
