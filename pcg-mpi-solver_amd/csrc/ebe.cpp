@@ -29,10 +29,11 @@ inline uint64_t spread21(uint64_t v)
     return v;
 }
 
-bool node_blocked24(const pcg_elem_group &g)
+// slots 3l, 3l+1, 3l+2 are the x, y, z dofs of one node, at most 32 nodes per element
+bool node_blocked(const pcg_elem_group &g)
 {
-    if (g.nd != 24) return false;
-    for (int l = 0; l < 8; ++l) {
+    if (g.nd % 3 != 0 || g.nd > 96 || g.nd < 3) return false;
+    for (int l = 0; l < g.nd / 3; ++l) {
         const int64_t *d0 = g.dof + (int64_t)(3 * l) * g.ne, *d1 = d0 + g.ne, *d2 = d1 + g.ne;
         for (int64_t e = 0; e < g.ne; ++e)
             if (d0[e] % 3 != 0 || d1[e] != d0[e] + 1 || d2[e] != d0[e] + 2) return false;
@@ -46,9 +47,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                int64_t n_boundary_nodes, const double *coords, bool allow_chunked, int ept, EbeHost &out)
 {
     if (ept != 1 && ept != 2) throw std::runtime_error("ebe: elements per thread must be 1 or 2");
-    const int kChunkElems = kChunkThreads * ept;
     out = EbeHost();
-    out.chunked.ept = ept;
     out.n_nodes = n_nodes;
     out.groups.resize(n_groups);
     out.diag.assign((size_t)n_nodes * 3, 0.0);
@@ -70,7 +69,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         }
         out.n_elem += in.ne;
         out.n_slots += (int64_t)in.nd * in.ne;
-        chunkable[g] = allow_chunked && node_blocked24(in);
+        chunkable[g] = allow_chunked && node_blocked(in);
     }
 
     // ---- one global, spatially coherent element order (Morton code of the first node, or its id) ----
@@ -210,99 +209,120 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
 
     // ================= chunked path ====================================================================
     auto &C = out.chunked;
-    std::vector<int32_t> g24_of(n_groups, -1);
-    int n_g24 = 0;
+    std::vector<int32_t> cls_of(n_groups, -1), ke_index(n_groups, -1);
+    bool any = false;
+    for (int c = 0; c < kChunkClasses; ++c) {
+        auto &K = C.cls[c];
+        K.nnp = 8 * (c + 1);
+        K.ept = c == 0 ? ept : 1;
+        K.words = 3 * K.nnp / 32 + 1;
+    }
     for (int g = 0; g < n_groups; ++g)
         if (chunkable[g]) {
-            g24_of[g] = n_g24++;
-            for (int b = 0; b < 24; ++b)
-                for (int a = 0; a < 24; ++a) C.ke_col.push_back(gs[g].ke[(size_t)a * 24 + b]);
+            const int nn = gs[g].nd / 3, c = (nn + 7) / 8 - 1, nd = gs[g].nd;
+            auto &K = C.cls[c];
+            const int ndp = 3 * K.nnp;
+            cls_of[g] = c;
+            ke_index[g] = (int32_t)(K.ke_col.size() / ((size_t)ndp * ndp));
+            for (int b = 0; b < ndp; ++b)
+                for (int a = 0; a < ndp; ++a) K.ke_col.push_back(a < nd && b < nd ? gs[g].ke[(size_t)a * nd + b] : 0.0);
+            any = true;
         }
-    if (n_g24 == 0) return;
+    if (!any) return;
     std::vector<int32_t> stamp((size_t)n_nodes, -1);
     std::vector<uint8_t> chunk_phase;
     struct Open { std::vector<int64_t> elems; std::vector<int32_t> nodes; };
-    std::vector<int64_t> ln(8);
     // sub-colour the elements of a candidate chunk (greedy, element order); false if > 63 colours are needed
-    auto sub_colour = [&](int g, const Open &o, std::vector<int> &sc, std::vector<std::array<uint16_t, 8>> &lids, int &nsub,
-                          bool &bnd) {
+    auto sub_colour = [&](int g, const Open &o, std::vector<int> &sc, std::vector<uint16_t> &lids, int &nsub, bool &bnd) {
         const auto &in = gs[g];
+        const int nno = in.nd / 3;
         const int nn = (int)o.nodes.size(), ne = (int)o.elems.size();
         std::vector<uint64_t> used(nn, 0);
-        sc.resize(ne); lids.resize(ne);
+        sc.resize(ne); lids.resize((size_t)ne * nno);
         nsub = 0; bnd = false;
         for (int t = 0; t < ne; ++t) {
             uint64_t forb = 0;
-            for (int l = 0; l < 8; ++l) {
+            for (int l = 0; l < nno; ++l) {
                 const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + o.elems[t]]);
                 const int li = (int)(std::lower_bound(o.nodes.begin(), o.nodes.end(), (int32_t)node) - o.nodes.begin());
-                lids[t][l] = (uint16_t)li;
+                lids[(size_t)t * nno + l] = (uint16_t)li;
                 forb |= used[li];
                 bnd |= node < n_boundary_nodes;
             }
             forb |= 1ull << 63;                               // keep the code below 255 (= padding marker) and 64 bits
             if (~forb == 0) return false;
             const int c = __builtin_ctzll(~forb);
-            for (int l = 0; l < 8; ++l) used[lids[t][l]] |= (1ull << c);
+            for (int l = 0; l < nno; ++l) used[lids[(size_t)t * nno + l]] |= (1ull << c);
             sc[t] = c;
             nsub = std::max(nsub, c + 1);
         }
         return true;
     };
-    auto close_chunk = [&](int g, Open &o, std::vector<int> &sc, std::vector<std::array<uint16_t, 8>> &lids, int nsub, bool bnd) {
+    auto close_chunk = [&](int g, Open &o, std::vector<int> &sc, std::vector<uint16_t> &lids, int nsub, bool bnd) {
         if (o.elems.empty()) return;
         const auto &in = gs[g];
+        auto &K = C.cls[cls_of[g]];
+        const int nno = in.nd / 3, CE = kChunkThreads * K.ept, W = K.words;
         const int32_t cid = (int32_t)C.n_chunks++;
+        const int32_t kci = (int32_t)K.n_chunks++;
         const int nn = (int)o.nodes.size();
         const int ne = (int)o.elems.size();
-        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, 0, g24_of[g]});
+        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, ke_index[g], kci, in.nd, cls_of[g], 0});
         C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
-        C.hdr[(size_t)cid * 4 + 2] = nsub;
         C.max_subcolors = std::max(C.max_subcolors, nsub);
         chunk_phase.push_back(bnd ? 0 : 1);
+        K.list[bnd ? 0 : 1].push_back(cid);
         // lanes ordered by sub-colour (stable) so that whole waves share a phase
         std::vector<int> lane_of(ne);
         std::iota(lane_of.begin(), lane_of.end(), 0);
         std::stable_sort(lane_of.begin(), lane_of.end(), [&](int a, int b) { return sc[a] < sc[b]; });
-        const size_t base = (size_t)cid * kChunkElems;
-        C.ck.resize(base + kChunkElems, 0.0);
-        C.sgn.resize(base + kChunkElems, 0xff000000u);
-        C.lid.resize(((size_t)cid + 1) * 8 * kChunkElems, 0);
+        const size_t base = (size_t)kci * CE;
+        K.ck.resize(base + CE, 0.0);
+        K.sgn.resize((size_t)(kci + 1) * W * CE, 0u);
+        K.lid.resize((size_t)(kci + 1) * K.nnp * CE, 0);
+        for (int lane = 0; lane < CE; ++lane)                        // padding slots: sub-colour 255
+            K.sgn[((size_t)kci * W + (W - 1)) * CE + lane] = 0xff000000u;
         for (int lane = 0; lane < ne; ++lane) {
             const int t = lane_of[lane];
             const int64_t e = o.elems[t];
-            C.ck[base + lane] = in.ck[e];
-            uint32_t bits = 0;
-            for (int a = 0; a < 24; ++a)
-                if (in.sign[(int64_t)a * in.ne + e]) bits |= (1u << a);
-            C.sgn[base + lane] = bits | ((uint32_t)sc[t] << 24);
-            for (int l = 0; l < 8; ++l) C.lid[((size_t)cid * 8 + l) * kChunkElems + lane] = lids[t][l];
+            K.ck[base + lane] = in.ck[e];
+            for (int w = 0; w < W; ++w) {
+                uint32_t bits = 0;
+                for (int a = 32 * w; a < std::min(in.nd, 32 * w + 32); ++a)
+                    if (in.sign[(int64_t)a * in.ne + e]) bits |= (1u << (a - 32 * w));
+                if (w == W - 1) bits |= ((uint32_t)sc[t] << 24);
+                K.sgn[((size_t)kci * W + w) * CE + lane] = bits;
+            }
+            for (int l = 0; l < nno; ++l) K.lid[((size_t)kci * K.nnp + l) * CE + lane] = lids[(size_t)t * nno + l];
         }
         o.elems.clear();
         o.nodes.clear();
     };
     // Chunks = octree-like cells: the spatially sorted element list of a group is split recursively at
-    // Morton-bit boundaries until a cell holds <= 256 elements and <= kChunkMaxNodes nodes.  On a uniform
-    // region the cells form a regular lattice of boxes, which the greedy chunk colouring below resolves
-    // with 8 colours.  Without coordinates (keys = node ids) cells are plain runs of <= 256 elements.
+    // Morton-bit boundaries until a cell holds <= 256*ept elements, <= kChunkMaxNodes nodes and <= 63
+    // sub-colours.  On a uniform region the cells form a regular lattice of full boxes.  Without coordinates
+    // (keys = node ids) cells are plain runs of elements.
     {
         int32_t next_stamp = 0;
         std::vector<std::vector<ElemRef>> per_group(n_groups);
         for (const auto &r : order)
             if (chunkable[r.g]) per_group[r.g].push_back(r);
         for (int g = 0; g < n_groups; ++g) {
+            if (!chunkable[g]) continue;
             const auto &in = gs[g];
             const auto &L = per_group[g];
+            const int nno = in.nd / 3;
+            const size_t chunk_elems = (size_t)kChunkThreads * C.cls[cls_of[g]].ept;
             Open o;
             std::vector<int> sc;
-            std::vector<std::array<uint16_t, 8>> lids;
+            std::vector<uint16_t> lids;
             // build the candidate chunk [lo_, hi_); emit it if it respects every limit (elements, nodes, sub-colours)
             auto try_emit = [&](size_t lo_, size_t hi_) {
-                if (hi_ - lo_ > (size_t)kChunkElems) return false;
+                if (hi_ - lo_ > chunk_elems) return false;
                 const int32_t id = next_stamp++;
                 o.elems.clear(); o.nodes.clear();
                 for (size_t k = lo_; k < hi_; ++k) {
-                    for (int l = 0; l < 8; ++l) {
+                    for (int l = 0; l < nno; ++l) {
                         const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
                         if (stamp[node] != id) { stamp[node] = id; o.nodes.push_back((int32_t)node); }
                     }
@@ -334,7 +354,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     if (mid > cdesc.lo && mid < cdesc.hi) break;
                     --bit;
                 }
-                if (bit < 0) mid = cdesc.lo + std::min<size_t>(n_el / 2, (size_t)kChunkElems);      // no spatial key left: cut the run
+                if (bit < 0) mid = cdesc.lo + std::min<size_t>(n_el / 2, chunk_elems);             // no spatial key left: cut the run
                 if (mid == cdesc.lo) mid = cdesc.lo + 1;
                 stack.push_back(Cell{mid, cdesc.hi, bit - 1});                                   // right half later
                 stack.push_back(Cell{cdesc.lo, mid, bit - 1});                                   // left half first (keeps order)
@@ -350,7 +370,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         // phase in which a shared node becomes final = max phase of the chunks that contain it
         std::vector<uint8_t> final_phase((size_t)n_nodes, 0);
         for (int64_t c = 0; c < C.n_chunks; ++c) {
-            const int32_t off = C.hdr[(size_t)c * 4], nn = C.hdr[(size_t)c * 4 + 1];
+            const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1];
             for (int k = 0; k < nn; ++k) final_phase[C.nodes[off + k]] = std::max(final_phase[C.nodes[off + k]], chunk_phase[c]);
         }
         std::vector<int32_t> sh_index((size_t)n_nodes, -1);           // index into sh_node of its final phase
@@ -369,7 +389,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         for (int ph = 0; ph < 2; ++ph) fill[ph].assign(C.sh_ptr[ph].begin(), C.sh_ptr[ph].end() - 1);
         C.dst.resize(C.nodes.size());
         for (int64_t c = 0; c < C.n_chunks; ++c) {                     // ascending chunk id = summation order
-            const int32_t off = C.hdr[(size_t)c * 4], nn = C.hdr[(size_t)c * 4 + 1];
+            const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1];
             for (int k = 0; k < nn; ++k) {
                 const int32_t nd = C.nodes[off + k];
                 if (cnt[nd] == 1) { C.dst[off + k] = 3 * nd; continue; }
@@ -379,9 +399,11 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 C.sh_slot[ph][fill[ph][sh_index[nd]]++] = slot;
             }
         }
-        for (int64_t c = 0; c < C.n_chunks; ++c) C.list[chunk_phase[c]].push_back((int32_t)c);
-        out.n_colors[0] = std::max<int32_t>(out.n_colors[0], C.list[0].empty() ? 0 : 1);
-        out.n_colors[1] = std::max<int32_t>(out.n_colors[1], C.list[1].empty() ? 0 : 1);
+        for (int ph = 0; ph < 2; ++ph) {
+            int launches = 0;
+            for (const auto &K : C.cls) launches += K.list[ph].empty() ? 0 : 1;
+            out.n_colors[ph] = std::max<int32_t>(out.n_colors[ph], launches);
+        }
         if (!out.ranges[0].empty() || !out.ranges[1].empty()) C.needs_zero = true;   // other groups accumulate with +=
     }
 }

@@ -254,40 +254,48 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
     }
 }
 
-// Chunked form (EbeChunkedHost): one workgroup (256 threads, EPT elements each) = one chunk of hex8-like elements.
+// Chunked form (EbeChunkedHost): one workgroup (256 threads, EPT elements each) = one chunk of node-blocked
+// elements with at most NNP nodes (NDP = 3*NNP dofs; the hex8 fast path is NNP = 8).
 //   1. the chunk's unique nodes are staged into LDS (x tile) with node-contiguous global loads,
-//   2. each lane = one element: u_b from the LDS tile, 24 independent FMA chains acc[a] += Ke[a][b]*u_b
-//      with Ke (column-major, wave-uniform) streamed through SGPRs by scalar loads,
-//   3. LDS-staged partial sums: the lanes add their 24 outputs into the LDS y tile sub-colour by
-//      sub-colour (no two lanes of a sub-colour share a node; fixed order -> deterministic),
+//   2. each lane = one element: u_b from the LDS tile, NDP independent FMA chains acc[a] += Ke[a][b]*u_b
+//      with Ke (column-major, zero padded, wave-uniform) streamed through SGPRs by scalar loads,
+//   3. LDS-staged partial sums: the lanes add their outputs into the LDS y tile sub-colour by sub-colour
+//      (no two lanes of a sub-colour share a node; fixed order -> deterministic),
 //   4. tile nodes owned by this chunk alone are stored straight to y; nodes shared with other chunks go
 //      to this chunk's slots of the boundary buffer, summed afterwards by k_ebe_shared in chunk order.
-// All chunks of a phase are ONE launch (no colour-by-colour launches, no read-modify-write of y).
-template <int EPT, bool DOT>
-__global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk24(
+// All chunks of a phase and node-count class are ONE launch (no colour-by-colour launches, no
+// read-modify-write of y).
+template <int NNP, int EPT> struct ChunkLB { static constexpr int w = NNP == 8 ? (EPT == 1 ? 4 : 3) : 2; };
+
+template <int NNP, int EPT, bool DOT>
+__global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_chunk(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
     const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
     const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
     const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
 {
     constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
-    constexpr int kChunkElems = kChunkThreads * EPT;
+    constexpr int CE = kChunkThreads * EPT;                  // element slots per chunk
+    constexpr int NDP = 3 * NNP;
+    constexpr int W = NDP / 32 + 1;                          // sign words; bits 24..31 of the last one = sub-colour
     __shared__ double xs[3 * kChunkMaxNodes];
     __shared__ double ys[3 * kChunkMaxNodes];
     const int chunk = chunk_list[blockIdx.x];
-    const int4 h = hdr[chunk];                               // node_off, n_nodes, n_sub, group24
+    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
+    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
+    const int kci = h2.x, nd = h2.y;
     // ---- issue every global load of this chunk up front: element data, node ids, x tile ---------------
-    unsigned sg[EPT];
+    unsigned sg[EPT][W];
     double c[EPT];
-    int l3[EPT][8];
+    int l3[EPT][NNP];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const size_t t = (size_t)chunk * kChunkElems + j * kChunkThreads + threadIdx.x;
-        sg[j] = __builtin_nontemporal_load(sgn + t);
-        c[j] = __builtin_nontemporal_load(ck + t);
+        const size_t lane = j * kChunkThreads + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)chunk * 8 + k) * kChunkElems + j * kChunkThreads + threadIdx.x);
+        for (int w = 0; w < W; ++w) sg[j][w] = __builtin_nontemporal_load(sgn + ((size_t)kci * W + w) * CE + lane);
+        c[j] = __builtin_nontemporal_load(ck + (size_t)kci * CE + lane);
+#pragma unroll
+        for (int k = 0; k < NNP; ++k) l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
     }
     int dst[NPT];
     double dot = 0.0;
@@ -304,43 +312,60 @@ __global__ __launch_bounds__(kChunkThreads, (EPT == 1 ? 4 : 3)) void k_ebe_chunk
         }
     }
     __syncthreads();
-    const double *K = ke_col + (size_t)h.w * 576;
-    double acc[EPT][24];
+    const double *K = ke_col + (size_t)h.w * NDP * NDP;
+    // output rows are produced RB at a time (register budget: RB accumulators per element); one pass for
+    // <= 24-node patterns, two for 32-node ones
+    constexpr int RB = NNP == 32 ? 48 : NDP;
 #pragma unroll
-    for (int j = 0; j < EPT; ++j)
-#pragma unroll
-        for (int a = 0; a < 24; ++a) acc[j][a] = 0.0;
-#pragma unroll
-    for (int b = 0; b < 24; ++b) {
-        double u[EPT];
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            double v = xs[l3[j][b / 3] + b % 3];             // :277 gather (from the LDS tile)
-            if ((sg[j] >> b) & 1u) v = -v;                   // :278
-            u[j] = c[j] * v;                                 // :279 Ck * U
-        }
-#pragma unroll
-        for (int a = 0; a < 24; ++a) {
-            const double k = K[b * 24 + a];                  // wave-uniform -> SGPR pair
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
-        }
-    }
-    for (int s = 0; s < h.z; ++s) {
+    for (int a0 = 0; a0 < NDP; a0 += RB) {
+        if (NNP != 8 && a0 >= nd) break;
+        double acc[EPT][RB];
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
-            if ((int)(sg[j] >> 24) == s) {                   // the 24 targets of one element are distinct: batch the reads
-                double old[24];
 #pragma unroll
-                for (int a = 0; a < 24; ++a) old[a] = ys[l3[j][a / 3] + a % 3];
+            for (int a = 0; a < RB; ++a) acc[j][a] = 0.0;
 #pragma unroll
-                for (int a = 0; a < 24; ++a) {
-                    double o = acc[j][a];
-                    if ((sg[j] >> a) & 1u) o = -o;           // :280
-                    ys[l3[j][a / 3] + a % 3] = old[a] + o;   // :300, LDS-staged partial sums
-                }
+        for (int b = 0; b < NDP; ++b) {
+            if (NNP != 8 && b >= nd) break;                  // (hex8 class: columns >= nd are zero padded, no test)
+            double u[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                double v = xs[l3[j][b / 3] + b % 3];         // :277 gather (from the LDS tile)
+                if ((sg[j][b >> 5] >> (b & 31)) & 1u) v = -v;    // :278
+                u[j] = c[j] * v;                             // :279 Ck * U
             }
-        __syncthreads();
+#pragma unroll
+            for (int a = 0; a < RB; ++a) {
+                const double k = K[b * NDP + a0 + a];        // wave-uniform -> SGPR pair
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
+            }
+        }
+        for (int s = 0; s < h.z; ++s) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+                if ((int)(sg[j][W - 1] >> 24) == s) {        // the targets of one element are distinct: batch the reads
+#pragma unroll
+                    for (int q0 = 0; q0 < RB; q0 += 24) {
+                        if (NNP != 8 && a0 + q0 >= nd) break;
+                        double old[24];
+#pragma unroll
+                        for (int q = 0; q < 24; ++q) {
+                            const int a = a0 + q0 + q;
+                            old[q] = (NNP == 8 || a < nd) ? ys[l3[j][a / 3] + a % 3] : 0.0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 24; ++q) {
+                            const int a = a0 + q0 + q;
+                            if (NNP != 8 && a >= nd) break;
+                            double o = acc[j][q0 + q];
+                            if ((sg[j][a >> 5] >> (a & 31)) & 1u) o = -o;   // :280
+                            ys[l3[j][a / 3] + a % 3] = old[q] + o;          // :300, LDS-staged partial sums
+                        }
+                    }
+                }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
@@ -631,8 +656,16 @@ class HipBackend : public Backend {
     std::vector<EbeRange> ebe_ranges_[2];
     bool ebe_ = false;
     // chunked matrix-free operator
-    int *d_ch_list_[2] = {nullptr, nullptr};
-    int ch_count_[2] = {0, 0}, sh_count_[2] = {0, 0};
+    struct ChunkClassDev {
+        int nnp = 8, ept = 1;
+        int *list[2] = {nullptr, nullptr};
+        int count[2] = {0, 0};
+        unsigned short *lid = nullptr;
+        double *ck = nullptr, *ke = nullptr;
+        unsigned *sgn = nullptr;
+    } chc_[kChunkClasses];
+    int n_chunks_total_[2] = {0, 0};
+    int sh_count_[2] = {0, 0};
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr}, *d_sh_slot_[2] = {nullptr, nullptr};
     int *d_ch_dst_ = nullptr;
     double *d_ch_buf_ = nullptr;
@@ -640,11 +673,7 @@ class HipBackend : public Backend {
     int cnt_ebe_ = 0;
     bool ch_needs_zero_ = true;
     int4 *d_ch_hdr_ = nullptr;
-    int ch_ept_ = 1;
     int *d_ch_nodes_ = nullptr;
-    unsigned short *d_ch_lid_ = nullptr;
-    double *d_ch_ck_ = nullptr, *d_ch_ke_ = nullptr;
-    unsigned *d_ch_sgn_ = nullptr;
     // halo
     int *d_send_idx_ = nullptr, *d_fptr_ = nullptr, *d_fpos_ = nullptr;
     int64_t halo_count_ = 0, nb_dofs_ = 0;
@@ -711,8 +740,10 @@ public:
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
-        for (void *p : {(void *)d_ch_list_[0], (void *)d_ch_list_[1], (void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_lid_,
-                        (void *)d_ch_ck_, (void *)d_ch_sgn_, (void *)d_ch_ke_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
+        for (auto &D : chc_)
+            for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke})
+                if (p) (void)hipFree(p);
+        for (void *p : {(void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
                         (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1], (void *)d_sh_slot_[0], (void *)d_sh_slot_[1]})
             if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
@@ -792,30 +823,37 @@ public:
         }
         for (int ph = 0; ph < 2; ++ph) ebe_ranges_[ph] = m.ranges[ph];
         const auto &C = m.chunked;
-        ch_ept_ = C.ept;
         if (C.n_chunks > 0) {
             auto up = [&](auto *&dst, const auto &v) {
                 using T = std::remove_reference_t<decltype(*dst)>;
-                dst = (T *)alloc(sizeof(v[0]) * v.size());
+                dst = (T *)alloc(sizeof(v[0]) * std::max<size_t>(1, v.size()));
                 h2d(dst, v.data(), sizeof(v[0]) * v.size());
             };
             d_ch_hdr_ = (int4 *)alloc(sizeof(int) * C.hdr.size());
             h2d(d_ch_hdr_, C.hdr.data(), sizeof(int) * C.hdr.size());
-            up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst); up(d_ch_lid_, C.lid); up(d_ch_ck_, C.ck); up(d_ch_sgn_, C.sgn);
-            up(d_ch_ke_, C.ke_col);
+            up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst);
             d_ch_buf_ = (double *)alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(1, C.n_slots));
-            {
-                size_t np = 8;
-                for (int ph = 0; ph < 2; ++ph) np += C.list[ph].size() + (C.sh_node[ph].size() + kBlock - 1) / kBlock;
-                d_part_ebe_ = (double *)alloc(sizeof(double) * np);
-            }
             ch_needs_zero_ = C.needs_zero;
+            size_t np = 8;
+            for (int c = 0; c < kChunkClasses; ++c) {
+                const auto &K = C.cls[c];
+                auto &D = chc_[c];
+                D.nnp = K.nnp; D.ept = K.ept;
+                if (K.n_chunks == 0) continue;
+                up(D.lid, K.lid); up(D.ck, K.ck); up(D.sgn, K.sgn); up(D.ke, K.ke_col);
+                for (int ph = 0; ph < 2; ++ph) {
+                    D.count[ph] = (int)K.list[ph].size();
+                    n_chunks_total_[ph] += D.count[ph];
+                    np += K.list[ph].size();
+                    if (D.count[ph]) up(D.list[ph], K.list[ph]);
+                }
+            }
             for (int ph = 0; ph < 2; ++ph) {
-                ch_count_[ph] = (int)C.list[ph].size();
-                if (ch_count_[ph]) up(d_ch_list_[ph], C.list[ph]);
                 sh_count_[ph] = (int)C.sh_node[ph].size();
+                np += (C.sh_node[ph].size() + kBlock - 1) / kBlock;
                 if (sh_count_[ph]) { up(d_sh_node_[ph], C.sh_node[ph]); up(d_sh_ptr_[ph], C.sh_ptr[ph]); up(d_sh_slot_[ph], C.sh_slot[ph]); }
             }
+            d_part_ebe_ = (double *)alloc(sizeof(double) * np);
         }
     }
     void ebe_launch_range(const EbeRange &r, const double *x, double *y)
@@ -828,30 +866,38 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
-    template <int EPT>
-    void launch_chunks(int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    template <int NNP, int EPT>
+    void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
-            hipLaunchKernelGGL((k_ebe_chunk24<EPT, true>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
-            hipLaunchKernelGGL((k_ebe_chunk24<EPT, false>), dim3(ch_count_[ph]), dim3(kChunkThreads), 0, st_, d_ch_list_[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, d_ch_lid_, d_ch_ck_, d_ch_sgn_, d_ch_ke_, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+    }
+    void launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        switch (D.nnp) {
+        case 8: if (D.ept == 2) launch_chunks<8, 2>(D, ph, x, y, dot, part, dot_lo); else launch_chunks<8, 1>(D, ph, x, y, dot, part, dot_lo); break;
+        case 16: launch_chunks<16, 1>(D, ph, x, y, dot, part, dot_lo); break;
+        case 24: launch_chunks<24, 1>(D, ph, x, y, dot, part, dot_lo); break;
+        default: launch_chunks<32, 1>(D, ph, x, y, dot, part, dot_lo); break;
+        }
     }
     bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
         // the fused dot needs every dof to be finalised by the chunk / shared kernels
-        const bool fuse = with_dot && ebe_ranges_[0].empty() && ebe_ranges_[1].empty() && (ch_count_[0] + ch_count_[1]) > 0;
+        const bool fuse = with_dot && ebe_ranges_[0].empty() && ebe_ranges_[1].empty() && (n_chunks_total_[0] + n_chunks_total_[1]) > 0;
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         if (zero_first && ch_needs_zero_) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
-            if (ch_count_[ph]) {
-                double *part = d_part_ebe_ + cnt_ebe_;
-                if (ch_ept_ == 1) launch_chunks<1>(ph, x, y, fuse, part, dot_lo);
-                else launch_chunks<2>(ph, x, y, fuse, part, dot_lo);
-                if (fuse) cnt_ebe_ += ch_count_[ph];
-            }
+            for (const auto &D : chc_)                           // one launch per node-count class
+                if (D.count[ph]) {
+                    launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
+                    if (fuse) cnt_ebe_ += D.count[ph];
+                }
             if (sh_count_[ph]) {
                 const int grid = (sh_count_[ph] + kBlock - 1) / kBlock;
                 double *part = d_part_ebe_ + cnt_ebe_;

@@ -51,19 +51,31 @@ struct EbeGroupHost {
 };
 struct EbeRange { int32_t group; int64_t lo, hi; };      // elements [lo,hi) of `group`: one launch
 
-// Chunked form for hex8-like groups (nd == 24, slots 3l..3l+2 = the three dofs of local node l):
-// a chunk = up to 512 spatially clustered elements of one group = one workgroup.  The chunk's unique
-// nodes are staged in LDS (x tile in, y tile out); elements of a chunk are sub-coloured and add into
-// the LDS y tile phase by phase.  All chunks of a phase run in ONE launch: a tile node that belongs to
-// a single chunk is stored straight to y, a node shared by several chunks goes to that chunk's slot of
-// a boundary buffer and a second small kernel sums the slots of every shared node in chunk order
-// (deterministic, no atomics, no colour-by-colour launches, no read-modify-write of y).
+// Chunked form for node-blocked pattern types (slots 3l..3l+2 = the three dofs of local node l, at most 32
+// nodes): a chunk = up to 256*ept spatially clustered elements of one group = one workgroup.  The chunk's
+// unique nodes are staged in LDS (x tile in, y tile out); elements of a chunk are sub-coloured and add
+// into the LDS y tile phase by phase.  All chunks of a phase run in ONE launch per node-count class: a
+// tile node that belongs to a single chunk is stored straight to y, a node shared by several chunks goes
+// to that chunk's slot of a boundary buffer and a second small kernel sums the slots of every shared node
+// in chunk order (deterministic, no atomics, no colour-by-colour launches, no read-modify-write of y).
 constexpr int kChunkThreads = 256;                 // workgroup size
 constexpr int kChunkMaxNodes = 768;                // 8x8x8 hex cells -> 729 nodes (LDS x + y tiles = 36.9 KB)
-struct EbeChunkedHost {
-    int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (1 or 2; 2 amortises the Ke stream)
+constexpr int kChunkClasses = 4;                   // patterns with <= 8 / 16 / 24 / 32 nodes (nd <= 24 / 48 / 72 / 96)
+struct EbeClassHost {
+    int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
+    int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (2 only for nnp == 8)
+    int32_t words = 1;                 // sign words per element = NDP/32 + 1; bits 24..31 of the last word = sub-colour
     int64_t n_chunks = 0;
-    std::vector<int32_t> hdr;          // (n_chunks, 4): node_off, n_nodes, n_subcolors, group24 index
+    std::vector<uint16_t> lid;         // (n_chunks, nnp, 256*ept) local node index of element-node l (0 for padding)
+    std::vector<double> ck;            // (n_chunks, 256*ept)   (0 for padding slots)
+    std::vector<uint32_t> sgn;         // (n_chunks, words, 256*ept); sub-colour 255 = padding slot
+    std::vector<double> ke_col;        // (groups of the class, NDP b, NDP a) column-major, zero padded
+    std::vector<int32_t> list[2];      // per phase: global chunk ids of this class (one launch each)
+};
+struct EbeChunkedHost {
+    int64_t n_chunks = 0;
+    std::vector<int32_t> hdr;          // (n_chunks, 8): node_off, n_nodes, n_subcolours, ke index in class,
+                                       //                chunk index in class, nd, class, 0
     std::vector<int32_t> nodes;        // concatenated unique node ids (engine numbering, ascending per chunk)
     std::vector<int32_t> dst;          // same shape: >= 0: y offset 3*node (exclusive node); < 0: -(boundary slot + 1)
     int64_t n_slots = 0;               // boundary-buffer slots (one per (chunk, shared node))
@@ -71,11 +83,7 @@ struct EbeChunkedHost {
     std::vector<int32_t> sh_ptr[2];    //            CSR over their slots
     std::vector<int32_t> sh_slot[2];   //            slots in ascending chunk order
     bool needs_zero = false;           // some node is touched by no chunk (isolated, or only by non-chunked groups)
-    std::vector<uint16_t> lid;         // (n_chunks, 8, 256*ept) local node index of element-node l
-    std::vector<double> ck;            // (n_chunks, 256*ept)   (0 for padding slots)
-    std::vector<uint32_t> sgn;         // (n_chunks, 256*ept)   bits 0..23 sign mask, bits 24..31 sub-colour (255 = padding)
-    std::vector<double> ke_col;        // (n_group24, 24 b, 24 a) column-major element matrices
-    std::vector<int32_t> list[2];      // per phase: chunk ids (one launch per phase)
+    EbeClassHost cls[kChunkClasses];
     int32_t max_subcolors = 0;
 };
 struct EbeHost {

@@ -49,35 +49,38 @@ public:
         const auto &C = ebe_.chunked;
         if (zero_first && (C.n_chunks == 0 || C.needs_zero)) std::memset(y, 0, sizeof(double) * n_);
         std::vector<double> u;
-        const int kChunkElems = kChunkThreads * C.ept;
-        std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc(24 * (size_t)kChunkElems);
+        std::vector<double> xs(3 * kChunkMaxNodes), ys(3 * kChunkMaxNodes), acc;
         if (ebuf_.size() < (size_t)C.n_slots * 3) ebuf_.assign((size_t)C.n_slots * 3, 0.0);
         for (int ph = plo; ph < phi; ++ph) {
-            for (int32_t cid : C.list[ph]) {
-                const int32_t off = C.hdr[(size_t)cid * 4], nn = C.hdr[(size_t)cid * 4 + 1], nsub = C.hdr[(size_t)cid * 4 + 2];
-                const double *K = &C.ke_col[(size_t)C.hdr[(size_t)cid * 4 + 3] * 576];
+            for (const auto &K : C.cls)                               // one launch per node-count class
+            for (int32_t cid : K.list[ph]) {
+                const int32_t *h = &C.hdr[(size_t)cid * 8];
+                const int32_t off = h[0], nn = h[1], nsub = h[2], kci = h[4], nd = h[5];
+                const int CE = kChunkThreads * K.ept, W = K.words, ndp = 3 * K.nnp;
+                const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
+                acc.assign((size_t)nd * CE, 0.0);
                 for (int n = 0; n < nn; ++n)
                     for (int d = 0; d < 3; ++d) { xs[3 * n + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
-                for (int lane = 0; lane < kChunkElems; ++lane) {
-                    const uint32_t sg = C.sgn[(size_t)cid * kChunkElems + lane];
-                    const double c = C.ck[(size_t)cid * kChunkElems + lane];
-                    double *a = &acc[(size_t)lane * 24];
-                    for (int k = 0; k < 24; ++k) a[k] = 0.0;
-                    for (int b = 0; b < 24; ++b) {
-                        double v = xs[3 * C.lid[((size_t)cid * 8 + b / 3) * kChunkElems + lane] + b % 3];
-                        if ((sg >> b) & 1u) v = -v;
+                auto sbit = [&](int lane, int a) { return (K.sgn[((size_t)kci * W + a / 32) * CE + lane] >> (a % 32)) & 1u; };
+                auto subc = [&](int lane) { return (int)(K.sgn[((size_t)kci * W + W - 1) * CE + lane] >> 24); };
+                for (int lane = 0; lane < CE; ++lane) {
+                    if (subc(lane) == 255) continue;
+                    const double c = K.ck[(size_t)kci * CE + lane];
+                    double *a = &acc[(size_t)lane * nd];
+                    for (int b = 0; b < nd; ++b) {
+                        double v = xs[3 * K.lid[((size_t)kci * K.nnp + b / 3) * CE + lane] + b % 3];
+                        if (sbit(lane, b)) v = -v;
                         v = c * v;
-                        for (int k = 0; k < 24; ++k) a[k] += K[b * 24 + k] * v;
+                        for (int k = 0; k < nd; ++k) a[k] += Kc[(size_t)b * ndp + k] * v;
                     }
                 }
                 for (int s = 0; s < nsub; ++s)
-                    for (int lane = 0; lane < kChunkElems; ++lane) {
-                        const uint32_t sg = C.sgn[(size_t)cid * kChunkElems + lane];
-                        if ((int)(sg >> 24) != s) continue;
-                        for (int k = 0; k < 24; ++k) {
-                            double o = acc[(size_t)lane * 24 + k];
-                            if ((sg >> k) & 1u) o = -o;
-                            ys[3 * C.lid[((size_t)cid * 8 + k / 3) * kChunkElems + lane] + k % 3] += o;
+                    for (int lane = 0; lane < CE; ++lane) {
+                        if (subc(lane) != s) continue;
+                        for (int k = 0; k < nd; ++k) {
+                            double o = acc[(size_t)lane * nd + k];
+                            if (sbit(lane, k)) o = -o;
+                            ys[3 * K.lid[((size_t)kci * K.nnp + k / 3) * CE + lane] + k % 3] += o;
                         }
                     }
                 for (int n = 0; n < nn; ++n) {

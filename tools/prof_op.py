@@ -9,7 +9,13 @@ from pcg_mi355x.operator import from_refmeshpart
 kind = sys.argv[1] if len(sys.argv) > 1 else "ebe"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-P = make_parts(Brick(N))[0]
-op = from_refmeshpart(P, kind=kind)
+if os.environ.get("PROF_OCTREE"):          # two-level octree mesh with hanging-node transition patterns (nd = 39)
+    from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
+    m = TwoLevelMesh(N, N, N // 2, N // 8)
+    P = make_octree_parts(m, 1)[0]
+    print("octree mesh", m.n_dof, "dof", {k: len(v) for k, v in m.cells.items()})
+else:
+    P = make_parts(Brick(N))[0]
+op = from_refmeshpart(P, kind=kind, ebe_chunked=os.environ.get("PROF_EBE_CHUNKED", "1") == "1")
 ms = op.bench_spmv(3, reps)
 print(kind, N, op.operator_info(), "median ms", float(np.median(ms)), "min", float(ms.min()))
