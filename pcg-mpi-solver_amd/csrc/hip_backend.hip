@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
     constexpr int RB = NNP == 32 ? 48 : NDP;
 #pragma unroll
     for (int a0 = 0; a0 < NDP; a0 += RB) {
-        if (NNP != 8 && a0 >= nd) break;
+        if (a0 >= nd) break;
         double acc[EPT][RB];
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
             for (int a = 0; a < RB; ++a) acc[j][a] = 0.0;
 #pragma unroll
         for (int b = 0; b < NDP; ++b) {
-            if (NNP != 8 && b >= nd) break;                  // (hex8 class: columns >= nd are zero padded, no test)
+            if (b >= nd) break;                              // nd is block-uniform: a scalar compare
             double u[EPT];
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
@@ -347,17 +347,17 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
                 if ((int)(sg[j][W - 1] >> 24) == s) {        // the targets of one element are distinct: batch the reads
 #pragma unroll
                     for (int q0 = 0; q0 < RB; q0 += 24) {
-                        if (NNP != 8 && a0 + q0 >= nd) break;
+                        if (a0 + q0 >= nd) break;
                         double old[24];
 #pragma unroll
                         for (int q = 0; q < 24; ++q) {
                             const int a = a0 + q0 + q;
-                            old[q] = (NNP == 8 || a < nd) ? ys[l3[j][a / 3] + a % 3] : 0.0;
+                            old[q] = a < nd ? ys[l3[j][a / 3] + a % 3] : 0.0;
                         }
 #pragma unroll
                         for (int q = 0; q < 24; ++q) {
                             const int a = a0 + q0 + q;
-                            if (NNP != 8 && a >= nd) break;
+                            if (a >= nd) break;              // padded slots alias local node 0: never write them
                             double o = acc[j][q0 + q];
                             if ((sg[j][a >> 5] >> (a & 31)) & 1u) o = -o;   // :280
                             ys[l3[j][a / 3] + a % 3] = old[q] + o;          // :300, LDS-staged partial sums

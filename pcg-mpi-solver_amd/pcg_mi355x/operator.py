@@ -273,8 +273,9 @@ class Operator:
 
     def close(self):
         if getattr(self, "_h", None):
-            if getattr(self, "_comm", None) is not None:
-                self._comm.release_stream(self.stream_ptr())
+            rel = getattr(getattr(self, "_comm", None), "release_stream", None)
+            if rel is not None:
+                rel(self.stream_ptr())
             self._L.pcg_destroy(self._h)
             self._h = None
 
