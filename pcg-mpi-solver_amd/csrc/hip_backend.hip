@@ -316,55 +316,61 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
     // output rows are produced RB at a time (register budget: RB accumulators per element); one pass for
     // <= 24-node patterns, two for 32-node ones
     constexpr int RB = NNP == 32 ? 48 : NDP;
+    // nd is block-uniform, so every `x < nd` below is a scalar compare + uniform branch; the loops stay
+    // fully unrolled (no `break`), which keeps the accumulators in registers
 #pragma unroll
     for (int a0 = 0; a0 < NDP; a0 += RB) {
-        if (a0 >= nd) break;
-        double acc[EPT][RB];
-#pragma unroll
-        for (int j = 0; j < EPT; ++j)
-#pragma unroll
-            for (int a = 0; a < RB; ++a) acc[j][a] = 0.0;
-#pragma unroll
-        for (int b = 0; b < NDP; ++b) {
-            if (b >= nd) break;                              // nd is block-uniform: a scalar compare
-            double u[EPT];
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                double v = xs[l3[j][b / 3] + b % 3];         // :277 gather (from the LDS tile)
-                if ((sg[j][b >> 5] >> (b & 31)) & 1u) v = -v;    // :278
-                u[j] = c[j] * v;                             // :279 Ck * U
-            }
-#pragma unroll
-            for (int a = 0; a < RB; ++a) {
-                const double k = K[b * NDP + a0 + a];        // wave-uniform -> SGPR pair
-#pragma unroll
-                for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
-            }
-        }
-        for (int s = 0; s < h.z; ++s) {
+        if (a0 < nd) {
+            double acc[EPT][RB];
 #pragma unroll
             for (int j = 0; j < EPT; ++j)
-                if ((int)(sg[j][W - 1] >> 24) == s) {        // the targets of one element are distinct: batch the reads
 #pragma unroll
-                    for (int q0 = 0; q0 < RB; q0 += 24) {
-                        if (a0 + q0 >= nd) break;
-                        double old[24];
+                for (int a = 0; a < RB; ++a) acc[j][a] = 0.0;
 #pragma unroll
-                        for (int q = 0; q < 24; ++q) {
-                            const int a = a0 + q0 + q;
-                            old[q] = a < nd ? ys[l3[j][a / 3] + a % 3] : 0.0;
-                        }
+            for (int b = 0; b < NDP; ++b) {
+                if (b < nd) {
+                    double u[EPT];
 #pragma unroll
-                        for (int q = 0; q < 24; ++q) {
-                            const int a = a0 + q0 + q;
-                            if (a >= nd) break;              // padded slots alias local node 0: never write them
-                            double o = acc[j][q0 + q];
-                            if ((sg[j][a >> 5] >> (a & 31)) & 1u) o = -o;   // :280
-                            ys[l3[j][a / 3] + a % 3] = old[q] + o;          // :300, LDS-staged partial sums
-                        }
+                    for (int j = 0; j < EPT; ++j) {
+                        double v = xs[l3[j][b / 3] + b % 3];             // :277 gather (from the LDS tile)
+                        if ((sg[j][b >> 5] >> (b & 31)) & 1u) v = -v;    // :278
+                        u[j] = c[j] * v;                                 // :279 Ck * U
+                    }
+#pragma unroll
+                    for (int a = 0; a < RB; ++a) {
+                        const double k = K[b * NDP + a0 + a];            // wave-uniform -> SGPR pair
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
                     }
                 }
-            __syncthreads();
+            }
+            for (int s = 0; s < h.z; ++s) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j)
+                    if ((int)(sg[j][W - 1] >> 24) == s) {    // the targets of one element are distinct: batch the reads
+#pragma unroll
+                        for (int q0 = 0; q0 < RB; q0 += 24) {
+                            if (a0 + q0 < nd) {
+                                double old[24];
+#pragma unroll
+                                for (int q = 0; q < 24; ++q) {
+                                    const int a = a0 + q0 + q;
+                                    old[q] = a < nd ? ys[l3[j][a / 3] + a % 3] : 0.0;
+                                }
+#pragma unroll
+                                for (int q = 0; q < 24; ++q) {
+                                    const int a = a0 + q0 + q;
+                                    if (a < nd) {                        // padded slots alias local node 0: never write them
+                                        double o = acc[j][q0 + q];
+                                        if ((sg[j][a >> 5] >> (a & 31)) & 1u) o = -o;   // :280
+                                        ys[l3[j][a / 3] + a % 3] = old[q] + o;          // :300, LDS-staged partial sums
+                                    }
+                                }
+                            }
+                        }
+                    }
+                __syncthreads();
+            }
         }
     }
 #pragma unroll
