@@ -213,13 +213,15 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     bool any = false;
     for (int c = 0; c < kChunkClasses; ++c) {
         auto &K = C.cls[c];
-        K.nnp = 8 * (c + 1);
+        K.nnp = c == 4 ? 8 : 8 * (c + 1);
+        K.full = c == 0;
         K.ept = c == 0 ? ept : 1;
         K.words = 3 * K.nnp / 32 + 1;
     }
     for (int g = 0; g < n_groups; ++g)
         if (chunkable[g]) {
-            const int nn = gs[g].nd / 3, c = (nn + 7) / 8 - 1, nd = gs[g].nd;
+            const int nn = gs[g].nd / 3, nd = gs[g].nd;
+            const int c = nn == 8 ? 0 : (nn < 8 ? 4 : (nn + 7) / 8 - 1);
             auto &K = C.cls[c];
             const int ndp = 3 * K.nnp;
             cls_of[g] = c;

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
 // read-modify-write of y).
 template <int NNP, int EPT> struct ChunkLB { static constexpr int w = NNP == 8 ? (EPT == 1 ? 4 : 3) : 2; };
 
-template <int NNP, int EPT, bool DOT>
+// FULL: every element of the launch has exactly NNP nodes (the hex8 class): the `< nd` guards compile away.
+template <int NNP, int EPT, bool FULL, bool DOT>
 __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_chunk(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
     const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
     const int chunk = chunk_list[blockIdx.x];
     const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
     const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
-    const int kci = h2.x, nd = h2.y;
+    const int kci = h2.x, nd = FULL ? 3 * NNP : h2.y;
     // ---- issue every global load of this chunk up front: element data, node ids, x tile ---------------
     unsigned sg[EPT][W];
     double c[EPT];
@@ -664,6 +665,7 @@ class HipBackend : public Backend {
     // chunked matrix-free operator
     struct ChunkClassDev {
         int nnp = 8, ept = 1;
+        bool full = false;
         int *list[2] = {nullptr, nullptr};
         int count[2] = {0, 0};
         unsigned short *lid = nullptr;
@@ -844,7 +846,7 @@ public:
             for (int c = 0; c < kChunkClasses; ++c) {
                 const auto &K = C.cls[c];
                 auto &D = chc_[c];
-                D.nnp = K.nnp; D.ept = K.ept;
+                D.nnp = K.nnp; D.ept = K.ept; D.full = K.full;
                 if (K.n_chunks == 0) continue;
                 up(D.lid, K.lid); up(D.ck, K.ck); up(D.sgn, K.sgn); up(D.ke, K.ke_col);
                 for (int ph = 0; ph < 2; ++ph) {
@@ -872,23 +874,27 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
-    template <int NNP, int EPT>
+    template <int NNP, int EPT, bool FULL>
     void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
                                d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
                                d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     void launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         switch (D.nnp) {
-        case 8: if (D.ept == 2) launch_chunks<8, 2>(D, ph, x, y, dot, part, dot_lo); else launch_chunks<8, 1>(D, ph, x, y, dot, part, dot_lo); break;
-        case 16: launch_chunks<16, 1>(D, ph, x, y, dot, part, dot_lo); break;
-        case 24: launch_chunks<24, 1>(D, ph, x, y, dot, part, dot_lo); break;
-        default: launch_chunks<32, 1>(D, ph, x, y, dot, part, dot_lo); break;
+        case 8:
+            if (!D.full) launch_chunks<8, 1, false>(D, ph, x, y, dot, part, dot_lo);
+            else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo);
+            else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo);
+            break;
+        case 16: launch_chunks<16, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
+        case 24: launch_chunks<24, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
+        default: launch_chunks<32, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
         }
     }
     bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override

@@ -60,9 +60,11 @@ struct EbeRange { int32_t group; int64_t lo, hi; };      // elements [lo,hi) of 
 // in chunk order (deterministic, no atomics, no colour-by-colour launches, no read-modify-write of y).
 constexpr int kChunkThreads = 256;                 // workgroup size
 constexpr int kChunkMaxNodes = 768;                // 8x8x8 hex cells -> 729 nodes (LDS x + y tiles = 36.9 KB)
-constexpr int kChunkClasses = 4;                   // patterns with <= 8 / 16 / 24 / 32 nodes (nd <= 24 / 48 / 72 / 96)
+constexpr int kChunkClasses = 5;                   // 0: exactly 8 nodes (hex8, unguarded kernel); 1..3: <= 16 / 24 / 32 nodes;
+                                                   // 4: fewer than 8 nodes (padded to 8)
 struct EbeClassHost {
     int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
+    bool full = false;                 // every element of the class has exactly nnp nodes (no padding guards needed)
     int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (2 only for nnp == 8)
     int32_t words = 1;                 // sign words per element = NDP/32 + 1; bits 24..31 of the last word = sub-colour
     int64_t n_chunks = 0;

@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
 import numpy as np
+if os.environ.get("PCG_LIB"):               # A/B against another build of the engine (development only)
+    from pcg_mi355x import _lib
+    _lib.use_library(os.environ["PCG_LIB"])
 from pcg_mi355x.brick import Brick, make_parts
 from pcg_mi355x.operator import from_refmeshpart
 kind = sys.argv[1] if len(sys.argv) > 1 else "ebe"
