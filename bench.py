@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nodes-per-side", type=int, default=int(os.environ.get("PCG_BENCH_N", "150")),
                     help="brick size N (150 -> 10M dof = the metric's configuration; 70 -> 1M; 322 -> 100M)")
+    ap.add_argument("--workload", choices=["brick", "octree"], default="brick",
+                    help="brick = SURVEY 8(d) uniform brick (the metric's configuration); octree = two-level 2:1 graded mesh with "
+                         "hanging-node transition patterns, ~1.2 M dof (BASELINE configs[1] names an octree mesh)")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
     ap.add_argument("--operator", choices=["sell", "ebe", "both"], default="both",
                     help="sell = assembled SELL-BSR3 matrix (the headline value/roofline); both = also time the matrix-free operator")
@@ -118,9 +121,18 @@ def main():
 
     N = args.nodes_per_side
     t0 = time.perf_counter()
-    brick = Brick(N, seed=0)
-    grid = default_grid(world)
-    part = make_parts(brick, block_partition(brick, *grid) if world > 1 else None, only=[rank])[0]
+    if args.workload == "octree":
+        from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
+        brick = TwoLevelMesh(96, 96, 40, 8, seed=0)                 # .n_dof like a Brick; nnz filled in after assembly
+        grid = (world, 1, 1)
+        part = make_octree_parts(brick, world, axis=0)[rank]
+        brick.nnz = None
+        wl_name = f"two-level octree mesh 96x96x(40 fine + 8 coarse), hanging-node transition patterns (nd=39), {brick.n_dof} dof"
+    else:
+        brick = Brick(N, seed=0)
+        grid = default_grid(world)
+        part = make_parts(brick, block_partition(brick, *grid) if world > 1 else None, only=[rank])[0]
+        wl_name = f"synthetic 3D elasticity brick N={N} ({brick.n_dof} dof, {brick.nnz} nnz)"
     t_parts = time.perf_counter() - t0
 
     def fence():
@@ -185,7 +197,9 @@ def main():
     op, elapsed, spmv_ms, n_spmv, final, standalone = m["op"], m["elapsed"], m["op_ms"], m["n_op"], m["final"], m["standalone"]
     info = op.matrix_info()
     if rank == 0:
-        log(f"brick N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
+        if brick.nnz is None:
+            brick.nnz = op.nnz if world == 1 else None
+        log(f"{args.workload} N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
             f"RefMeshPart {t_parts:.1f}s, assemble+upload {m['t_setup']:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
             f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
     n_loc, nnz_loc = op.n, op.nnz
@@ -231,8 +245,7 @@ def main():
         "value": iters_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic 3D elasticity brick N={N} ({brick.n_dof} dof, {brick.nnz} nnz), Jacobi-PCG Tol 1e-7, "
-                               f"{world} part(s) {grid[0]}x{grid[1]}x{grid[2]}",
+        "config": {"workload": f"{wl_name}, Jacobi-PCG Tol 1e-7, {world} part(s) {grid[0]}x{grid[1]}x{grid[2]}",
                    "dofs": brick.n_dof, "nnz": brick.nnz, "parts": world, "format": f"SELL-{info['slice_rows']} over 3x3 blocks",
                    "spmv_achieved_GBps": achieved, "iter_algorithmic_GBps": iter_bytes * world / (elapsed / args.steps) / 1e9},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL-BSR3 SpMV + fused p.Ap)", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -79,20 +79,19 @@ class TwoLevelMesh:
         self.dims = (X, Y, Z)
         lat = lambda x, y, z: (z * Y + y) * X + x                                       # noqa: E731
         rng = np.random.default_rng(seed)
-        fine, coarse, trans = [], [], []
-        for k in range(nzf):
-            for j in range(ny):
-                for i in range(nx):
-                    fine.append([lat(i + (a & 1), j + ((a >> 1) & 1), k + ((a >> 2) & 1)) for a in range(8)])
-        for kc in range(nzc):
-            z0 = nzf + 2 * kc
-            for jc in range(ny // 2):
-                for ic in range(nx // 2):
-                    x0, y0 = 2 * ic, 2 * jc
-                    if kc == 0:
-                        trans.append([lat(x0 + px, y0 + py, z0 + pz) for (px, py, pz) in KEPT])
-                    else:
-                        coarse.append([lat(x0 + 2 * (a & 1), y0 + 2 * ((a >> 1) & 1), z0 + 2 * ((a >> 2) & 1)) for a in range(8)])
+
+        def grid(ni, nj, nk):                       # cell origins, x fastest
+            k, j, i = np.meshgrid(np.arange(nk), np.arange(nj), np.arange(ni), indexing="ij")
+            return i.ravel(), j.ravel(), k.ravel()
+        i, j, k = grid(nx, ny, nzf)
+        fine = np.stack([lat(i + (a & 1), j + ((a >> 1) & 1), k + ((a >> 2) & 1)) for a in range(8)], 1)
+        ic, jc, kc = grid(nx // 2, ny // 2, nzc)
+        x0, y0, z0 = 2 * ic, 2 * jc, nzf + 2 * kc
+        first = kc == 0
+        trans = np.stack([lat(x0[first] + px, y0[first] + py, z0[first] + pz) for (px, py, pz) in KEPT], 1)
+        rest = ~first
+        coarse = np.stack([lat(x0[rest] + 2 * (a & 1), y0[rest] + 2 * ((a >> 1) & 1), z0[rest] + 2 * ((a >> 2) & 1))
+                           for a in range(8)], 1)
         self.cells = {"fine": np.array(fine, np.int64).reshape(-1, 8), "coarse": np.array(coarse, np.int64).reshape(-1, 8),
                       "trans": np.array(trans, np.int64).reshape(-1, 13)}
         used = np.unique(np.concatenate([v.ravel() for v in self.cells.values()]))
