@@ -76,10 +76,11 @@ void pcg_asm_destroy(pcg_asm *a);
  * rows_per_lane: SELL slice = 64*rows_per_lane block rows (1 or 2; 0 = library default). */
 int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols,
                const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
-/* The same engine from an already assembled scalar CSR matrix (n = 3 * nodes rows, i64 row pointer, i32
- * columns, f64 values; dof = 3*node + dir): grouped into 3x3 blocks internally. */
+/* The same engine from an already assembled scalar CSR matrix (i64 row pointer, i32 columns, f64 values).
+ * block = 0/3: n = 3 * nodes rows (dof = 3*node + dir) grouped into 3x3 blocks internally (the fast format);
+ * block = 1:   the scalar format is kept (any n; one f64 + one i32 per non-zero = the literal CSR traffic). */
 int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val,
-                   int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
+                   int64_t n_boundary_nodes, int32_t block, pcg_engine **out);
 /* Matrix-free variant: the operator stays in the reference's element-by-element form
  * (pcg_solver.py:265-300); nothing is assembled.  Same groups / numbering arguments as pcg_asm_create. */
 /* node_coords (n_nodes x 3, ORIGINAL node numbering, may be NULL: RefMeshPart['NodeCoordVec'],

@@ -208,6 +208,56 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     }
 }
 
+// Scalar-row variant (SellHost::bs == 1): one lane per matrix ROW, one f64 value + one i32 column per stored
+// entry - the literal CSR data volume (12 B per non-zero), in the same slice layout, so a wave's loads of a
+// slice column are one 512 B + one 256 B coalesced line.  Used by pcg_create_csr(block = 1): systems whose
+// rows are not 3-dof node blocks, and the "CSR-format" point of the roofline table.
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_scalar(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
+                                                        const double *__restrict__ vals, const double *__restrict__ x,
+                                                        double *__restrict__ y, const uint8_t *__restrict__ flags,
+                                                        double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
+                                                        int64_t n_rows)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
+    double dot = 0.0;
+    for (int64_t s = slice_lo + (int64_t)blockIdx.x * kWavesPerBlock + wid; s < slice_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const double *vp = vals + (size_t)base * 64 + lane;
+        const int *cp = cols + (size_t)base * 64 + lane;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        int k = 0;
+        for (; k + 9 <= w; k += 9) {                            // 9 independent gathers in flight per lane
+            int j[9];
+            double v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { j[c] = ntload(cp + (size_t)(k + c) * 64); v[c] = ntload(vp + (size_t)(k + c) * 64); }
+#pragma unroll
+            for (int c = 0; c < 9; c += 3) {
+                a0 = fma(v[c], x[j[c]], a0);
+                a1 = fma(v[c + 1], x[j[c + 1]], a1);
+                a2 = fma(v[c + 2], x[j[c + 2]], a2);
+            }
+        }
+        for (; k < w; ++k) a0 = fma(ntload(vp + (size_t)k * 64), x[ntload(cp + (size_t)k * 64)], a0);
+        const int64_t row = s * 64 + lane;
+        if (row < n_rows) {
+            const double r = (a0 + a1) + a2;
+            y[row] = r;
+            if constexpr (DOT)
+                if ((flags[row] & 3) == 3) dot += x[row] * r;
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Matrix-free operator (the reference's element-by-element form, pcg_solver.py:277-280 + :300).
 // One thread per element of ONE colour (no two elements of a launch share a node -> plain
@@ -651,6 +701,7 @@ class HipBackend : public Backend {
     int n_cu_ = 256;
     hipStream_t st_ = nullptr;
     // matrix
+    int bs_ = 3;
     int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
     int C_ = 64;
     int64_t *d_slice_ptr_ = nullptr;
@@ -788,7 +839,8 @@ public:
 
     void upload_matrix(const SellHost &m) override
     {
-        n_nodes_ = m.n_nodes; n_ = 3 * m.n_nodes; n_slices_ = m.n_slices; n_bnd_slices_ = m.n_bnd_slices; C_ = m.C;
+        bs_ = m.bs;
+        n_nodes_ = m.n_nodes; n_ = m.bs * m.n_nodes; n_slices_ = m.n_slices; n_bnd_slices_ = m.n_bnd_slices; C_ = m.C;
         d_slice_ptr_ = (int64_t *)alloc(sizeof(int64_t) * m.slice_ptr.size());
         d_cols_ = (int *)alloc(sizeof(int) * m.cols.size());
         d_vals_ = (double *)alloc(sizeof(double) * m.vals.size());
@@ -798,7 +850,7 @@ public:
         h2d(d_cols_, m.cols.data(), sizeof(int) * m.cols.size());
         h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
         h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
-        nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * 3);
+        nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
     }
     void upload_ebe(const EbeHost &m) override
     {
@@ -949,6 +1001,15 @@ public:
     template <int RPL>
     void launch_spmv(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid)
     {
+        if (bs_ == 1) {
+            if (dot)
+                hipLaunchKernelGGL((k_spmv_scalar<true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
+                                   d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+            else
+                hipLaunchKernelGGL((k_spmv_scalar<false>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
+                                   d_flags_, d_part_spmv_, lo, hi, n_nodes_);
+            return;
+        }
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
                                d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);

@@ -348,11 +348,36 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
 // 3x3 node blocks (dof = 3*node + dir), missing entries of a touched block are explicit zeros, then the
 // same SELL-BSR3 path as pcg_create.  Duplicate (row, col) entries are summed in input order.
 int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val,
-                   int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out)
+                   int64_t n_boundary_nodes, int32_t block, pcg_engine **out)
 {
     return guarded("pcg_create_csr", [&]() -> int {
         if (!out || !rowptr || !col || !val || n <= 0) return set_error("pcg_create_csr: bad argument");
-        if (n % 3) return set_error("pcg_create_csr: n must be a multiple of 3 (dof = 3*node + dir)");
+        if (block == 1) {                                    // keep the scalar format: one f64 + one i32 per non-zero
+            auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
+            e->be = make_backend(device);
+            SellHost m;
+            csr_to_sell1(n, rowptr, col, val, 3 * n_boundary_nodes, 8, m);
+            e->n_nodes = n;                                  // rows
+            e->n = n;
+            e->n_slices = m.n_slices;
+            e->n_bnd_slices = m.n_bnd_slices;
+            e->n_bnd_dofs = std::min<int64_t>(n, m.n_bnd_slices * m.C);
+            e->C = m.C;
+            e->nnzb = m.nnzb;
+            e->stored_blocks = m.slice_ptr.back() * m.C;
+            e->be->upload_matrix(m);
+            e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
+            e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+            e->be->set_status_block(e->d_st);
+            e->v_minv = e->vec();
+            std::vector<uint8_t> f((size_t)e->n, 3);
+            e->be->upload_masks(f.data(), e->n);
+            *out = e.release();
+            return 0;
+        }
+        if (block != 0 && block != 3) return set_error("pcg_create_csr: block must be 0/3 (3x3 node blocks) or 1 (scalar)");
+        const int32_t rows_per_lane = 0;
+        if (n % 3) return set_error("pcg_create_csr: n must be a multiple of 3 (dof = 3*node + dir); use block = 1 otherwise");
         const int64_t nn = n / 3;
         std::vector<int64_t> brow((size_t)nn + 1, 0);
         std::vector<int32_t> bcol;

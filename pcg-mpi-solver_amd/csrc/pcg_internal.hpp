@@ -21,6 +21,8 @@ const std::string &last_error_string();
 //     cols[ (slice_ptr[s] + k)          * C + (row - s*C)]     block column (node) index
 // Padding entries carry value 0 and the row's own (valid) column.  C = 64 * rows_per_lane.
 struct SellHost {
+    int32_t bs = 3;               // block size: 3 = 3x3 node blocks (the solver's format); 1 = scalar rows (literal CSR data:
+                                  // one f64 + one i32 column per non-zero), `n_nodes` then counts scalar rows
     int64_t n_nodes = 0;
     int64_t n_slices = 0;
     int32_t C = 64;
@@ -32,6 +34,8 @@ struct SellHost {
     std::vector<double> diag;     // diag(A) local, length 3*n_nodes (extracted at build time)
 };
 
+void csr_to_sell1(int64_t n, const int64_t *rowptr, const int32_t *cols, const double *vals, int64_t n_boundary_rows,
+                  int n_threads, SellHost &out);
 void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
                  int64_t n_boundary_nodes, int32_t rows_per_lane, int n_threads, SellHost &out);
 

@@ -70,4 +70,47 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
     }
 }
 
+// scalar rows: the same slice layout with 1 value per entry (vals[(slice_ptr[s]+k)*C + lane]); duplicates summed
+void csr_to_sell1(int64_t n, const int64_t *rowptr, const int32_t *cols, const double *vals, int64_t n_boundary_rows,
+                  int n_threads, SellHost &out)
+{
+    (void)n_threads;
+    const int C = 64;
+    out.bs = 1;
+    out.n_nodes = n;
+    out.C = C;
+    out.n_slices = (n + C - 1) / C;
+    out.nnzb = rowptr[n];
+    out.n_bnd_slices = std::min<int64_t>(out.n_slices, (n_boundary_rows + C - 1) / C);
+    out.slice_ptr.assign(out.n_slices + 1, 0);
+    for (int64_t s = 0; s < out.n_slices; ++s) {
+        int64_t w = 0;
+        for (int64_t r = s * C; r < std::min<int64_t>(n, (s + 1) * C); ++r) w = std::max<int64_t>(w, rowptr[r + 1] - rowptr[r]);
+        out.slice_ptr[s + 1] = out.slice_ptr[s] + w;
+    }
+    const int64_t tot = out.slice_ptr[out.n_slices];
+    out.cols.assign((size_t)tot * C, 0);
+    out.vals.assign((size_t)tot * C, 0.0);
+    out.diag.assign((size_t)n, 0.0);
+    for (int64_t s = 0; s < out.n_slices; ++s) {
+        const int64_t base = out.slice_ptr[s], w = out.slice_ptr[s + 1] - base;
+        for (int l = 0; l < C; ++l) {
+            const int64_t r = s * C + l;
+            const bool live = r < n;
+            const int64_t r0 = live ? rowptr[r] : 0, len = live ? rowptr[r + 1] - r0 : 0;
+            for (int64_t k = 0; k < w; ++k) {
+                const size_t i = (size_t)(base + k) * C + l;
+                if (k < len) {
+                    if (cols[r0 + k] < 0 || cols[r0 + k] >= n) throw std::runtime_error("csr: column index out of range");
+                    out.cols[i] = cols[r0 + k];
+                    out.vals[i] = vals[r0 + k];
+                    if (cols[r0 + k] == r) out.diag[r] += vals[r0 + k];
+                } else {
+                    out.cols[i] = live ? (int32_t)r : 0;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace pcg

@@ -105,9 +105,10 @@ class Operator:
         self.last_result = None
 
     @classmethod
-    def from_csr(cls, rowptr, cols, vals, device=0, rows_per_lane=0):
+    def from_csr(cls, rowptr, cols, vals, device=0, block=0):
         """Engine operator from an assembled scalar CSR matrix (e.g. scipy.sparse.csr_matrix: indptr, indices,
-        data) with n = 3*nodes rows (pcg_create_csr).  Single part; every dof owned and free until set_masks()."""
+        data), pcg_create_csr.  block = 0/3: n = 3*nodes rows regrouped into 3x3 node blocks (the fast format);
+        block = 1: scalar rows kept (any n).  Single part; every dof owned and free until set_masks()."""
         self = cls.__new__(cls)
         L = _lib.lib()
         rowptr = np.ascontiguousarray(rowptr, np.int64)
@@ -115,12 +116,12 @@ class Operator:
         vals = _f64(vals)
         n = len(rowptr) - 1
         h = C.c_void_p()
-        check(L.pcg_create_csr(device, n, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data, 0, int(rows_per_lane),
+        check(L.pcg_create_csr(device, n, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data, 0, int(block),
                                C.byref(h)), "pcg_create_csr")
         self._L, self._h, self.kind = L, h, "sell"
         self.n, self.n_nodes, self._map = n, n // 3, None
         info = self.matrix_info()
-        self.nnzb, self.nnz = info["nnzb"], 9 * info["nnzb"]
+        self.nnzb, self.nnz = info["nnzb"], (1 if block == 1 else 9) * info["nnzb"]
         self._comm = self._hooks = None
         self.glob_n_eff = None
         self.last_result = None

@@ -37,7 +37,7 @@ public:
     void d2d(void *d, const void *s, size_t b) override { std::memcpy(d, s, b); }
     void zero(void *d, size_t b) override { std::memset(d, 0, b); }
     void sync() override {}
-    void upload_matrix(const SellHost &m) override { m_ = m; n_ = 3 * m.n_nodes; }
+    void upload_matrix(const SellHost &m) override { m_ = m; n_ = m.bs * m.n_nodes; }
     void upload_ebe(const EbeHost &m) override
     {
         ebe_ = m; n_ = 3 * m.n_nodes;
@@ -128,6 +128,21 @@ public:
     {
         const int C = m_.C;
         double acc = 0;
+        if (m_.bs == 1) {                                               // scalar rows (pcg_create_csr block = 1)
+            for (int64_t s = lo; s < hi; ++s) {
+                const int64_t base = m_.slice_ptr[s], w = m_.slice_ptr[s + 1] - base;
+                for (int l = 0; l < C; ++l) {
+                    const int64_t r = s * C + l;
+                    if (r >= m_.n_nodes) break;
+                    double t = 0;
+                    for (int64_t k = 0; k < w; ++k) t += m_.vals[(size_t)(base + k) * C + l] * x[m_.cols[(size_t)(base + k) * C + l]];
+                    y[r] = t;
+                    if (with_dot && own_free(r)) acc += x[r] * t;
+                }
+            }
+            if (with_dot) dot_spmv_ = acc;
+            return;
+        }
         for (int64_t s = lo; s < hi; ++s) {
             const int64_t base = m_.slice_ptr[s], w = m_.slice_ptr[s + 1] - base;
             for (int l = 0; l < C; ++l) {

@@ -146,3 +146,42 @@ def test_operator_from_scalar_csr(hostops):
     assert np.linalg.norm(r) / np.linalg.norm(P["RefLoadVector"][free]) < 1.01e-7
     with pytest.raises(Exception):
         Operator.from_csr(np.array([0, 1, 2]), np.array([0, 1]), np.array([1.0, 1.0]))     # n not a multiple of 3
+
+
+def test_operator_from_scalar_csr_kept_scalar(hostops):
+    """pcg_create_csr(block = 1): the scalar format is kept (12 B per non-zero), any n - here a system with
+    n % 3 != 0 (a 2-D 5-point Laplacian, ragged rows) and the brick operator, both solved to Tol."""
+    import scipy.sparse as sp
+    from pcg_mi355x.operator import assemble_bsr3, Operator
+    m = 19
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
+    A = (sp.kron(sp.eye(m), T) + sp.kron(T, sp.eye(m))).tocsr()          # n = 361, rows of 3..5 entries
+    assert A.shape[0] % 3 != 0
+    op = Operator.from_csr(A.indptr, A.indices, A.data, block=1)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(A.shape[0])
+    assert relerr(op.apply(x), A @ x) < 1e-14
+    assert relerr(op.diag(), A.diagonal()) < 1e-15
+    inv = op.build_jacobi()
+    b = rng.standard_normal(A.shape[0])
+    xs, res, _ = op.solve(b, None, inv, 1e-9, 5000, A.shape[0])
+    assert res.flag == 0 and np.linalg.norm(b - A @ xs) / np.linalg.norm(b) < 1.01e-9
+    op.close()
+    # the brick operator, scalar vs blocked format: same operator, same iteration path
+    bk = Brick(6, n_types=2)
+    P = make_parts(bk)[0]
+    A3 = bsr(*assemble_bsr3(P["SubDomainData"]["StrucDataList"], bk.n_node), bk.n_node)
+    free = np.zeros(bk.n_dof, bool); free[P["LocDofEff"]] = True
+    out = []
+    for blk in (1, 3):
+        o = Operator.from_csr(A3.indptr, A3.indices, A3.data, block=blk)
+        xb = np.random.default_rng(11).standard_normal(bk.n_dof)
+        assert relerr(o.apply(xb), A3 @ xb) < 1e-13
+        o.set_masks(np.ones(bk.n_dof, bool), free)
+        xs, res, _ = o.solve(P["RefLoadVector"], None, o.build_jacobi(), 1e-7, 5000, int(free.sum()))
+        out.append((xs, res.flag, res.iter))
+        o.close()
+    assert out[0][1] == out[1][1] == 0 and abs(out[0][2] - out[1][2]) <= 1
+    assert relerr(out[0][0], out[1][0]) < 1e-7
+    with pytest.raises(Exception):
+        Operator.from_csr(A.indptr, A.indices, A.data, block=2)

@@ -50,6 +50,45 @@ def test_spmv_kernel_vs_oracle(gpu_lib, oracle_c, rpl, n_types):
     op.close()
 
 
+def test_scalar_csr_format_kernel_and_solve(gpu_lib):
+    """pcg_create_csr(block = 1), the literal CSR data volume: k_spmv_scalar vs the oracle mat-vec (<= 1e-13),
+    the fused dot, a ragged non-3-dof system, and the same iteration path as the blocked format."""
+    import scipy.sparse as sp
+    from pcg_mi355x.operator import assemble_bsr3, Operator
+    from pcg_mi355x._lib import check
+    b = Brick(21, n_types=3)
+    P = make_parts(b)[0]
+    rp, cj, vv = assemble_bsr3(P["SubDomainData"]["StrucDataList"], b.n_node)
+    A = sp.bsr_matrix((vv.reshape(-1, 3, 3), cj, rp), shape=(b.n_dof, b.n_dof)).tocsr()
+    op = Operator.from_csr(A.indptr, A.indices, A.data, block=1)
+    free = np.zeros(b.n_dof, bool); free[P["LocDofEff"]] = True
+    op.set_masks(np.ones(b.n_dof, bool), free)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(b.n_dof)
+    y = np.empty(b.n_dof); pxy = C.c_double()
+    check(op._L.pcg_k_spmv_local(op._h, x.ctypes.data, y.ctypes.data, C.byref(pxy)))
+    ref = pcg_oracle.matvec_local(P, x)
+    assert relerr(y, ref) < 1e-13
+    assert abs(pxy.value - np.dot(x[free], ref[free])) <= 1e-12 * np.dot(np.abs(x), np.abs(ref))
+    xs1, r1, _ = op.solve(P["RefLoadVector"], None, op.build_jacobi(), 1e-7, 5000, int(free.sum()))
+    op.close()
+    op3 = Operator.from_csr(A.indptr, A.indices, A.data, block=3)
+    op3.set_masks(np.ones(b.n_dof, bool), free)
+    xs3, r3, _ = op3.solve(P["RefLoadVector"], None, op3.build_jacobi(), 1e-7, 5000, int(free.sum()))
+    op3.close()
+    assert r1.flag == r3.flag == 0 and abs(r1.iter - r3.iter) <= 1 and relerr(xs1, xs3) < 1e-7
+    m = 37
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
+    L = (sp.kron(sp.eye(m), T) + sp.kron(T, sp.eye(m))).tocsr()           # n = 1369 (n % 3 = 1), rows of 3..5
+    o = Operator.from_csr(L.indptr, L.indices, L.data, block=1)
+    xl = rng.standard_normal(L.shape[0])
+    assert relerr(o.apply(xl), L @ xl) < 1e-14
+    bl = rng.standard_normal(L.shape[0])
+    xs, res, _ = o.solve(bl, None, o.build_jacobi(), 1e-9, 5000, L.shape[0])
+    assert res.flag == 0 and np.linalg.norm(bl - L @ xs) / np.linalg.norm(bl) < 1.01e-9
+    o.close()
+
+
 def test_vector_kernels_vs_numpy(gpu_lib):
     from pcg_mi355x.operator import from_refmeshpart
     from pcg_mi355x._lib import check

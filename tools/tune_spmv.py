@@ -46,9 +46,10 @@ res["setup_s"] = time.time() - t0
 alg = 12.0 * brick.nnz + 20.0 * brick.n_dof
 res["alg_bytes"] = alg
 res["runs"] = []
-for rpl in (1, 2):
-    for dot in (0, 1):
-        for xcd in (1, 0):
+QUICK = os.environ.get("TUNE_QUICK", "0") == "1"          # one blocked configuration (the default) as the in-box yardstick
+for rpl in ((1,) if QUICK else (1, 2)):
+    for dot in ((1,) if QUICK else (0, 1)):
+        for xcd in ((0,) if QUICK else (1, 0)):
             for bpc in (4,):
                 os.environ["PCG_SPMV_BLOCKS_PER_CU"] = str(bpc)
                 os.environ["PCG_SPMV_XCD"] = str(xcd)
@@ -63,4 +64,26 @@ for rpl in (1, 2):
                 res["runs"].append(r)
                 print(r, file=sys.stderr, flush=True)
                 op.close()
+# the literal CSR data volume: scalar rows, 8 B value + 4 B column per non-zero (pcg_create_csr block = 1)
+if os.environ.get("TUNE_SCALAR", "1") == "1":
+    import scipy.sparse as sp
+    t0 = time.time()
+    A = sp.bsr_matrix((v.reshape(-1, 3, 3), c, rp), shape=(brick.n_dof, brick.n_dof)).tocsr()
+    del v, c, rp
+    res["scalar_setup_s"] = time.time() - t0
+    res["scalar_runs"] = []
+    for dot in (0, 1):
+        for bpc in (4, 8):
+            os.environ["PCG_SPMV_BLOCKS_PER_CU"] = str(bpc)
+            os.environ["PCG_BENCH_SPMV_DOT"] = str(dot)
+            op = Operator.from_csr(A.indptr, A.indices, A.data, block=1)
+            info = op.matrix_info()
+            ms = op.bench_spmv(5, 30)
+            impl = info["stored_blocks"] * 12.0 + 16.0 * brick.n_dof      # stored entries x (f64 + i32) + x + y
+            r = {"format": "scalar", "dot": dot, "blocks_per_cu": bpc, "min_ms": float(ms.min()), "med_ms": float(np.median(ms)),
+                 "alg_GBps": alg / (float(np.median(ms)) * 1e-3) / 1e9, "impl_GBps": impl / (float(np.median(ms)) * 1e-3) / 1e9,
+                 "padding": info["stored_blocks"] / info["nnzb"] - 1}
+            res["scalar_runs"].append(r)
+            print(r, file=sys.stderr, flush=True)
+            op.close()
 print(json.dumps(res))
