@@ -122,6 +122,54 @@ class _World:
         self.barrier_obj.wait()
         return out
 
+    # -- what partition_mesh.py / file_operations.py additionally touch, single worker only ------------
+    def Split_type(self, kind):                         # partition_mesh.py:92, file_operations.py:308
+        assert self.n == 1
+        return self
+
+    def Allgather(self, send, recv):                    # partition_mesh.py:681
+        assert self.n == 1
+        recv[...] = np.asarray(send).reshape(recv.shape)
+
+    def bcast(self, value, root=0):                     # partition_mesh.py:1352
+        assert self.n == 1
+        return value
+
+
+class _Win:
+    """MPI.Win.Allocate_shared stand-in: plain process memory (file_operations.py:320-327)."""
+
+    def __init__(self, nbytes, itemsize):
+        self.buf, self.itemsize = bytearray(int(nbytes)), itemsize
+
+    @classmethod
+    def Allocate_shared(cls, nbytes, itemsize, comm=None):
+        return cls(nbytes, itemsize)
+
+    def Shared_query(self, rank):
+        return self.buf, self.itemsize
+
+
+class _File:
+    """MPI.File stand-in (partition_mesh.py:1362-1369): Open / Write / Close on an ordinary file."""
+
+    def __init__(self, name):
+        self.f = open(name, "wb")
+
+    @classmethod
+    def Open(cls, comm, name, amode=0):
+        return cls(name)
+
+    def Write(self, buf):
+        self.f.write(np.asarray(buf).tobytes())
+
+    def Close(self):
+        self.f.close()
+
+
+def _dtype_size(n):
+    return types.SimpleNamespace(Get_size=lambda: n)
+
 
 WORLD = _World()
 _ref = None
@@ -141,6 +189,12 @@ def load_reference():
     MPI.SUM = "SUM"
     MPI.Request = types.SimpleNamespace(Waitall=lambda reqs: None)      # pcg_solver.py:328
     MPI.Comm = _World
+    MPI.COMM_SELF = WORLD
+    MPI.COMM_TYPE_SHARED = 0
+    MPI.LONG, MPI.DOUBLE, MPI.BOOL = _dtype_size(8), _dtype_size(8), _dtype_size(1)     # file_operations.py:311-313
+    MPI.Win = _Win
+    MPI.File = _File
+    MPI.MODE_WRONLY, MPI.MODE_CREATE = 1, 2
     mpi4py.MPI = MPI
     sys.modules["mpi4py"] = mpi4py
     sys.modules["mpi4py.MPI"] = MPI
@@ -153,6 +207,71 @@ def load_reference():
     ref.eps = np.finfo(float).eps                                        # pcg_solver.py:972
     _ref = ref
     return ref
+
+
+_part = None
+
+
+def load_partitioner():
+    """Import the reference's partitioner + METIS front end (src/solver/partition_mesh.py, run_metis.py) with the
+    fake MPI in place; module globals as their `__main__` sets them for ONE worker (partition_mesh.py:1374-1376)."""
+    global _part
+    if _part is not None:
+        return _part
+    load_reference()
+    import src.solver.partition_mesh as pmesh                           # noqa: E402  (the real code)
+    import src.solver.run_metis as rmetis                               # noqa: E402
+    pmesh.Comm = WORLD
+    pmesh.Rank = 0
+    pmesh.N_Workers = 1
+    _part = (pmesh, rmetis)
+    return _part
+
+
+def ref_partition(work_dir, mdf_path, out_prefix, n_parts):
+    """Run the reference's pipeline stage 2+3 unmodified on the model in `mdf_path` (MeshPart_<n>.npy must exist):
+    run_metis.config_GlobData (run_metis.py:19-43), then partition_mesh's `__main__` sequence (:1378-1418) with one
+    worker owning all parts.  Writes <out_prefix><n>_<id>.mpidat + _metadat.npy through exportMP and returns the
+    list of RefMeshPart dicts exactly as exported."""
+    import pickle
+    import zlib
+    pmesh, rmetis = load_partitioner()
+    WORLD.configure(1)
+    mdf_path = os.path.join(mdf_path, "")
+    rmetis.config_GlobData(mdf_path, mdf_path + "MeshData_Glob.zpkl")
+    os.makedirs(os.path.join(work_dir, "__pycache__"), exist_ok=True)
+    os.makedirs(os.path.dirname(out_prefix), exist_ok=True)
+    paths = {"ScratchPath": work_dir, "MDF_Path": mdf_path, "PyDataPath_Part": out_prefix, "ModelName": "synthetic"}
+    with open(os.path.join(work_dir, "__pycache__", "ModelDataPaths.zpkl"), "wb") as f:     # read_input_model.py:44-45
+        f.write(zlib.compress(pickle.dumps(paths, pickle.HIGHEST_PROTOCOL)))
+    cwd, argv = os.getcwd(), sys.argv
+    try:
+        os.chdir(work_dir)
+        sys.argv = ["partition_mesh.py", str(n_parts), "0"]
+        gd = pmesh.initModelData()
+        mpg = {"GlobData": gd, "PotentialNbrDataFlag": False}
+        pmesh.extract_Elepart(mpg)
+        pmesh.extract_PlotSettings(mpg)
+        pmesh.extract_ElemMeshData(mpg)
+        pmesh.config_ElemVectors(mpg)
+        pmesh.extract_NodalVectors(mpg)
+        pmesh.config_TypeGroupList(mpg)
+        pmesh.config_ElemMaterial(mpg)
+        pmesh.config_ElemLib(mpg)
+        pmesh.config_IntfcElem(mpg)
+        pmesh.identify_PotentialNeighbours(mpg)
+        pmesh.config_Neighbours(mpg)
+        pmesh.config_NonlocalNeighbours(mpg)
+        pmesh.exportMP(mpg)
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+    meta = np.load(out_prefix + str(n_parts) + "_metadat.npy", allow_pickle=True).item()
+    parts = []
+    for k in range(n_parts):                                            # pcg_solver.py:100-106
+        buf = np.fromfile(out_prefix + str(n_parts) + "_" + str(k) + ".mpidat", dtype=meta["DTypeData"][k], count=meta["NfData"][k])
+        parts.append(pickle.loads(zlib.decompress(buf.tobytes())))
+    return parts
 
 
 def _run_threads(n, fn):

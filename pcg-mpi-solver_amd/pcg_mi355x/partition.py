@@ -1,0 +1,220 @@
+"""Partition set-up: global MDF model + element -> part vector  ->  one RefMeshPart dict per part.
+
+Restates what src/solver/partition_mesh.py computes for the solver (its `__main__`, :1392-1418), function by
+function, producing the SAME keys with the SAME values (tests/test_partition.py compares against parts written by
+the unmodified reference, tests/golden/part_*.npz):
+
+    extract_Elepart            :76-128    elements of a part = ascending ids with ElePart == part id
+    config_ElemVectors         :208-292   unique node / dof ids of the part, per-element local indices
+    extract_NodalVectors       :296-415   nodal vectors restricted to the part, free / fixed local dofs
+    config_TypeGroupList       :420-491   one group per pattern type, (nd, Ne) element-minor tables
+    config_ElemLib             :538-599   Ke / Me of the type
+    identify_PotentialNeighbours :657-741 } every part that shares a node, ascending part id (the reference's
+    config_Neighbours          :745-887   } bounding-box pre-filter cannot change that set), overlap lists, weights
+
+The reference walks Python lists element by element (its own TODOs: "Perform the element loop in Cython",
+:237,:272,:282); here every step is a whole-array operation (ragged gathers through offset arithmetic,
+sorted-unique + searchsorted), so a 10 M-dof model partitions in seconds, and a rank of a multi-GPU job can
+build ONLY its own part (`only=[rank]`): the other parts enter through one scatter / gather pass over the flat
+element -> node list that finds the interface nodes.  Not built: interface (cohesive) elements (ElemTypeId -2 / -1, :603-653 - no
+such model exists in the reference repository) and the non-local stress neighbourhoods (:1006-1282,
+ExportNonLocalStress = 0 in examples/run_basic_script.bash), both outside the PCG hot path.
+Host-side set-up only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["partition_model", "geometric_partition", "REF_KEY_LIST"]
+
+# exportMP's key list (partition_mesh.py:1310-1317)
+REF_KEY_LIST = ["Id", "SubDomainData", "NDOF", "NNode", "DofVector", "NodeIdVector", "InvDiagM", "NodeWeightVector",
+                "RefLoadVector", "NbrMPIdVector", "ElemIdVector", "OvrlpLocalNodeIdVecList", "OvrlpLocalDofVecList",
+                "RefPlotData", "MPList_RefPlotDofIndicesList", "IntfcLocalNodeIdList", "MPList_IntfcNodeIdVector",
+                "MPList_IntfcNNode", "DofWeightVector", "LocFixedDof", "Flat_ElemLocDof", "NCountDof", "N_NbrDof", "Ud", "Vd",
+                "DofEff", "LocDofEff", "NElem", "MatProp", "NodeCoordVec"]
+
+
+def _ragged_take(flat, off, rows):
+    """Concatenation of flat[off[r,0] : off[r,1]+1] for r in rows, plus the per-row lengths (:238-248)."""
+    lo = off[rows, 0]
+    n = off[rows, 1] - lo + 1
+    end = np.cumsum(n)
+    idx = np.arange(end[-1] if len(end) else 0, dtype=np.int64) + np.repeat(lo - (end - n), n)
+    return flat[idx], n
+
+
+def geometric_partition(model, n_parts, axis=None):
+    """Element -> part id by recursive coordinate bisection of the element centroids (`sctrs`): the stand-in for
+    run_metis.py:88 (mgmetis is not installed here; any ElePart vector is accepted by partition_model)."""
+    c = np.asarray(model["sctrs"], float)
+    part = np.zeros(len(c), np.int64)
+
+    def split(ids, lo, n):
+        if n == 1:
+            part[ids] = lo
+            return
+        ax = int(np.argmax(c[ids].max(0) - c[ids].min(0))) if axis is None else axis
+        order = ids[np.argsort(c[ids, ax], kind="stable")]
+        n_left = n // 2
+        cut = len(order) * n_left // n
+        split(order[:cut], lo, n_left)
+        split(order[cut:], lo + n_left, n - n_left)
+
+    split(np.arange(len(c)), 0, int(n_parts))
+    return part
+
+
+def partition_model(model, ele_part, only=None, glob_data=None):
+    """RefMeshPart dicts (REF_KEY_LIST + 'GlobData') for the part ids in `only` (default: every part)."""
+    ele_part = np.asarray(ele_part).astype(np.int64)
+    E = int(model["GlobNElem"])
+    if ele_part.shape != (E,):
+        raise ValueError(f"ElePart has {ele_part.shape} entries, the model {E} elements")
+    n_total = int(ele_part.max()) + 1
+    only = list(range(n_total)) if only is None else [int(k) for k in only]
+    # the dtypes the reference converts to on load (PyDataTypeList, partition_mesh.py:174,223-225,324-330)
+    model = dict(model)
+    for k in ("NodeGlbOffset", "DofGlbOffset", "SignOffset", "Type", "PolyMat", "StrsGlb", "NodeGlbFlat", "DofGlbFlat", "DofEff",
+              "FixedDof"):
+        model[k] = np.asarray(model[k]).astype(np.int64, copy=False)
+    for k in ("Level", "Ck", "Cm", "Ce", "sctrs", "DiagM", "F", "Ud", "Vd", "NodeCoordVec"):
+        model[k] = np.asarray(model[k]).astype(np.float64, copy=False)
+    node_flat, node_off = model["NodeGlbFlat"], model["NodeGlbOffset"]
+    dof_flat, dof_off = model["DofGlbFlat"], model["DofGlbOffset"]
+    sign_flat, sign_off = model["SignFlat"], model["SignOffset"]
+    coord = model["NodeCoordVec"]
+    n_dof_glob = int(model["GlobNDof"])
+    eff = np.zeros(n_dof_glob, bool)
+    eff[model["DofEff"]] = True
+    fixed = np.zeros(n_dof_glob, bool)
+    fixed[model["FixedDof"]] = True
+
+    gd = {"N_TotalMshPrt": n_total, "N_MPGs": 1, "ExportNonLocalStress": False}          # initModelData :48-53
+    gd.update({k: model[k] for k in ("GlobNElem", "GlobNDof", "GlobNNode", "GlobNDofGlbFlat", "GlobNNodeGlbFlat", "GlobNDofEff",
+                                     "GlobNFacesFlat", "GlobNFaces", "GlobNPolysFlat", "GlobNFixedDof", "dt") if k in model})   # :89
+    gd["qpoint"] = np.zeros((0, 3))                                                        # extract_PlotSettings :137-141
+    gd["RefPlotDofVec"] = np.array([])
+    if glob_data:
+        gd.update(glob_data)
+
+    # element ids of every part (ascending, :120)
+    order = np.argsort(ele_part, kind="stable")
+    counts = np.bincount(ele_part, minlength=n_total)
+    if counts.min() == 0:
+        raise ValueError(f"part {int(np.argmin(counts))} has no elements")
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    elem_ids = lambda pid: order[starts[pid]:starts[pid + 1]]                               # noqa: E731
+
+    # Interface table.  The reference finds neighbours in two steps: bounding boxes widened by Tol = 1e-6 select
+    # candidates (:657-741), then np.intersect1d of the sorted node ids keeps those that share a node (:822-824).
+    # The result is "every part that shares a node, ascending part id" - the box test can never drop such a part -
+    # so it is computed directly, in whole-array passes over the flat element -> node list and without building
+    # any other part's node set: scatter one part id per node, entries that disagree mark the interface nodes,
+    # and the (node, part) pairs of those few nodes are sorted once.
+    if_node = if_part = np.zeros(0, np.int64)
+    if n_total > 1:
+        n_per = node_off[:, 1] - node_off[:, 0] + 1
+        contiguous = E and node_off[0, 0] == 0 and np.all(node_off[1:, 0] == node_off[:-1, 1] + 1) and node_off[-1, 1] + 1 == len(node_flat)
+        flat_nodes = node_flat if contiguous else _ragged_take(node_flat, node_off, np.arange(E))[0]
+        part_of_flat = np.repeat(ele_part.astype(np.int32), n_per)
+        rec = np.full(n_dof_glob // 3 + 1, -1, np.int32)
+        rec[flat_nodes] = part_of_flat
+        on_if = np.zeros(len(rec), bool)
+        on_if[flat_nodes[rec[flat_nodes] != part_of_flat]] = True
+        sel = np.flatnonzero(on_if[flat_nodes])
+        key = np.unique(flat_nodes[sel] * n_total + part_of_flat[sel])
+        if_node, if_part = key // n_total, key % n_total
+        del rec, on_if, sel, key, part_of_flat
+
+    def neighbours(pid):
+        """[(q, ascending shared global node ids)] for ascending q."""
+        mine = if_node[if_part == pid]
+        rows = np.flatnonzero(np.isin(if_node, mine) & (if_part != pid))
+        rows = rows[np.lexsort((if_node[rows], if_part[rows]))]
+        q = if_part[rows]
+        cut = np.flatnonzero(np.diff(q)) + 1
+        return [(int(q[a]), if_node[rows[a:b]]) for a, b in zip(np.concatenate([[0], cut]), np.concatenate([cut, [len(rows)]])) if b > a]
+
+    ref_dir = np.array([[0], [1], [2]], dtype=int)
+    parts = []
+    for pid in only:
+        eids = elem_ids(pid)
+        ne = len(eids)
+        # ---- config_ElemVectors --------------------------------------------------------------------------
+        cum_node, nn_e = _ragged_take(node_flat, node_off, eids)
+        cum_dof, nd_e = _ragged_take(dof_flat, dof_off, eids)
+        cum_sign, ns_e = _ragged_take(sign_flat, sign_off, eids)
+        if not np.array_equal(nd_e, ns_e) or not np.array_equal(nd_e, 3 * nn_e):
+            raise ValueError("inconsistent node / dof / sign ranges")
+        nodes = np.unique(cum_node)                                                        # :252
+        dofs = np.unique(cum_dof)                                                          # :256
+        loc_node = np.searchsorted(nodes, cum_node)                                        # getIndices (:58-67) on sorted unique
+        loc_dof = np.searchsorted(dofs, cum_dof)
+        e_first_n = np.cumsum(nn_e) - nn_e
+        e_first_d = np.cumsum(nd_e) - nd_e
+        n_node, n_dof = len(nodes), len(dofs)
+        # ---- config_TypeGroupList + config_ElemLib -------------------------------------------------------
+        mp_type = model["Type"][eids]
+        groups = []
+        for t in np.unique(mp_type):                                                       # :443
+            I = np.flatnonzero(mp_type == t)
+            nd, nn = int(nd_e[I[0]]), int(nn_e[I[0]])
+            if np.any(nd_e[I] != nd):
+                raise ValueError(f"pattern type {t}: elements with different dof counts")
+            tbl = loc_dof[e_first_d[I][:, None] + np.arange(nd)[None, :]].T               # (nd, Ne) view of (Ne, nd), :452
+            ntb = loc_node[e_first_n[I][:, None] + np.arange(nn)[None, :]].T
+            sgn = cum_sign[e_first_d[I][:, None] + np.arange(nd)[None, :]].astype(bool).T
+            g = {"ElemTypeId": t, "ElemList_LocDofVector": tbl, "ElemList_LocDofVector_Flat": tbl.flatten(),
+                 "ElemList_LocNodeIdVector": ntb, "ElemList_SignVector": sgn,
+                 "ElemList_StrsGlb": (np.asarray(model["StrsGlb"][eids[I]], int) + 6 * np.arange(len(I))[:, None]).T,   # :464-465
+                 "ElemList_StrsSign": np.asarray(model["StrsSign"][eids[I]], bool).T,
+                 "ElemList_Level": model["Level"][eids[I]], "ElemList_Ck": model["Ck"][eids[I]],
+                 "ElemList_Omega": np.zeros(len(I), dtype=float), "ElemList_Cm": model["Cm"][eids[I]],
+                 "ElemList_Ce": model["Ce"][eids[I]], "ElemList_PolyMat": model["PolyMat"][eids[I]],
+                 "ElemList_IntfcElem": [], "ElemList_LocElemId": I, "N_Elem": len(I)}
+            if t in (-2, -1):
+                raise NotImplementedError("interface (cohesive) element groups are not supported")
+            if not 0 <= t < len(model["Ke"]):
+                raise ValueError(f"pattern type {t} not in Ke.mat")
+            ke = np.array(model["Ke"][t], dtype=float)                                     # :576-581
+            if ke.shape != (nd, nd):
+                raise ValueError(f"Ke[{t}] is {ke.shape}, elements of the type have {nd} dofs")
+            g.update({"ElemStiffMat": ke, "ElemDiagStiffMat": np.array(np.diag(ke), dtype=float),
+                      "ElemMassMat": np.array(model["Me"][t], dtype=float), "NNodes": int(len(ke) / 3)})
+            groups.append(g)
+        flat = np.concatenate([g["ElemList_LocDofVector_Flat"] for g in groups]) if groups else np.zeros(0, int)   # :849-860
+        # ---- extract_NodalVectors ------------------------------------------------------------------------
+        loc_eff = np.flatnonzero(eff[dofs])                                                # :350-351
+        part = {
+            "Id": pid, "SubDomainData": {"MixedDataList": {}, "StrucDataList": groups},
+            "NDOF": n_dof, "NNode": n_node, "NElem": ne, "DofVector": dofs, "NodeIdVector": nodes, "ElemIdVector": eids,
+            "InvDiagM": np.array(1.0 / model["DiagM"][dofs], dtype=float), "RefLoadVector": model["F"][dofs],
+            "Ud": model["Ud"][dofs], "Vd": model["Vd"][dofs], "NodeCoordVec": coord[dofs],
+            "DofEff": dofs[loc_eff], "LocDofEff": loc_eff, "LocFixedDof": np.flatnonzero(fixed[dofs]),
+            "RefPlotData": {"TestPlotFlag": False, "J": [], "LocalDofVec": [], "DofVec": np.array([]),
+                            "RefPlotDofVec": gd["RefPlotDofVec"] if pid == 0 else [], "qpoint": gd["qpoint"] if pid == 0 else []},
+            "MPList_RefPlotDofIndicesList": [[] for _ in range(n_total)] if pid == 0 else [],   # :403-411
+            "IntfcLocalNodeIdList": [],                                                    # config_IntfcElem :616-617
+            "MPList_IntfcNodeIdVector": [[] for _ in range(n_total)] if pid == 0 else [],  # :645-650
+            "MPList_IntfcNNode": [0] * n_total if pid == 0 else [],
+            "MatProp": model["MatProp"], "Flat_ElemLocDof": flat, "NCountDof": len(flat), "GlobData": gd,
+        }
+        # ---- identify_PotentialNeighbours + config_Neighbours --------------------------------------------
+        part.update({"NbrMPIdVector": [], "OvrlpLocalNodeIdVecList": [], "OvrlpLocalDofVecList": []})
+        w_dof, w_node = np.ones(n_dof), np.ones(n_node)                                    # :868-869
+        for q, ov in neighbours(pid):                                                      # ascending ids (:722), shared nodes (:822)
+            loc = np.searchsorted(nodes, ov)
+            ldof = (3 * loc + ref_dir).T.ravel()                                           # :826 (assumes dof = 3*node + dir locally)
+            part["OvrlpLocalNodeIdVecList"].append(loc)
+            part["OvrlpLocalDofVecList"].append(ldof)
+            part["NbrMPIdVector"].append(q)
+            if pid > q:                                                                    # :885-887
+                w_dof[ldof] = 0
+                w_node[loc] = 0
+        part["N_NbrDof"] = np.sum([len(v) for v in part["OvrlpLocalDofVecList"]])         # :843
+        part["DofWeightVector"], part["NodeWeightVector"] = w_dof, w_node
+        if n_dof != 3 * n_node:
+            raise ValueError("a node of the part does not carry exactly 3 dofs")
+        parts.append(part)
+    return parts

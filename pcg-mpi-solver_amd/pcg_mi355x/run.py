@@ -9,6 +9,7 @@ replaces `mpiexec -np N python3 src/solver/pcg_solver.py <Run> <SpeedTestFlag>`.
 
     python -m pcg_mi355x.run --partition-prefix <PyDataPath_Part> --n-parts N \\
            --settings __pycache__/GlobSettings.zpkl --results <ScratchPath>/Results_Run1 [--operator ebe]
+    python -m pcg_mi355x.run --mdf <Scratch>/ModelData/MDF/ ...     (no partition files: each rank partitions in memory)
 """
 from __future__ import annotations
 
@@ -81,7 +82,9 @@ def run_load_steps(part, res_vec_path=None, comm=None):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--partition-prefix", required=True, help="PyDataPath_Part: files <prefix><N>_<id>.mpidat")
+    ap.add_argument("--partition-prefix", default=None, help="PyDataPath_Part: files <prefix><N>_<id>.mpidat")
+    ap.add_argument("--mdf", default=None, help="instead of partition files: an MDF directory (with MeshPart_<N>.npy or none "
+                                                "-> coordinate bisection); every rank builds ONLY its own part in memory")
     ap.add_argument("--n-parts", type=int, default=None, help="defaults to WORLD_SIZE")
     ap.add_argument("--settings", default="__pycache__/GlobSettings.zpkl")
     ap.add_argument("--results", required=True, help="result directory (Results_Run<R>)")
@@ -107,7 +110,22 @@ def main(argv=None):
 
     gd = init_glob_data()
     t0 = time.time()
-    part = read_partition(args.partition_prefix, n_parts, rank, gd)   # :980
+    if (args.partition_prefix is None) == (args.mdf is None):
+        raise SystemExit("give exactly one of --partition-prefix / --mdf")
+    if args.mdf is not None:
+        from . import mdf as mdf_mod
+        from .partition import partition_model, geometric_partition
+        model = mdf_mod.read_mdf(args.mdf)
+        try:
+            ele_part = mdf_mod.read_mesh_part(args.mdf, n_parts)
+        except FileNotFoundError:
+            ele_part = geometric_partition(model, n_parts)            # deterministic: every rank computes the same vector
+        part = partition_model(model, ele_part, only=[rank])[0]
+        gd.update(part["GlobData"])                                   # readModelData :107-108
+        part["GlobData"] = gd
+        del model
+    else:
+        part = read_partition(args.partition_prefix, n_parts, rank, gd)   # :980
     apply_settings(gd, importz(args.settings), args.speed_test)       # :981
     gd["MP_TimeRecData"]["dT_FileRead"] += time.time() - t0
     res_vec = os.path.join(args.results, "ResVecData") + os.sep

@@ -37,13 +37,22 @@ def main():
     import pcg_mi355x as pm
     from pcg_mi355x.dist import TorchComm
     import golden_cases
-    brick, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
-    assert len(parts) == world, (len(parts), world)
-    P = parts[rank]
     comm = TorchComm(device=device)
     pm.configure(comm=comm, device=int(os.environ.get("LOCAL_RANK", 0)), operator=opkind)
     out = {"rank": rank}
-    x = golden_cases.probe_for(brick, parts)[P["DofVector"]]
+    if case.startswith("partition:"):           # MDF model -> this rank's part only (pcg_mi355x.partition, only=[rank])
+        import partition_cases as pc
+        from pcg_mi355x.partition import partition_model
+        model, ele_part = pc.build_model(case.split(":", 1)[1])
+        assert int(ele_part.max()) + 1 == world
+        P = pc.prepare_for_solve(partition_model(model, ele_part, only=[rank]))[0]
+        x = np.cos(0.37 * P["DofVector"])
+        out["DofVector"] = P["DofVector"]
+    else:
+        brick, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
+        assert len(parts) == world, (len(parts), world)
+        P = parts[rank]
+        x = golden_cases.probe_for(brick, parts)[P["DofVector"]]
     out["y_probe"] = pm.calc_mpfint(x, P)
     out["diag"] = pm.calc_matvec_prod(P, "Preconditioner")
     pm.update_bc(P)
