@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
 // Scalar-row variant (SellHost::bs == 1): one lane per matrix ROW, one f64 value + one i32 column per stored
 // entry - the literal CSR data volume (12 B per non-zero), in the same slice layout, so a wave's loads of a
 // slice column are one 512 B + one 256 B coalesced line.  Used by pcg_create_csr(block = 1): systems whose
-// rows are not 3-dof node blocks, and the "CSR-format" point of the roofline table.
+// rows are not 3-dof node blocks, and the "CSR-format" point of the measurement table.
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_spmv_scalar(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
                                                         const double *__restrict__ vals, const double *__restrict__ x,
