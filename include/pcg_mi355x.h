@@ -139,10 +139,14 @@ typedef struct {
     double t_total_s, t_comm_s;            /* host wall split (dT_Calc = total - comm), :631-641  */
     double spmv_ms_sum;    /* HIP-event time of the SpMV launches when profiling is on            */
     int64_t spmv_count;
+    int64_t iters_enqueued; /* iterations whose device work was enqueued: iters_done + look-ahead iterations that
+                              were dropped because their predecessor ended the loop or replaced r (:527-549)  */
 } pcg_result;
 
 /* inv_diag may be NULL: use the Jacobi vector built by pcg_build_jacobi().
  * hist (may be NULL): rows [NormP, NormX, NormR] per iteration (the :507 allreduce). */
+/* The loop keeps ONE iteration in flight ahead of the host's tests (see pcg_driver.cpp); results are identical
+ * with it off (environment PCG_LOOK_AHEAD=0 at engine creation). */
 int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const double *inv_diag,
                     double tol, int64_t max_iter, int64_t glob_n_eff);
 int pcg_solve_run(pcg_engine *e, int64_t n_iters /* <0 = to completion */, double *hist, int64_t hist_cap,

@@ -74,11 +74,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* NV * k
 // out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x.
 // One block per value; every thread keeps 4 independent partial sums (loads in flight), then a
 // fixed wave/LDS tree -> deterministic.
-// alpha_mode: out is the status block: st[PQ] = sum, then alpha / stop exactly like k_scalar_alpha (:492-498).
+// alpha_mode: out is the status block: st[PQ] = sum, rho = st[RHO_NEXT], then alpha / stop exactly like k_scalar_alpha (:492-498).
 // mirror (may be null): host-visible copy of the words written, so the host needs no device->host copy.
 __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
                                                    const double *__restrict__ pb, int count_b, double *out,
-                                                   double *mirror, int alpha_mode, double rho)
+                                                   double *mirror, int alpha_mode)
 {
     __shared__ double lds[kWavesPerBlock];
     const int k = blockIdx.x;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa
             out[k] = v[0];
             if (mirror) mirror[k] = v[0];
         } else {
-            const double pq = v[0];
-            double stop = 0.0, alpha = out[ST_ALPHA];
+            const double pq = v[0], rho = out[ST_RHO_NEXT];
+            double stop = out[ST_STOP], alpha = out[ST_ALPHA];   // STOP is sticky: an iteration enqueued behind a broken one stays frozen
             if (pq <= 0.0 || isinf(pq)) stop = 1.0;
             else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
             out[ST_RHO] = rho; out[ST_PQ] = pq; out[ST_ALPHA] = alpha; out[ST_STOP] = stop;
@@ -547,11 +547,11 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
 // ------------------------------------------------------------------------------------------------
 // vector kernels (grid-stride, 16 B per lane, scalar tail)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_scalar_alpha(double *st, double rho, double *mirror)
+__global__ void k_scalar_alpha(double *st, double *mirror)
 {
-    const double pq = st[ST_PQ];
+    const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
     st[ST_RHO] = rho;
-    double stop = 0.0, alpha = st[ST_ALPHA];
+    double stop = st[ST_STOP], alpha = st[ST_ALPHA];
     if (pq <= 0.0 || isinf(pq)) stop = 1.0;                       // :492-494
     else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }      // :495-498
     st[ST_ALPHA] = alpha;
@@ -559,25 +559,36 @@ __global__ void k_scalar_alpha(double *st, double rho, double *mirror)
     if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ p, const double *__restrict__ r,
-                                                     const double *__restrict__ minv, double beta, int first, int64_t n)
+// beta = rho / rho_prev (:475) with rho = st[RHO_NEXT] read on the device: the host need not know rho yet when it
+// enqueues this kernel (look-ahead), and divides the same two doubles later for its own Flag-4 test (:476-478).
+__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, const double *__restrict__ pi,
+                                                     const double *__restrict__ r, const double *__restrict__ minv,
+                                                     const double *__restrict__ st, double rho_prev, int first, int64_t n)
 {
+    const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
     const int64_t n2 = n >> 1;
     const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
+    double2 *po2 = reinterpret_cast<double2 *>(po);
+    const double2 *pi2 = reinterpret_cast<const double2 *>(pi);
     const double2 *r2 = reinterpret_cast<const double2 *>(r), *m2 = reinterpret_cast<const double2 *>(minv);
     for (int64_t t = t0; t < n2; t += ts) {
         const double2 rr = r2[t], mm = m2[t];
         double2 z = make_double2(mm.x * rr.x, mm.y * rr.y);        // :447
-        if (!first) { const double2 pp = p2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
-        p2[t] = z;
+        if (!first) { const double2 pp = pi2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
+        po2[t] = z;
     }
     if ((n & 1) && t0 == 0) {
         const int64_t i = n - 1;
         double z = minv[i] * r[i];
-        if (!first) z = z + beta * p[i];
-        p[i] = z;
+        if (!first) z = z + beta * pi[i];
+        po[i] = z;
     }
+}
+
+// whole status block -> host-visible ring slot (multi-GPU: the all-reduce rewrote the block in place)
+__global__ void k_publish(const double *__restrict__ st, double *__restrict__ mirror)
+{
+    if (threadIdx.x < ST_COUNT) mirror[threadIdx.x] = st[threadIdx.x];
 }
 
 struct Up { double sqp, sqx, sqr, rho, ninf; };
@@ -596,8 +607,9 @@ __device__ __forceinline__ void update_one(double alpha, double p, double q, dou
 }
 
 __global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restrict__ st, const double *__restrict__ p,
-                                                         const double *__restrict__ q, double *__restrict__ r,
-                                                         const double *__restrict__ xo, double *__restrict__ xn,
+                                                         const double *__restrict__ q, const double *__restrict__ r,
+                                                         double *__restrict__ rn, const double *__restrict__ xo,
+                                                         double *__restrict__ xn,
                                                          const double *__restrict__ minv, const uint8_t *__restrict__ flags,
                                                          double *__restrict__ partials, int64_t n)
 {
@@ -609,7 +621,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restric
         const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
         const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
         const double2 *x2 = reinterpret_cast<const double2 *>(xo), *m2 = reinterpret_cast<const double2 *>(minv);
-        double2 *r2 = reinterpret_cast<double2 *>(r), *xn2 = reinterpret_cast<double2 *>(xn);
+        const double2 *r2 = reinterpret_cast<const double2 *>(r);
+        double2 *rn2 = reinterpret_cast<double2 *>(rn), *xn2 = reinterpret_cast<double2 *>(xn);
         const uchar2 *f2 = reinterpret_cast<const uchar2 *>(flags);
         for (int64_t t = t0; t < n2; t += ts) {
             const double2 pp = p2[t], qq = q2[t], xx = x2[t], mm = m2[t];
@@ -617,14 +630,14 @@ __global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restric
             const uchar2 ff = f2[t];
             update_one(alpha, pp.x, qq.x, rr.x, xx.x, xo2.x, mm.x, ff.x, u);
             update_one(alpha, pp.y, qq.y, rr.y, xx.y, xo2.y, mm.y, ff.y, u);
-            r2[t] = rr;
+            rn2[t] = rr;
             xn2[t] = xo2;
         }
         if ((n & 1) && t0 == 0) {
             const int64_t i = n - 1;
             double rr = r[i], xnew;
             update_one(alpha, p[i], q[i], rr, xo[i], xnew, minv[i], flags[i], u);
-            r[i] = rr;
+            rn[i] = rr;
             xn[i] = xnew;
         }
     }
@@ -810,7 +823,10 @@ public:
                 if (p) (void)hipFree(p);
         for (auto e : ev0_) (void)hipEventDestroy(e);
         for (auto e : ev1_) (void)hipEventDestroy(e);
-        if (h_mirror_) (void)hipHostFree(h_mirror_);
+        if (h_mirror_) {
+            (void)hipHostFree(h_mirror_);
+            for (auto e : ev_slot_) (void)hipEventDestroy(e);
+        }
         if (st_) (void)hipStreamDestroy(st_);
     }
     const char *name() const override { return "hip-gfx950"; }
@@ -1054,65 +1070,90 @@ public:
     {
         if (ebe_)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, red,
-                               mirror_of(red), 0, 0.0);
+                               mirror_of(red), 0);
         else
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                               cnt_fix_, red, mirror_of(red), 0, 0.0);
+                               cnt_fix_, red, mirror_of(red), 0);
         HIP_CHECK(hipGetLastError());
     }
-    void reduce_dot_alpha(double *st, double rho) override
+    void reduce_dot_alpha(double *st) override
     {
         if (ebe_)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, st,
-                               mirror_of(st), 1, rho);
+                               mirror_of(st), 1);
         else
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                               cnt_fix_, st, mirror_of(st), 1, rho);
+                               cnt_fix_, st, mirror_of(st), 1);
         HIP_CHECK(hipGetLastError());
     }
-    // ---- status block mirror in host-visible (pinned, mapped) memory -------------------------------
+    // ---- status ring in host-visible (pinned, mapped) memory: kStatusSlots copies of the status block ------------
+    // The reduce / alpha kernels mirror every status word they write into the CURRENT slot, so the host reads an
+    // iteration's sums without a device->host copy; one event per slot lets it wait for exactly that iteration
+    // while the next one is already queued behind it.
     double *d_st_base_ = nullptr, *h_mirror_ = nullptr, *d_mirror_ = nullptr;
+    int cur_slot_ = 0;
+    hipEvent_t ev_slot_[kStatusSlots] = {};
     double *mirror_of(double *p) const
     {
-        return (d_mirror_ && p >= d_st_base_ && p < d_st_base_ + ST_COUNT) ? d_mirror_ + (p - d_st_base_) : nullptr;
+        return (d_mirror_ && p >= d_st_base_ && p < d_st_base_ + ST_COUNT) ? d_mirror_ + (size_t)cur_slot_ * ST_COUNT + (p - d_st_base_)
+                                                                            : nullptr;
     }
     void set_status_block(double *st) override
     {
         d_st_base_ = st;
         if (!h_mirror_) {
-            HIP_CHECK(hipHostMalloc((void **)&h_mirror_, sizeof(double) * ST_COUNT, hipHostMallocMapped));
-            for (int k = 0; k < ST_COUNT; ++k) h_mirror_[k] = 0.0;
+            HIP_CHECK(hipHostMalloc((void **)&h_mirror_, sizeof(double) * ST_COUNT * kStatusSlots, hipHostMallocMapped));
+            for (int k = 0; k < ST_COUNT * kStatusSlots; ++k) h_mirror_[k] = 0.0;
             HIP_CHECK(hipHostGetDevicePointer((void **)&d_mirror_, h_mirror_, 0));
+            for (auto &ev : ev_slot_) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
     }
     bool read_status(double *host_out) override
     {
         if (!h_mirror_) return false;
         HIP_CHECK(hipStreamSynchronize(st_));
-        for (int k = 0; k < ST_COUNT; ++k) host_out[k] = ((volatile double *)h_mirror_)[k];
+        const volatile double *m = h_mirror_ + (size_t)cur_slot_ * ST_COUNT;
+        for (int k = 0; k < ST_COUNT; ++k) host_out[k] = m[k];
         return true;
     }
-    void scalar_alpha(double *st, double rho) override
+    void set_status_slot(int slot) override { cur_slot_ = slot; }
+    void publish_status(bool copy_block) override
     {
-        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, rho, mirror_of(st));
+        if (copy_block) {
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st_, d_st_base_, d_mirror_ + (size_t)cur_slot_ * ST_COUNT);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipEventRecord(ev_slot_[cur_slot_], st_));
+    }
+    void wait_status(int slot, double *host_out) override
+    {
+        HIP_CHECK(hipEventSynchronize(ev_slot_[slot]));
+        const volatile double *m = h_mirror_ + (size_t)slot * ST_COUNT;
+        for (int k = 0; k < ST_COUNT; ++k) host_out[k] = m[k];
+    }
+    void scalar_alpha(double *st) override
+    {
+        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, mirror_of(st));
         HIP_CHECK(hipGetLastError());
     }
-    void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
+    void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
+                  bool first) override
     {
-        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, p, r, minv, beta, first ? 1 : 0, n_);
+        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, n_);
         HIP_CHECK(hipGetLastError());
     }
-    void fused_update(const double *st, const double *p, const double *q, double *r, const double *xo, double *xn,
-                      const double *minv) override
+    void fused_update(const double *st, const double *p, const double *q, const double *r, double *rn, const double *xo,
+                      double *xn, const double *minv) override
     {
         cnt_vec_ = vec_grid(n_);
-        hipLaunchKernelGGL(k_fused_update, dim3(cnt_vec_), dim3(kBlock), 0, st_, st, p, q, r, xo, xn, minv, d_flags_, d_part_, n_);
+        hipLaunchKernelGGL(k_fused_update, dim3(cnt_vec_), dim3(kBlock), 0, st_, st, p, q, r, rn, xo, xn, minv, d_flags_, d_part_,
+                           n_);
         HIP_CHECK(hipGetLastError());
     }
     void reduce_update(double *red5) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(5), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5,
-                           mirror_of(red5), 0, 0.0);
+                           mirror_of(red5), 0);
         HIP_CHECK(hipGetLastError());
     }
     void residual(const double *b, const double *ax, double *r, const double *minv) override
@@ -1124,7 +1165,7 @@ public:
     void reduce_residual(double *red3) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(3), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3,
-                           mirror_of(red3), 0, 0.0);
+                           mirror_of(red3), 0);
         HIP_CHECK(hipGetLastError());
     }
     void dot_w(const double *a, const double *b) override
@@ -1136,7 +1177,7 @@ public:
     void reduce_dotw(double *red1) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1,
-                           mirror_of(red1), 0, 0.0);
+                           mirror_of(red1), 0);
         HIP_CHECK(hipGetLastError());
     }
     void copy_diag(double *d) override { d2d(d, d_diag_, sizeof(double) * (size_t)n_); }

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -51,10 +52,15 @@ struct pcg_engine {
     bool has_hooks = false;
     bool jacobi_built = false;
     bool profiling = false;
+    bool look_ahead = !(std::getenv("PCG_LOOK_AHEAD") && std::getenv("PCG_LOOK_AHEAD")[0] == '0');   // A/B switch
 
     double *d_send = nullptr, *d_recv = nullptr, *d_st = nullptr;
-    double *v_b = nullptr, *v_r = nullptr, *v_p = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
-    double *v_x[3] = {nullptr, nullptr, nullptr};
+    double *v_b = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
+    // Every vector an iteration UPDATES is written to a different buffer than it is read from (r, p: ping-pong;
+    // x: 4 rotating buffers, one of them protects XMin :555-558), so an iteration enqueued ahead of the host's
+    // decision on its predecessor can simply be dropped: nothing it read was overwritten.
+    double *v_r[2] = {nullptr, nullptr}, *v_p[2] = {nullptr, nullptr};
+    double *v_x[4] = {nullptr, nullptr, nullptr, nullptr};
     double *scr[4] = {nullptr, nullptr, nullptr, nullptr};
     double h_st[ST_COUNT];
 
@@ -75,6 +81,10 @@ struct pcg_engine {
         double normr_min = 0, normr_act = 0, relres = 0;
         int cur = 0, min_idx = 0;
         bool min_live = true;
+        int rcur = 0, pcur = 0;   // buffers holding the current residual / the last search direction
+        bool ahead = false;       // iteration `i` is already enqueued (look-ahead from the previous pass)
+        int ahead_nx = -1;        // ... writing its new x into this buffer
+        int64_t n_enqueued = 0;   // iterations whose device work was enqueued (those not consumed were look-aheads dropped)
         const double *minv = nullptr;
         double t_total = 0.0, t_comm0 = 0.0;
     } s;
@@ -82,8 +92,8 @@ struct pcg_engine {
     ~pcg_engine()
     {
         if (!be) return;
-        for (double *p : {d_send, d_recv, d_st, v_b, v_r, v_p, v_q, v_minv, v_minv_user, v_x[0], v_x[1], v_x[2],
-                          scr[0], scr[1], scr[2], scr[3]})
+        for (double *p : {d_send, d_recv, d_st, v_b, v_r[0], v_r[1], v_p[0], v_p[1], v_q, v_minv, v_minv_user, v_x[0], v_x[1],
+                          v_x[2], v_x[3], scr[0], scr[1], scr[2], scr[3]})
             if (p) be->release(p);
     }
 
@@ -175,17 +185,39 @@ struct pcg_engine {
     {
         apply(x, v_q, false);
         s.n_matvec++;
-        be->residual(v_b, v_q, v_r, s.minv);
+        be->residual(v_b, v_q, v_r[s.rcur], s.minv);
         be->reduce_residual(d_st + ST_SQR);
         allreduce(d_st + ST_SQR, 3);
         read_status();
     }
 
-    int pick_new_x() const
+    int pick_new_x(int also_not = -1) const
     {
-        for (int k = 0; k < 3; ++k)
-            if (k != s.cur && (s.min_live || k != s.min_idx)) return k;
+        for (int k = 0; k < 4; ++k)
+            if (k != s.cur && k != also_not && (s.min_live || k != s.min_idx)) return k;
         return -1;
+    }
+
+    // The device work of one iteration (:447-516 without the host's tests): p, q = A p, alpha, the fused update and
+    // its five sums, published in status slot `slot`.  rho of the iteration is st[RHO_NEXT] on the device.
+    void enqueue_iteration(bool first, double rho_prev, const double *p_in, double *p_out, const double *r_in, double *r_out,
+                           const double *x_in, double *x_out, int slot)
+    {
+        s.n_enqueued++;
+        be->set_status_slot(slot);
+        be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first);     // :447, :472-479
+        apply(p_out, v_q, true);                                            // :482-484
+        if (!has_hooks && !(kind == 1 && !ebe_dot_fused)) {
+            be->reduce_dot_alpha(d_st);                                     // :487-498, one launch (no all-reduce in between)
+        } else {
+            reduce_apply_dot(d_st + ST_PQ);                                 // :487
+            allreduce(d_st + ST_PQ, 1);                                     // :488
+            be->scalar_alpha(d_st);                                         // :492-498 (device side)
+        }
+        be->fused_update(d_st, p_out, v_q, r_in, r_out, x_in, x_out, s.minv);   // :501-516 (+ :447-462 of i+1)
+        be->reduce_update(d_st + ST_SQP);
+        allreduce(d_st + ST_SQP, 5);                                        // :507 (+ next rho, inf count)
+        be->publish_status(has_hooks);
     }
 };
 
@@ -194,16 +226,27 @@ namespace {
 void ensure_solver_buffers(pcg_engine *e)
 {
     if (e->v_b) return;
-    e->v_b = e->vec(); e->v_r = e->vec(); e->v_p = e->vec(); e->v_q = e->vec();
-    for (int k = 0; k < 3; ++k) e->v_x[k] = e->vec();
+    e->v_b = e->vec(); e->v_q = e->vec();
+    for (int k = 0; k < 2; ++k) { e->v_r[k] = e->vec(); e->v_p[k] = e->vec(); }
+    for (int k = 0; k < 4; ++k) e->v_x[k] = e->vec();
 }
 
 // One pass of the reference's `for i in range(MaxIter)` body (:438-562).  Returns true when the
 // loop is finished (break or exhausted).
-bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
+//
+// Look-ahead: the host's part of an iteration (the tests of :447-479 before, :492-562 after the device work) needs
+// the five sums of the iteration, i.e. one device -> host round trip per iteration.  To keep the GPU busy during
+// that round trip (and during the Python communication hooks of a multi-GPU run), iteration i+1 is enqueued
+// BEFORE the host waits for the sums of iteration i, assuming i ends the ordinary way.  When it does not (any
+// break, or the true-residual branch :527-549 which replaces r), the look-ahead iteration is dropped - it wrote
+// only into buffers nobody reads (see pcg_engine) - and, if the loop goes on, enqueued again from the new state.
+// Every value the host tests is the value the reference tests; the arithmetic on the device is unchanged.
+bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_ahead)
 {
     auto &s = e->s;
-    Backend &be = *e->be;
+    const bool in_flight = s.ahead;
+    const int flight_nx = s.ahead_nx;
+    s.ahead = false;
     if (s.i >= s.max_iter) return true;                       // loop exhausted, Flag stays 1
     const int64_t i = s.i;
     s.last_i = i;
@@ -211,26 +254,27 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
     const double rho_1 = s.rho;                                // :461
     s.rho = s.rho_next;                                        // :462-463 (computed with the residual)
     if (s.rho == 0 || std::isinf(s.rho)) { s.flag = 4; return true; }     // :467-469
-    double beta = 0.0;
     if (i > 0) {                                               // :472-479
-        beta = s.rho / rho_1;
+        const double beta = s.rho / rho_1;
         if (beta == 0 || std::isinf(beta)) { s.flag = 4; return true; }
     }
-    be.update_p(e->v_p, e->v_r, s.minv, beta, i == 0);
-    e->apply(e->v_p, e->v_q, true);                            // :482-484
+    const int slot = (int)(i % kStatusSlots);
+    const int nx = in_flight ? flight_nx : e->pick_new_x();
+    double *r_in = e->v_r[s.rcur], *r_out = e->v_r[s.rcur ^ 1];
+    double *p_in = e->v_p[s.pcur], *p_out = e->v_p[s.pcur ^ 1];
+    if (!in_flight)                                            // else: the look-ahead of the previous pass IS iteration i
+        e->enqueue_iteration(i == 0, rho_1, p_in, p_out, r_in, r_out, e->v_x[s.cur], e->v_x[nx], slot);
     s.n_matvec++;
-    if (!e->has_hooks && !(e->kind == 1 && !e->ebe_dot_fused)) {
-        be.reduce_dot_alpha(e->d_st, s.rho);                   // :487-498, one launch (no all-reduce in between)
-    } else {
-        e->reduce_apply_dot(e->d_st + ST_PQ);                  // :487
-        e->allreduce(e->d_st + ST_PQ, 1);                      // :488
-        be.scalar_alpha(e->d_st, s.rho);                       // :492-498 (device side)
+    // ---- look ahead: iteration i+1 from the state iteration i leaves when it ends the ordinary way --------------
+    if (may_look_ahead && s.more == 0 && i + 1 < s.max_iter) {
+        const int nx2 = e->pick_new_x(nx);                     // not x_i (a frozen iteration i keeps it), not x_{i+1}, not XMin
+        if (nx2 >= 0) {
+            e->enqueue_iteration(false, s.rho, p_out, p_in, r_out, r_in, e->v_x[nx], e->v_x[nx2], (int)((i + 1) % kStatusSlots));
+            s.ahead = true;
+            s.ahead_nx = nx2;
+        }
     }
-    const int nx = e->pick_new_x();
-    be.fused_update(e->d_st, e->v_p, e->v_q, e->v_r, e->v_x[s.cur], e->v_x[nx], s.minv);   // :501-516 (+ :447-462 of i+1)
-    be.reduce_update(e->d_st + ST_SQP);
-    e->allreduce(e->d_st + ST_SQP, 5);                         // :507 (+ next rho, inf count)
-    e->read_status();
+    e->be->wait_status(slot, e->h_st);
     const double *st = e->h_st;
     if (st[ST_STOP] != 0) { s.flag = 4; return true; }         // pq<=0 / inf / alpha inf: nothing was updated
     const double alpha = st[ST_ALPHA];
@@ -242,9 +286,12 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap)
     if (normp * std::fabs(alpha) < kEps * normx) s.stag += 1;  // :512-513
     else s.stag = 0;
     s.cur = nx;                                                // :516
+    s.rcur ^= 1;
+    s.pcur ^= 1;
     s.normr_act = normr;                                       // :518
     s.i = i + 1;
     if (normr <= s.tolb || s.stag >= 3 || s.more > 0) {        // :527
+        s.ahead = false;                                       // r is about to be replaced: the look-ahead is void
         e->true_residual(e->v_x[s.cur]);                       // :528-533 (R is REPLACED, :531)
         s.normr_act = std::sqrt(e->h_st[ST_SQR]);
         s.rho_next = e->h_st[ST_RHO_NEXT];
@@ -293,6 +340,7 @@ void fill_result(pcg_engine *e, pcg_result *res)
     if (e->profiling) e->be->collect_profile(&ms, &cnt);
     res->spmv_ms_sum = ms;
     res->spmv_count = cnt;
+    res->iters_enqueued = s.n_enqueued;
 }
 
 template <class F>
@@ -585,6 +633,8 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         auto &s = e->s;
         s = pcg_engine::Solve();
         s.active = true;
+        be.set_status_slot(0);
+        be.zero(e->d_st, sizeof(double) * ST_COUNT);                        // STOP is sticky within a solve
         s.t_comm0 = e->t_comm;
         s.tol = tol;
         s.max_iter = max_iter;
@@ -639,9 +689,11 @@ int pcg_solve_run(pcg_engine *e, int64_t n_iters, double *hist, int64_t hist_cap
         auto &s = e->s;
         int64_t k = 0;
         while (!s.done && (n_iters < 0 || k < n_iters)) {
-            if (iterate_once(e, hist, hist_cap)) s.done = true;
+            // no look-ahead out of the last pass of this call: a run of K passes enqueues exactly K iterations
+            if (iterate_once(e, hist, hist_cap, e->look_ahead && (n_iters < 0 || k + 1 < n_iters))) s.done = true;
             ++k;
         }
+        if (s.done) s.ahead = false;
         e->be->sync();
         s.t_total += now_s() - t0;
         fill_result(e, res);
@@ -734,9 +786,13 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
     return guarded("pcg_k_update_p", [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
+        double *dpo = e->scratch(3);
         e->be->h2d(dp, p, bytes); e->be->h2d(dr, r, bytes); e->be->h2d(dm, inv_diag, bytes);
-        e->be->update_p(dp, dr, dm, beta, first != 0);
-        e->be->d2h(p, dp, bytes);
+        double st[ST_COUNT] = {0};
+        st[ST_RHO_NEXT] = beta;                               // beta = st[RHO_NEXT] / rho_prev with rho_prev = 1: exact
+        e->be->h2d(e->d_st, st, sizeof(st));
+        e->be->update_p(dpo, dp, dr, dm, e->d_st, 1.0, first != 0);
+        e->be->d2h(p, dpo, bytes);
         return 0;
     });
 }
@@ -748,17 +804,17 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         const size_t bytes = sizeof(double) * (size_t)e->n;
         ensure_solver_buffers(e);
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
-        double *dxo = e->v_x[0], *dxn = e->v_x[1];
+        double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2];
         e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
         e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         e->be->h2d(e->d_st, st, sizeof(st));
-        e->be->fused_update(e->d_st, dp, dq, dr, dxo, dxn, dm);
+        e->be->fused_update(e->d_st, dp, dq, dr, drn, dxo, dxn, dm);
         e->be->reduce_update(e->d_st + ST_SQP);
         e->read_status();
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->d2h(r, dr, bytes);
+        e->be->d2h(r, drn, bytes);
         e->be->d2h(x_new, dxn, bytes);
         return 0;
     });

@@ -113,6 +113,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups, 
 // All `double*` below are buffers obtained from alloc() ("device" pointers).
 enum { ST_RHO = 0, ST_PQ = 1, ST_ALPHA = 2, ST_STOP = 3, ST_SQP = 4, ST_SQX = 5, ST_SQR = 6,
        ST_RHO_NEXT = 7, ST_NINF = 8, ST_COUNT = 16 };
+constexpr int kStatusSlots = 4;          // status ring of the solve loop's look-ahead (2 would do; 4 keeps slots apart)
 
 struct HaloHost {
     int32_t n_peers = 0;
@@ -159,21 +160,31 @@ public:
     virtual void begin_dot() = 0;
     // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
     virtual void reduce_dot(double *red) = 0;
+    // rho = st[RHO_NEXT] (left there by the previous update / residual reduction, device side) ;
     // st[RHO] = rho ; st[ALPHA] = rho / st[PQ] ; st[STOP] per pcg_solver.py:492-498
-    virtual void scalar_alpha(double *st, double rho) = 0;
-    // single part (no all-reduce between the two): reduce_dot(st + ST_PQ) and scalar_alpha(st, rho) in one launch
-    virtual void reduce_dot_alpha(double *st, double rho) = 0;
+    virtual void scalar_alpha(double *st) = 0;
+    // single part (no all-reduce between the two): reduce_dot(st + ST_PQ) and scalar_alpha(st) in one launch
+    virtual void reduce_dot_alpha(double *st) = 0;
     // Status block: `st` is the device block the reduce/scalar kernels write into.  A back end may mirror
     // those writes into host-visible memory so that read_status() is a stream sync instead of a copy;
     // it returns false when it has no mirror (the caller then copies).
     virtual void set_status_block(double *st) = 0;
     virtual bool read_status(double *host_out) = 0;
-    // p = first ? M^-1 r : M^-1 r + beta p                                (:447,:472-479)
-    virtual void update_p(double *p, const double *r, const double *minv, double beta, bool first) = 0;
-    // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r -= alpha q ; sum r^2 w ; x_new = x_old + alpha p ;
+    // Status ring for the one-iteration look-ahead of the solve loop: the words an iteration writes go to ring slot
+    // `slot` (set before the iteration is enqueued); publish_status() closes the iteration (copy_block: the device
+    // block was rewritten in place by an all-reduce after the kernels mirrored it, copy it whole) and marks the point
+    // the host may wait for; wait_status() blocks until THAT iteration is done - later work may already be queued.
+    virtual void set_status_slot(int slot) = 0;
+    virtual void publish_status(bool copy_block) = 0;
+    virtual void wait_status(int slot, double *host_out) = 0;
+    // p_out = first ? M^-1 r : M^-1 r + beta p_in , beta = st[RHO_NEXT] / rho_prev (device-side division of the same
+    // two doubles the host divides for its Flag-4 test)                     (:447,:472-479)
+    virtual void update_p(double *p_out, const double *p_in, const double *r, const double *minv, const double *st,
+                          double rho_prev, bool first) = 0;
+    // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r_new = r_old - alpha q ; sum r^2 w ; x_new = x_old + alpha p ;
     // z = M^-1 r ; sum z r w ; count of inf in z.  Partials -> reduce_update().   (:501-516,:447-462)
-    virtual void fused_update(const double *st, const double *p, const double *q, double *r, const double *x_old,
-                              double *x_new, const double *minv) = 0;
+    virtual void fused_update(const double *st, const double *p, const double *q, const double *r_old, double *r_new,
+                              const double *x_old, double *x_new, const double *minv) = 0;
     virtual void reduce_update(double *red5) = 0;
     // r = b - ax ; sums r^2 w, (M^-1 r) r w, inf count                      (:413-416,:530-533)
     virtual void residual(const double *b, const double *ax, double *r, const double *minv) = 0;

@@ -110,6 +110,7 @@ class SolveInfo:
         self.t_comm_s = float(res.t_comm_s)
         self.spmv_ms_sum = float(res.spmv_ms_sum)
         self.spmv_count = int(res.spmv_count)
+        self.iters_enqueued = int(res.iters_enqueued)
         self.history = hist
 
     def __repr__(self):

@@ -68,6 +68,7 @@ def main():
     out["Un"] = P["Un"]
     out["history"] = info.history
     out["flag"], out["iter"], out["relres"] = info.flag, info.iter, info.relres
+    out["iters_done"], out["iters_enqueued"] = info.iters_done, info.iters_enqueued
     gd = P["GlobData"]
     out["tl_flag"], out["tl_iter"], out["tl_relres"] = gd["TimeList_Flag"][1], gd["TimeList_Iter"][1], gd["TimeList_RelRes"][1]
     out["n_allreduce"], out["n_halo"] = comm.n_allreduce, comm.n_halo

@@ -185,27 +185,36 @@ public:
     }
     void begin_dot() override { dot_spmv_ = dot_fix_ = 0; }
     void reduce_dot(double *red) override { red[0] = dot_spmv_ + dot_fix_; }
-    void scalar_alpha(double *st, double rho) override
+    void scalar_alpha(double *st) override
     {
-        const double pq = st[ST_PQ];
+        const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
         st[ST_RHO] = rho;
-        st[ST_STOP] = 0;
-        if (pq <= 0 || std::isinf(pq)) { st[ST_STOP] = 1; return; }
+        if (pq <= 0 || std::isinf(pq)) { st[ST_STOP] = 1; return; }     // STOP is sticky (never cleared here)
         st[ST_ALPHA] = rho / pq;
         if (std::isinf(st[ST_ALPHA])) st[ST_STOP] = 1;
     }
-    void reduce_dot_alpha(double *st, double rho) override { reduce_dot(st + ST_PQ); scalar_alpha(st, rho); }
-    void set_status_block(double *) override {}
+    void reduce_dot_alpha(double *st) override { reduce_dot(st + ST_PQ); scalar_alpha(st); }
+    // status ring: every "kernel" here runs at once, so a look-ahead iteration has ALREADY overwritten the block
+    // when the host asks for its predecessor's sums - the most adversarial order a GPU could produce
+    void set_status_block(double *st) override { st_ = st; }
     bool read_status(double *) override { return false; }
-    void update_p(double *p, const double *r, const double *minv, double beta, bool first) override
+    void set_status_slot(int slot) override { slot_ = slot; }
+    void publish_status(bool) override { std::memcpy(ring_[slot_], st_, sizeof(double) * ST_COUNT); }
+    void wait_status(int slot, double *out) override { std::memcpy(out, ring_[slot], sizeof(double) * ST_COUNT); }
+    double *st_ = nullptr;
+    int slot_ = 0;
+    double ring_[kStatusSlots][ST_COUNT] = {};
+    void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
+                  bool first) override
     {
+        const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
         for (int64_t i = 0; i < n_; ++i) {
             const double z = minv[i] * r[i];
-            p[i] = first ? z : z + beta * p[i];
+            po[i] = first ? z : z + beta * pi[i];
         }
     }
-    void fused_update(const double *st, const double *p, const double *q, double *r, const double *xo, double *xn,
-                      const double *minv) override
+    void fused_update(const double *st, const double *p, const double *q, const double *r, double *rnew, const double *xo,
+                      double *xn, const double *minv) override
     {
         for (double &v : up_) v = 0;
         if (st[ST_STOP] != 0) return;
@@ -214,7 +223,7 @@ public:
             const bool w = own_free(i);
             if (w) { up_[0] += p[i] * p[i]; up_[1] += xo[i] * xo[i]; }
             const double rn = r[i] - alpha * q[i];
-            r[i] = rn;
+            rnew[i] = rn;
             xn[i] = xo[i] + alpha * p[i];
             const double z = minv[i] * rn;
             if (is_free(i) && std::isinf(z)) up_[4] += 1;

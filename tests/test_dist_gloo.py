@@ -48,8 +48,11 @@ def test_multi_rank_solve_matches_reference(tmp_path, case, nproc, port):
     dof, u = read_result_vector(res + "Dof"), read_result_vector(res + "U_0")
     assert len(dof) == len(U) and len(np.unique(dof)) == len(dof)        # each global dof exactly once (ownership mask)
     assert relerr(u, g["Un"][dof]) < tol_u
-    # two all-reduces per iteration instead of the reference's three (merged, same arithmetic)
-    assert int(o0["n_allreduce"]) <= int(g["n_allreduce"])
+    # two all-reduces per iteration instead of the reference's three (merged, same arithmetic); a look-ahead
+    # iteration that was dropped (at most one per break / entry into the true-residual branch) adds its two
+    dropped = int(o0["iters_enqueued"]) - int(o0["iters_done"])
+    assert 0 <= dropped <= 2
+    assert int(o0["n_allreduce"]) <= int(g["n_allreduce"]) + 2 * dropped
     assert float(o0["t_comm"]) > 0
 
 

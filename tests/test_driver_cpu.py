@@ -64,6 +64,52 @@ def test_functional_api_and_resume(hostops):
     assert np.array_equal(x1, x2)
 
 
+def _solve_both_ways(monkeypatch, case, kind="sell"):
+    """The same load step with the one-iteration look-ahead of the solve loop on and off."""
+    from pcg_mi355x.operator import from_refmeshpart
+    out = []
+    for la in ("1", "0"):
+        monkeypatch.setenv("PCG_LOOK_AHEAD", la)                  # read when the engine is created
+        _, parts = golden_cases.build_case(case)
+        P = parts[0]
+        op = from_refmeshpart(P, kind=kind)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"],
+                                P["GlobData"]["GlobNDofEff"], history=True)
+        out.append((x, res.flag, res.iter, res.relres, res.iters_done, res.iters_enqueued, res.n_matvec, hist))
+        op.close()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("case", ["n9_p1", "n9_maxiter", "n9_stagnate", "n9_flag4", "n9_flag2", "oct_p1"])
+def test_look_ahead_changes_nothing(hostops, monkeypatch, case, kind):
+    """Iteration i+1 is enqueued before the host has seen the sums of iteration i; every exit path (converged,
+    MaxIter, stagnation, breakdown, inf) must give bit-identical results with the look-ahead on and off."""
+    on, off = _solve_both_ways(monkeypatch, case, kind)
+    assert np.array_equal(on[0], off[0])
+    assert on[1:5] == off[1:5] and on[6] == off[6]
+    assert np.array_equal(on[7], off[7])
+    assert 0 <= off[5] - off[4] <= 1                              # off: the consumed iterations (+ the one a breakdown froze)
+    assert 0 <= on[5] - off[5] <= 2                               # on: plus the dropped look-aheads of a break / the :527 branch
+
+
+def test_look_ahead_windows_enqueue_exactly_k(hostops):
+    """pcg_solve_run(K) must leave nothing in flight: a timed window of K passes is K iterations of device work."""
+    _, parts = golden_cases.build_case("n9_p1")
+    P = parts[0]
+    op = pm.get_operator(P)
+    fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+    op.solve_begin(fext, None, op.build_jacobi(), 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    r = op.solve_run(10)
+    assert (r.iters_done, r.iters_enqueued) == (10, 10)
+    r = op.solve_run(1)
+    assert (r.iters_done, r.iters_enqueued) == (11, 11)
+    op.solve_run(-1)
+    x, res = op.solve_end()
+    assert (res.flag, res.iter) == (0, 118) and res.iters_enqueued - res.iters_done == 1    # the one behind the converged iteration
+
+
 def test_missing_preconditioner_is_an_error(hostops):
     _, parts = golden_cases.build_case("n9_p1")
     op = pm.get_operator(parts[0])

@@ -208,6 +208,28 @@ def test_run_to_run_bit_reproducible(gpu_lib):
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("case", ["n9_p1", "n9_stagnate", "n9_flag4", "n9_flag2", "n9_maxiter", "oct_p1"])
+def test_look_ahead_changes_nothing_on_gpu(gpu_lib, monkeypatch, case, kind):
+    """One iteration is kept in flight ahead of the host's tests (pcg_driver.cpp iterate_once); on a real stream the
+    look-ahead kernels overlap the host's wait.  Results must be bit-identical to the strictly sequential loop."""
+    from pcg_mi355x.operator import from_refmeshpart
+    out = []
+    for la in ("1", "0"):
+        monkeypatch.setenv("PCG_LOOK_AHEAD", la)
+        _, parts = golden_cases.build_case(case)
+        P = parts[0]
+        op = from_refmeshpart(P, kind=kind)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"],
+                                P["GlobData"]["GlobNDofEff"], history=True)
+        out.append((x, (res.flag, res.iter, res.relres, res.iters_done, res.n_matvec), hist, res.iters_enqueued))
+        op.close()
+    on, off = out
+    assert np.array_equal(on[0], off[0]) and on[1] == off[1] and np.array_equal(on[2], off[2])
+    assert 0 <= on[3] - off[3] <= 2
+
+
 def test_full_size_1m_properties(gpu_lib, oracle_c):
     """BASELINE configs[1] size (N=70, 1 029 000 dof): oracle mat-vec parity on one vector, linearity,
     symmetry, rigid-body null space, and a full solve whose TRUE residual is re-checked by the oracle."""
