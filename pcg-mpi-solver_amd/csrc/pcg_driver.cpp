@@ -52,7 +52,13 @@ struct pcg_engine {
     bool has_hooks = false;
     bool jacobi_built = false;
     bool profiling = false;
-    bool look_ahead = !(std::getenv("PCG_LOOK_AHEAD") && std::getenv("PCG_LOOK_AHEAD")[0] == '0');   // A/B switch
+    // One-iteration look-ahead of the solve loop (iterate_once).  Measured on MI355X (profiles/r01_look_ahead_ab.json):
+    // 1 M dof +5.6 % (assembled) / +10 % (matrix-free) iterations/s, with the Python all-reduce hooks in the loop
+    // +7..11 %; at 10 M dof the 13 us of host gap it removes per 1.4 ms iteration are lost again (the SpMV, now
+    // back-to-back, ran 3 % slower: -1.5 % overall).  Default: on when the part is small enough for the gap to
+    // matter or communication hooks are in the loop; PCG_LOOK_AHEAD=0/1 forces it.
+    int look_ahead_mode = std::getenv("PCG_LOOK_AHEAD") ? (std::getenv("PCG_LOOK_AHEAD")[0] == '0' ? 0 : 1) : -1;
+    bool look_ahead() const { return look_ahead_mode == 1 || (look_ahead_mode < 0 && (has_hooks || n <= 4000000)); }
 
     double *d_send = nullptr, *d_recv = nullptr, *d_st = nullptr;
     double *v_b = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
@@ -690,7 +696,7 @@ int pcg_solve_run(pcg_engine *e, int64_t n_iters, double *hist, int64_t hist_cap
         int64_t k = 0;
         while (!s.done && (n_iters < 0 || k < n_iters)) {
             // no look-ahead out of the last pass of this call: a run of K passes enqueues exactly K iterations
-            if (iterate_once(e, hist, hist_cap, e->look_ahead && (n_iters < 0 || k + 1 < n_iters))) s.done = true;
+            if (iterate_once(e, hist, hist_cap, e->look_ahead() && (n_iters < 0 || k + 1 < n_iters))) s.done = true;
             ++k;
         }
         if (s.done) s.ahead = false;
