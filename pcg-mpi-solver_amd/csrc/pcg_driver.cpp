@@ -430,7 +430,6 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
             return 0;
         }
         if (block != 0 && block != 3) return set_error("pcg_create_csr: block must be 0/3 (3x3 node blocks) or 1 (scalar)");
-        const int32_t rows_per_lane = 0;
         if (n % 3) return set_error("pcg_create_csr: n must be a multiple of 3 (dof = 3*node + dir); use block = 1 otherwise");
         const int64_t nn = n / 3;
         std::vector<int64_t> brow((size_t)nn + 1, 0);
@@ -455,7 +454,7 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
                 }
             brow[i + 1] = (int64_t)bcol.size();
         }
-        return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, rows_per_lane, out);
+        return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, 0, out);
     });
 }
 
