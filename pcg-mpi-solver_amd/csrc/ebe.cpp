@@ -269,23 +269,31 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         const int32_t kci = (int32_t)K.n_chunks++;
         const int nn = (int)o.nodes.size();
         const int ne = (int)o.elems.size();
-        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, ke_index[g], kci, in.nd, cls_of[g], 0});
+        // slot of every element: sorted by sub-colour (stable) so that whole waves share a phase; in the hex8 class
+        // every sub-colour group starts on a multiple of 16 slots, i.e. a 16-element MFMA tile is sub-colour pure
+        std::vector<int> lane_of(ne);
+        std::iota(lane_of.begin(), lane_of.end(), 0);
+        std::stable_sort(lane_of.begin(), lane_of.end(), [&](int a, int b) { return sc[a] < sc[b]; });
+        std::vector<int> slot_of(ne);
+        int next_slot = 0;
+        for (int k = 0; k < ne; ++k) {
+            if (K.full && k > 0 && sc[lane_of[k]] != sc[lane_of[k - 1]]) next_slot = (next_slot + 15) / 16 * 16;
+            slot_of[k] = next_slot++;
+        }
+        const int n_tiles = (next_slot + 15) / 16;
+        C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, ke_index[g], kci, in.nd, cls_of[g], n_tiles});
         C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
         C.max_subcolors = std::max(C.max_subcolors, nsub);
         chunk_phase.push_back(bnd ? 0 : 1);
         K.list[bnd ? 0 : 1].push_back(cid);
-        // lanes ordered by sub-colour (stable) so that whole waves share a phase
-        std::vector<int> lane_of(ne);
-        std::iota(lane_of.begin(), lane_of.end(), 0);
-        std::stable_sort(lane_of.begin(), lane_of.end(), [&](int a, int b) { return sc[a] < sc[b]; });
         const size_t base = (size_t)kci * CE;
         K.ck.resize(base + CE, 0.0);
         K.sgn.resize((size_t)(kci + 1) * W * CE, 0u);
         K.lid.resize((size_t)(kci + 1) * K.nnp * CE, 0);
         for (int lane = 0; lane < CE; ++lane)                        // padding slots: sub-colour 255
             K.sgn[((size_t)kci * W + (W - 1)) * CE + lane] = 0xff000000u;
-        for (int lane = 0; lane < ne; ++lane) {
-            const int t = lane_of[lane];
+        for (int k = 0; k < ne; ++k) {
+            const int t = lane_of[k], lane = slot_of[k];
             const int64_t e = o.elems[t];
             K.ck[base + lane] = in.ck[e];
             for (int w = 0; w < W; ++w) {
@@ -335,6 +343,13 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 int nsub = 0;
                 bool bnd = false;
                 if (!sub_colour(g, o, sc, lids, nsub, bnd)) return false;
+                if (C.cls[cls_of[g]].full) {                 // hex8 class: sub-colour groups start on 16-slot tiles (k_ebe_mfma)
+                    std::vector<int> cnt(nsub, 0);
+                    for (int c : sc) cnt[c]++;
+                    size_t padded = 0;
+                    for (int c : cnt) padded += (size_t)(c + 15) / 16 * 16;
+                    if (padded > chunk_elems) return false;
+                }
                 close_chunk(g, o, sc, lids, nsub, bnd);
                 return true;
             };

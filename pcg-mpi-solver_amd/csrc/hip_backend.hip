@@ -446,6 +446,151 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// hex8 chunks on the matrix cores.  The reference computes Ke @ (Ck * U) for all elements of a type as ONE
+// dgemm (pcg_solver.py:279): Y(24 x Ne) = Ke(24 x 24) . U(24 x Ne).  That is what v_mfma_f64_16x16x4_f64 is
+// for: M = output dofs (24 -> two 16-row tiles, 25 % padding), N = 16 elements, K = 24 = 6 steps of 4.
+//   A (16 x 4): lane l holds Ke[16 mt + (l & 15)][4 ks + (l >> 4)]         - 12 doubles per lane, loaded once
+//   B (4 x 16): lane l holds u[dof 4 ks + (l >> 4)] of element (l & 15)    - gathered from the LDS x tile
+//   D (16x16): lane l, register r holds y[dof 16 mt + (l >> 4) + 4 r] of element (l & 15)
+// so a lane gathers AND scatters the same six dofs {g, g+4, .., g+20}, g = l >> 4, of "its" element: the six LDS
+// addresses are computed once.  A tile holds 16 elements of ONE sub-colour (build_ebe pads every sub-colour
+// group of a hex8 chunk to a multiple of 16 slots), so the 64 lanes of a scatter instruction never collide;
+// sub-colours are processed in order with a block barrier in between -> the same deterministic summation
+// order per node as k_ebe_chunk.  f64 MFMA peak equals the vector peak on MI355X (78.6 TF); the idea is the issue
+// port: 12 MFMA per 16 elements instead of 576 v_fma per element leave the VALU/LDS pipes to the gather/scatter.
+// Measured (10 M dof): correct (same parity tests), 62 cycles per MFMA as expected, but the matrix pipe is busy
+// only 29 % of the time and the apply takes 0.25 ms vs 0.20 ms for k_ebe_chunk: a wave lives ~35 k cycles for
+// 3 k cycles of MFMA; the rest is the load chain at the head of the block, the LDS phases and ten block
+// barriers per chunk.  Kept as an opt-in (PCG_EBE_MFMA=1) for the next round's work on that structure.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int EPT, bool DOT>
+__global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
+    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
+    const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
+    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
+{
+    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
+    constexpr int CE = kChunkThreads * EPT;                  // element slots per chunk
+    constexpr int TPW = CE / 16 / kWavesPerBlock;            // tiles a wave may own (tile t -> wave t & 3)
+    __shared__ double xs[3 * kChunkMaxNodes];
+    __shared__ double ys[3 * kChunkMaxNodes];
+    const int chunk = chunk_list[blockIdx.x];
+    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
+    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, tiles in use
+    const int kci = h2.x, n_tiles = h2.w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    // ---- x tile -> LDS, y tile = 0 -----------------------------------------------------------------------
+    int dst[NPT];
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        int gn = -1;
+        dst[j] = 0;
+        if (n < h.y) { gn = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n); }
+        if (gn >= 0) {
+            const double *xp = x + 3 * (size_t)gn;
+            xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
+            ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
+        }
+    }
+    // ---- A operand: the pattern matrix, once per wave (ke_col is column-major: ke_col[b * 24 + a] = Ke[a][b]) ----
+    const double *K = ke_col + (size_t)h.w * 24 * 24;
+    double A0[6], A1[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int b = 4 * ks + g;
+        A0[ks] = K[b * 24 + col];
+        A1[ks] = col < 8 ? K[b * 24 + 16 + col] : 0.0;      // rows 24..31 of the second M tile are padding
+    }
+    // the six dofs of this lane group: dof = g + 4 m -> (node, component)
+    int nd_[6], cp_[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { const int d = g + 4 * m; nd_[m] = d / 3; cp_[m] = d - 3 * (d / 3); }
+    // ---- element data of the tiles this wave owns: issued up front ---------------------------------------
+    unsigned sg[TPW];
+    double c[TPW];
+    int ad[TPW][6];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + kWavesPerBlock * i;
+        sg[i] = 0xff000000u; c[i] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ad[i][m] = 0;
+        if (t < n_tiles) {
+            const size_t slot = (size_t)t * 16 + col;
+            sg[i] = __builtin_nontemporal_load(sgn + (size_t)kci * CE + slot);
+            c[i] = __builtin_nontemporal_load(ck + (size_t)kci * CE + slot);
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                ad[i][m] = 3 * (int)lid[((size_t)kci * 8 + nd_[m]) * CE + slot] + cp_[m];
+        }
+    }
+    __syncthreads();
+    // ---- phase A: every tile of the wave, gather + 12 MFMA; independent of the sub-colours (xs is read-only), so the
+    // matrix pipe sees up to 2 * TPW independent accumulation chains back to back ---------------------------------
+    double o[TPW][6];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        double u[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            double v = xs[ad[i][m]];                                          // :277 gather (from the LDS tile)
+            if ((sg[i] >> (g + 4 * m)) & 1u) v = -v;                          // :278
+            u[m] = c[i] * v;                                                  // :279 Ck * U  (padding slots: Ck = 0)
+        }
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {                                      // :279 Ke @ (.)
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[ks], u[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[ks], u[ks], acc1, 0, 0, 0);
+        }
+        o[i][0] = acc0[0]; o[i][1] = acc0[1]; o[i][2] = acc0[2]; o[i][3] = acc0[3]; o[i][4] = acc1[0]; o[i][5] = acc1[1];
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            if ((sg[i] >> (g + 4 * m)) & 1u) o[i][m] = -o[i][m];              // :280
+    }
+    // ---- phase B: scatter-add into the LDS y tile, one sub-colour at a time (a tile is sub-colour pure) ----------
+    for (int s = 0; s < h.z; ++s) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if ((int)(sg[i] >> 24) == s) {                                    // real element of this sub-colour (padding: 255)
+                double old[6];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) old[m] = ys[ad[i][m]];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) ys[ad[i][m]] = old[m] + o[i][m];  // :300, LDS-staged partial sums
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        if (n < h.y) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            out[0] = ys[3 * n]; out[1] = ys[3 * n + 1]; out[2] = ys[3 * n + 2];
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                const uint8_t *fp = flags + dst[j];
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if ((fp[d] & 3) == 3) dot += xs[3 * n + d] * ys[3 * n + d];
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+
 // nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
@@ -781,6 +926,10 @@ class HipBackend : public Backend {
     int spmv_blocks_per_cu_ = 4;
     int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
     bool bench_dot_ = false;
+    // PCG_EBE_MFMA=1: hex8 chunks on the matrix cores (k_ebe_mfma) instead of the v_fma kernel (k_ebe_chunk).  Off by
+    // default: measured 0.25 ms vs 0.20 ms per apply at 10 M dof - neither kernel is bound by its arithmetic
+    // (profiles/r01_pmc_ebe_mfma.md).
+    bool ebe_mfma_ = false;
 
 public:
     explicit HipBackend(int device)
@@ -804,6 +953,7 @@ public:
         if (const char *e = getenv("PCG_SPMV_BLOCKS_PER_CU")) spmv_blocks_per_cu_ = std::max(1, atoi(e));
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
+        if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
     }
     ~HipBackend() override
     {
@@ -952,10 +1102,26 @@ public:
             hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
                                d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
-    void launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    template <int EPT>
+    void launch_mfma(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_mfma<EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+                               d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        else
+            hipLaunchKernelGGL((k_ebe_mfma<EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+                               d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+    }
+    // -> number of dot partials the launch writes
+    int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         switch (D.nnp) {
         case 8:
+            if (D.full && ebe_mfma_) {                          // hex8 class on the matrix cores
+                if (D.ept == 2) launch_mfma<2>(D, ph, x, y, dot, part, dot_lo);
+                else launch_mfma<1>(D, ph, x, y, dot, part, dot_lo);
+                break;
+            }
             if (!D.full) launch_chunks<8, 1, false>(D, ph, x, y, dot, part, dot_lo);
             else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo);
             else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo);
@@ -964,6 +1130,7 @@ public:
         case 24: launch_chunks<24, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
         default: launch_chunks<32, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
         }
+        return D.count[ph];
     }
     bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
@@ -975,8 +1142,8 @@ public:
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
             for (const auto &D : chc_)                           // one launch per node-count class
                 if (D.count[ph]) {
-                    launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
-                    if (fuse) cnt_ebe_ += D.count[ph];
+                    const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
+                    if (fuse) cnt_ebe_ += np;
                 }
             if (sh_count_[ph]) {
                 const int grid = (sh_count_[ph] + kBlock - 1) / kBlock;

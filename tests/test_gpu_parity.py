@@ -313,6 +313,36 @@ def test_ebe_kernel_vs_oracle(gpu_lib, n_types, chunked):
     assert np.array_equal(op.diag(), pcg_oracle.matvec_local(P, None, "Preconditioner"))
 
 
+@pytest.mark.parametrize("ept", ["1", "2"])
+@pytest.mark.parametrize("n_types", [1, 3])
+def test_ebe_matrix_core_kernel_vs_oracle(gpu_lib, monkeypatch, n_types, ept):
+    """k_ebe_mfma (opt-in, PCG_EBE_MFMA=1): the reference's Ke @ (Ck U) as v_mfma_f64_16x16x4 tiles of 16 same-sub-colour
+    elements; same oracle tolerance, bit-reproducible, fused dot, and the same solve as the default v_fma kernel."""
+    from pcg_mi355x.operator import from_refmeshpart
+    from pcg_mi355x._lib import check
+    monkeypatch.setenv("PCG_EBE_MFMA", "1")                                   # read when the engine is created
+    monkeypatch.setenv("PCG_EBE_EPT", ept)
+    b = Brick(23, n_types=n_types)                                           # 36 501 dof, ragged boundary chunks, padded tiles
+    P = make_parts(b)[0]
+    op = from_refmeshpart(P, kind="ebe")
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(b.n_dof)
+    y = np.empty(b.n_dof); pxy = C.c_double()
+    check(op._L.pcg_k_spmv_local(op._h, x.ctypes.data, y.ctypes.data, C.byref(pxy)))
+    ref = pcg_oracle.matvec_local(P, x)
+    assert relerr(y, ref) < 1e-13
+    assert abs(pxy.value - np.dot(x[P["LocDofEff"]], ref[P["LocDofEff"]])) <= 1e-12 * np.dot(np.abs(x), np.abs(ref))
+    assert np.array_equal(y, op.apply(x))
+    fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+    xs, res, _ = op.solve(fext, None, op.build_jacobi(), 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    op.close()
+    monkeypatch.setenv("PCG_EBE_MFMA", "0")
+    op0 = from_refmeshpart(P, kind="ebe")
+    xs0, res0, _ = op0.solve(fext, None, op0.build_jacobi(), 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    op0.close()
+    assert res.flag == res0.flag == 0 and abs(res.iter - res0.iter) <= 1 and relerr(xs, xs0) < 1e-7
+
+
 @pytest.mark.parametrize("N", [8, 9])
 def test_ebe_generic_nd_kernel(gpu_lib, ebe_cfg, N):
     b, P = make_super_part(N)                                                # nd = 36 (+ nd = 24 group when N-1 is odd)
