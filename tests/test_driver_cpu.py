@@ -45,6 +45,41 @@ def test_single_part_solve_matches_reference(hostops, name):
     assert gd["MP_TimeRecData"]["dT_Calc"] > 0
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_randomised_load_steps_vs_oracle(hostops, oracle_c, seed, kind):
+    """Seeded random models (size, pattern types, prescribed displacements, loads, tolerance, warm start) through the
+    engine and through the oracle (pinned bit-exact to the reference, tests/test_oracle_golden.py): same Flag, same
+    iteration count (+-1 for the matrix-free operator), same solution, same early residual history."""
+    import copy
+    import pcg_oracle
+    from pcg_mi355x.brick import Brick, make_parts
+    rng = np.random.default_rng(100 + seed)
+    b = Brick(int(rng.integers(6, 11)), seed=seed, n_types=int(rng.integers(1, 4)))
+    P = make_parts(b, tol=float(10.0 ** -rng.integers(5, 9)), max_iter=int(rng.integers(40, 400)))[0]
+    fixed = P["LocFixedDof"]
+    P["Ud"] = np.zeros(P["NDOF"]); P["Ud"][fixed] = 1e-3 * rng.standard_normal(len(fixed))          # :234
+    P["RefLoadVector"] = P["RefLoadVector"] + 0.1 * rng.standard_normal(P["NDOF"])
+    if seed % 2:
+        P["Un"] = 1e-2 * rng.standard_normal(P["NDOF"])                                                # warm start (:378)
+    Q = copy.deepcopy(P)
+    ref = pcg_oracle.solve_step([Q], use_c=True)
+    pm.configure(comm=None, operator=kind)
+    try:
+        pm.update_bc(P); pm.update_preconditioner(P)
+        assert relerr(P["Fext"], Q["Fext"]) < 1e-13
+        pm.solve(P, history=True)
+    finally:
+        pm.configure(comm=None)
+    info = P["_pcg_mi355x_info"]
+    tol_iter = 1 if kind == "ebe" else 0
+    assert info.flag == ref["flag"] and abs(info.iter - ref["iter"]) <= tol_iter, (info.flag, info.iter, ref["flag"], ref["iter"])
+    assert relerr(P["Un"], Q["Un"]) < (1e-6 if info.flag else 1e-8) * (1 if info.iter == ref["iter"] else 20)
+    m = min(len(info.history), int(0.3 * len(ref["history"])))
+    if m:
+        assert np.abs(info.history[:m, 2] / ref["history"][:m, 2] - 1).max() < 1e-10
+
+
 def test_functional_api_and_resume(hostops):
     """solve_system() + begin/run/end in several chunks gives the identical result."""
     brick, parts = golden_cases.build_case("n9_p1")
