@@ -18,6 +18,8 @@ CASES = {
     "part_octree_p3": {"octree": (4, 4, 2, 2), "sign_seed": 7, "rcb": 3},       # hanging-node patterns, 2 pattern types
     "part_octree_p5": {"octree": (6, 4, 3, 1), "sign_seed": None, "rcb": 5},    # uneven recursive bisection
     "part_octree_p1": {"octree": (4, 6, 2, 2), "sign_seed": 3, "rcb": 1},
+    # every element to a random part: disconnected parts, every part a neighbour of every other, nodes shared by up to 5
+    "part_brick_rand5": {"brick": dict(N=6, n_types=2), "random": (5, 11)},
 }
 SOLVER = {"Tol": 1e-7, "MaxIter": 10000}
 
@@ -30,6 +32,11 @@ def build_model(name):
     if "brick" in c:
         from pcg_mi355x.brick import Brick, block_partition
         b = Brick(c["brick"]["N"], seed=0, n_types=c["brick"]["n_types"])
+        if "random" in c:
+            n, seed = c["random"]
+            ep = np.random.default_rng(seed).integers(0, n, b.n_elem)
+            ep[:n] = np.arange(n)                                     # no empty part
+            return mdf.model_from_brick(b), ep.astype(np.int64)
         return mdf.model_from_brick(b), block_partition(b, *c["grid"]).astype(np.int64)
     from pcg_mi355x.octree import TwoLevelMesh
     mesh = TwoLevelMesh(*c["octree"], seed=0)

@@ -118,7 +118,7 @@ def test_geometric_partition_and_errors():
 
 
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
-@pytest.mark.parametrize("name", ["part_brick_p1", "part_octree_p1", "part_octree_p3", "part_brick_p4"])
+@pytest.mark.parametrize("name", ["part_brick_p1", "part_octree_p1", "part_octree_p3", "part_brick_p4", "part_brick_rand5"])
 def test_mdf_to_solution_matches_reference_pipeline(hostops, name, kind, tmp_path):
     """MDF files -> partition_model -> engine (CPU test double of the backend) vs the reference pipeline's solution."""
     import pcg_mi355x as pm
