@@ -318,15 +318,12 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
 template <int NNP, int EPT> struct ChunkLB { static constexpr int w = NNP == 8 ? (EPT == 1 ? 4 : 3) : 2; };
 
 // FULL: every element of the launch has exactly NNP nodes (the hex8 class): the `< nd` guards compile away.
-// PUPD: the search direction is formed here instead of in k_update_p: every chunk computes p = M^-1 r (+ beta p_old)
-// for its own tile nodes while it stages them, uses them, and stores them to x (= p_new; nodes shared by chunks are
-// stored more than once with identical bits; p_old is another buffer, so nothing a neighbour still reads changes).
-template <int NNP, int EPT, bool FULL, bool DOT, bool PUPD>
+template <int NNP, int EPT, bool FULL, bool DOT>
 __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_chunk(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
     const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-    const double *__restrict__ ke_col, const double *x, double *__restrict__ y, double *__restrict__ buf,
-    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo, PUpdate pu)
+    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
+    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
 {
     constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
     constexpr int CE = kChunkThreads * EPT;                  // element slots per chunk
@@ -360,21 +357,8 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
         dst[j] = 0;
         if (n < h.y) { g = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n); }
         if (g >= 0) {
-            if constexpr (PUPD) {
-                const double *rp = pu.r + 3 * (size_t)g, *mp = pu.minv + 3 * (size_t)g, *pp = pu.p_in + 3 * (size_t)g;
-                double *po = pu.p_out + 3 * (size_t)g;
-                const double beta = pu.first ? 0.0 : pu.st[ST_RHO_NEXT] / pu.rho_prev;   // :475, as in k_update_p
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    double z = mp[d] * rp[d];                                           // :447
-                    if (!pu.first) z = z + beta * pp[d];                                // :479
-                    xs[3 * n + d] = z;
-                    po[d] = z;
-                }
-            } else {
-                const double *xp = x + 3 * (size_t)g;
-                xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
-            }
+            const double *xp = x + 3 * (size_t)g;
+            xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
             ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
         }
     }
@@ -1108,24 +1092,15 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
-    template <int NNP, int EPT, bool FULL, bool DOT, bool PUPD>
-    void launch_chunks_k(const ChunkClassDev &D, int ph, const double *x, double *y, double *part, long long dot_lo, const PUpdate &pu)
-    {
-        hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, DOT, PUPD>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
-                           d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo, pu);
-    }
     template <int NNP, int EPT, bool FULL>
-    void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo,
-                       const PUpdate *pu)
+    void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
-        static const PUpdate none{};
-        if (pu) {
-            if (dot) launch_chunks_k<NNP, EPT, FULL, true, true>(D, ph, x, y, part, dot_lo, *pu);
-            else launch_chunks_k<NNP, EPT, FULL, false, true>(D, ph, x, y, part, dot_lo, *pu);
-        } else {
-            if (dot) launch_chunks_k<NNP, EPT, FULL, true, false>(D, ph, x, y, part, dot_lo, none);
-            else launch_chunks_k<NNP, EPT, FULL, false, false>(D, ph, x, y, part, dot_lo, none);
-        }
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        else
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     template <int EPT>
     void launch_mfma(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
@@ -1138,8 +1113,7 @@ public:
                                d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     // -> number of dot partials the launch writes
-    int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo,
-                     const PUpdate *pu)
+    int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         switch (D.nnp) {
         case 8:
@@ -1148,23 +1122,17 @@ public:
                 else launch_mfma<1>(D, ph, x, y, dot, part, dot_lo);
                 break;
             }
-            if (!D.full) launch_chunks<8, 1, false>(D, ph, x, y, dot, part, dot_lo, pu);
-            else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo, pu);
-            else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo, pu);
+            if (!D.full) launch_chunks<8, 1, false>(D, ph, x, y, dot, part, dot_lo);
+            else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo);
+            else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo);
             break;
-        case 16: launch_chunks<16, 1, false>(D, ph, x, y, dot, part, dot_lo, pu); break;
-        case 24: launch_chunks<24, 1, false>(D, ph, x, y, dot, part, dot_lo, pu); break;
-        default: launch_chunks<32, 1, false>(D, ph, x, y, dot, part, dot_lo, pu); break;
+        case 16: launch_chunks<16, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
+        case 24: launch_chunks<24, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
+        default: launch_chunks<32, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
         }
         return D.count[ph];
     }
-    bool ebe_can_fuse_p() const override
-    {
-        return ebe_ && !ebe_mfma_ && !ch_needs_zero_ && ebe_ranges_[0].empty() && ebe_ranges_[1].empty() &&
-               (n_chunks_total_[0] + n_chunks_total_[1]) > 0;
-    }
-    bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo,
-                   const PUpdate *pu) override
+    bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
         // the fused dot needs every dof to be finalised by the chunk / shared kernels
         const bool fuse = with_dot && ebe_ranges_[0].empty() && ebe_ranges_[1].empty() && (n_chunks_total_[0] + n_chunks_total_[1]) > 0;
@@ -1174,7 +1142,7 @@ public:
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
             for (const auto &D : chc_)                           // one launch per node-count class
                 if (D.count[ph]) {
-                    const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo, pu);
+                    const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
                     if (fuse) cnt_ebe_ += np;
                 }
             if (sh_count_[ph]) {
@@ -1419,13 +1387,13 @@ public:
     int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
     {
         if (ebe_) {
-            for (int k = 0; k < warmup; ++k) { cnt_ebe_ = 0; ebe_apply(x, y, 0, 2, true, bench_dot_, 0, nullptr); }
+            for (int k = 0; k < warmup; ++k) { cnt_ebe_ = 0; ebe_apply(x, y, 0, 2, true, bench_dot_, 0); }
             hipEvent_t a, b;
             HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
             for (int k = 0; k < reps; ++k) {
                 HIP_CHECK(hipEventRecord(a, st_));
                 cnt_ebe_ = 0;
-                ebe_apply(x, y, 0, 2, true, bench_dot_, 0, nullptr);
+                ebe_apply(x, y, 0, 2, true, bench_dot_, 0);
                 HIP_CHECK(hipEventRecord(b, st_));
                 HIP_CHECK(hipEventSynchronize(b));
                 HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));

@@ -135,18 +135,18 @@ struct pcg_engine {
 
     // y = A x with the interface sum (:242-336).  Interface rows first, exchange overlapped with
     // the interior rows, then the neighbour contributions are added in neighbour order (:333-334).
-    void apply(const double *x, double *y, bool with_dot, const PUpdate *pu = nullptr)
+    void apply(const double *x, double *y, bool with_dot)
     {
         if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
             if (with_dot) be->begin_dot();
             bool fused;
             if (!has_halo) {
-                fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0, pu);
+                fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0);
             } else {
-                fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs, pu);
+                fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs);
                 be->halo_pack(y, d_send);
                 halo_begin();
-                be->ebe_apply(x, y, 1, 2, false, with_dot, n_bnd_dofs, pu);
+                be->ebe_apply(x, y, 1, 2, false, with_dot, n_bnd_dofs);
                 halo_end();
                 be->boundary_fixup(y, d_recv, x, with_dot && fused);   // interface dofs: + neighbours, their dot
             }
@@ -211,13 +211,8 @@ struct pcg_engine {
     {
         s.n_enqueued++;
         be->set_status_slot(slot);
-        if (kind == 1 && be->ebe_can_fuse_p()) {                            // p is formed inside the element kernels
-            const PUpdate pu{p_in, r_in, s.minv, d_st, p_out, rho_prev, first ? 1 : 0};
-            apply(p_out, v_q, true, &pu);                                   // :447, :472-479 + :482-484
-        } else {
-            be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first); // :447, :472-479
-            apply(p_out, v_q, true);                                        // :482-484
-        }
+        be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first);     // :447, :472-479
+        apply(p_out, v_q, true);                                            // :482-484
         if (!has_hooks && !(kind == 1 && !ebe_dot_fused)) {
             be->reduce_dot_alpha(d_st);                                     // :487-498, one launch (no all-reduce in between)
         } else {

@@ -126,14 +126,6 @@ struct HaloHost {
     std::vector<int32_t> fix_pos;        // positions in the receive buffer
 };
 
-// the p-update an element-operator apply may absorb (Backend::ebe_apply)
-struct PUpdate {
-    const double *p_in, *r, *minv, *st;
-    double *p_out;
-    double rho_prev;
-    int first;
-};
-
 class Backend {
 public:
     virtual ~Backend() {}
@@ -153,14 +145,8 @@ public:
     // with_dot: also accumulate partials of sum x[d]*y[d]*own_free(d) over the dofs d >= dot_lo that become
     // final in these phases (interface dofs < dot_lo get theirs from boundary_fixup); returns false when the
     // operator cannot fuse the dot (then the caller runs dot_w).  reduce with reduce_dot().
-    // pu != null (only when ebe_can_fuse_p()): x is NOT read - every chunk computes the search direction of its own tile
-    // nodes, x = first ? M^-1 r : M^-1 r + beta p_in (beta = st[RHO_NEXT] / rho_prev, exactly update_p), uses it and
-    // stores it to x (nodes shared by chunks are stored more than once, with identical bits), so the separate
-    // update_p pass over the vectors disappears.
     virtual bool ebe_apply(const double *x, double *y, int phase_lo, int phase_hi, bool zero_first, bool with_dot,
-                           int64_t dot_lo, const PUpdate *pu = nullptr) = 0;
-    // true when every node is a tile node of some chunk and no element takes another path
-    virtual bool ebe_can_fuse_p() const = 0;
+                           int64_t dot_lo) = 0;
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;
 

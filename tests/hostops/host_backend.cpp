@@ -43,15 +43,8 @@ public:
         ebe_ = m; n_ = 3 * m.n_nodes;
         m_ = SellHost(); m_.n_nodes = m.n_nodes; m_.diag = m.diag;
     }
-    bool ebe_can_fuse_p() const override
+    bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
-        return ebe_.chunked.n_chunks > 0 && !ebe_.chunked.needs_zero && ebe_.ranges[0].empty() && ebe_.ranges[1].empty();
-    }
-    bool ebe_apply(const double *x_in, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo,
-                   const PUpdate *pu) override
-    {
-        const double *x = pu ? pu->p_out : x_in;
-        const double beta = pu && !pu->first ? pu->st[ST_RHO_NEXT] / pu->rho_prev : 0.0;
         const bool fuse = with_dot && ebe_.ranges[0].empty() && ebe_.ranges[1].empty() && ebe_.chunked.n_chunks > 0;
         const auto &C = ebe_.chunked;
         if (zero_first && (C.n_chunks == 0 || C.needs_zero)) std::memset(y, 0, sizeof(double) * n_);
@@ -67,14 +60,7 @@ public:
                 const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
                 acc.assign((size_t)nd * CE, 0.0);
                 for (int n = 0; n < nn; ++n)
-                    for (int d = 0; d < 3; ++d) {
-                        const int64_t dd = 3 * (int64_t)C.nodes[off + n] + d;
-                        if (pu) {                                       // the chunk forms p for its own tile nodes and stores it
-                            const double z = pu->minv[dd] * pu->r[dd];
-                            pu->p_out[dd] = pu->first ? z : z + beta * pu->p_in[dd];
-                        }
-                        xs[3 * n + d] = x[dd]; ys[3 * n + d] = 0.0;
-                    }
+                    for (int d = 0; d < 3; ++d) { xs[3 * n + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
                 auto sbit = [&](int lane, int a) { return (K.sgn[((size_t)kci * W + a / 32) * CE + lane] >> (a % 32)) & 1u; };
                 auto subc = [&](int lane) { return (int)(K.sgn[((size_t)kci * W + W - 1) * CE + lane] >> 24); };
                 for (int lane = 0; lane < CE; ++lane) {
@@ -278,7 +264,7 @@ public:
     void collect_profile(double *ms, int64_t *c) override { *ms = 0; *c = 0; }
     int bench_spmv(const double *x, double *y, int, int reps, float *ms) override
     {
-        if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true, false, 0, nullptr);
+        if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true, false, 0);
         else spmv(x, y, 0, m_.n_slices, false);
         for (int k = 0; k < reps; ++k) ms[k] = 0.f;
         return 0;
