@@ -297,7 +297,11 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         }
         const int n_tiles = (next_slot + 15) / 16;
         C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, ke_index[g], kci, in.nd, cls_of[g], n_tiles});
-        C.nodes.insert(C.nodes.end(), o.nodes.begin(), o.nodes.end());
+        {                                                    // global side in address order, LDS side in slot order
+            std::vector<int32_t> by_id(o.nodes);
+            std::sort(by_id.begin(), by_id.end());
+            for (int32_t nd_ : by_id) { C.nodes.push_back(nd_); C.tslot.push_back((uint16_t)local_of[nd_]); }
+        }
         C.max_subcolors = std::max(C.max_subcolors, nsub);
         chunk_phase.push_back(bnd ? 0 : 1);
         K.list[bnd ? 0 : 1].push_back(cid);

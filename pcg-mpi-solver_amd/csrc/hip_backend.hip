@@ -321,7 +321,7 @@ template <int NNP, int EPT> struct ChunkLB { static constexpr int w = NNP == 8 ?
 template <int NNP, int EPT, bool FULL, bool DOT>
 __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_chunk(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
-    const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
     const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
     const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
 {
@@ -348,18 +348,22 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
 #pragma unroll
         for (int k = 0; k < NNP; ++k) l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
     }
-    int dst[NPT];
+    int dst[NPT], sl3[NPT];
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int n = threadIdx.x + j * kChunkThreads;
         int g = -1;
         dst[j] = 0;
-        if (n < h.y) { g = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n); }
+        sl3[j] = 0;
+        if (n < h.y) {
+            g = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n);
+            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
+        }
         if (g >= 0) {
             const double *xp = x + 3 * (size_t)g;
-            xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
-            ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
+            xs[sl3[j]] = xp[0]; xs[sl3[j] + 1] = xp[1]; xs[sl3[j] + 2] = xp[2];
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
         }
     }
     __syncthreads();
@@ -429,12 +433,12 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
         const int n = threadIdx.x + j * kChunkThreads;
         if (n < h.y) {
             double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            out[0] = ys[3 * n]; out[1] = ys[3 * n + 1]; out[2] = ys[3 * n + 2];
+            out[0] = ys[sl3[j]]; out[1] = ys[sl3[j] + 1]; out[2] = ys[sl3[j] + 2];
             if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
                 const uint8_t *fp = flags + dst[j];
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    if ((fp[d] & 3) == 3) dot += xs[3 * n + d] * ys[3 * n + d];
+                    if ((fp[d] & 3) == 3) dot += xs[sl3[j] + d] * ys[sl3[j] + d];
             }
         }
     }
@@ -468,7 +472,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 template <int EPT, bool DOT>
 __global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
-    const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
     const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
     const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
 {
@@ -484,18 +488,22 @@ __global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, col = lane & 15;
     // ---- x tile -> LDS, y tile = 0 -----------------------------------------------------------------------
-    int dst[NPT];
+    int dst[NPT], sl3[NPT];
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int n = threadIdx.x + j * kChunkThreads;
         int gn = -1;
         dst[j] = 0;
-        if (n < h.y) { gn = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n); }
+        sl3[j] = 0;
+        if (n < h.y) {
+            gn = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n);
+            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
+        }
         if (gn >= 0) {
             const double *xp = x + 3 * (size_t)gn;
-            xs[3 * n] = xp[0]; xs[3 * n + 1] = xp[1]; xs[3 * n + 2] = xp[2];
-            ys[3 * n] = 0.0; ys[3 * n + 1] = 0.0; ys[3 * n + 2] = 0.0;
+            xs[sl3[j]] = xp[0]; xs[sl3[j] + 1] = xp[1]; xs[sl3[j] + 2] = xp[2];
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
         }
     }
     // ---- A operand: the pattern matrix, once per wave (ke_col is column-major: ke_col[b * 24 + a] = Ke[a][b]) ----
@@ -573,12 +581,12 @@ __global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
         const int n = threadIdx.x + j * kChunkThreads;
         if (n < h.y) {
             double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            out[0] = ys[3 * n]; out[1] = ys[3 * n + 1]; out[2] = ys[3 * n + 2];
+            out[0] = ys[sl3[j]]; out[1] = ys[sl3[j] + 1]; out[2] = ys[sl3[j] + 2];
             if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
                 const uint8_t *fp = flags + dst[j];
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    if ((fp[d] & 3) == 3) dot += xs[3 * n + d] * ys[3 * n + d];
+                    if ((fp[d] & 3) == 3) dot += xs[sl3[j] + d] * ys[sl3[j] + d];
             }
         }
     }
@@ -891,6 +899,7 @@ class HipBackend : public Backend {
     bool ch_needs_zero_ = true;
     int4 *d_ch_hdr_ = nullptr;
     int *d_ch_nodes_ = nullptr;
+    unsigned short *d_ch_tslot_ = nullptr;
     // halo
     int *d_send_idx_ = nullptr, *d_fptr_ = nullptr, *d_fpos_ = nullptr;
     int64_t halo_count_ = 0, nb_dofs_ = 0;
@@ -965,7 +974,7 @@ public:
         for (auto &D : chc_)
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke})
                 if (p) (void)hipFree(p);
-        for (void *p : {(void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
+        for (void *p : {(void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_tslot_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
                         (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1], (void *)d_sh_slot_[0], (void *)d_sh_slot_[1]})
             if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
@@ -1057,7 +1066,7 @@ public:
             };
             d_ch_hdr_ = (int4 *)alloc(sizeof(int) * C.hdr.size());
             h2d(d_ch_hdr_, C.hdr.data(), sizeof(int) * C.hdr.size());
-            up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst);
+            up(d_ch_nodes_, C.nodes); up(d_ch_dst_, C.dst); up(d_ch_tslot_, C.tslot);
             d_ch_buf_ = (double *)alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(1, C.n_slots));
             ch_needs_zero_ = C.needs_zero;
             size_t np = 8;
@@ -1097,20 +1106,20 @@ public:
     {
         if (dot)
             hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+                               d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
             hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+                               d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     template <int EPT>
     void launch_mfma(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
             hipLaunchKernelGGL((k_ebe_mfma<EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
             hipLaunchKernelGGL((k_ebe_mfma<EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     // -> number of dot partials the launch writes
     int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)

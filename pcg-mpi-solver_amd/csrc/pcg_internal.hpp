@@ -81,8 +81,11 @@ struct EbeClassHost {
 struct EbeChunkedHost {
     int64_t n_chunks = 0;
     std::vector<int32_t> hdr;          // (n_chunks, 8): node_off, n_nodes, n_subcolours, ke index in class,
-                                       //                chunk index in class, nd, class, 0
-    std::vector<int32_t> nodes;        // concatenated unique node ids (engine numbering, ascending per chunk)
+                                       //                chunk index in class, nd, class, 16-element tiles in use (hex8 class)
+    std::vector<int32_t> nodes;        // concatenated unique node ids (engine numbering, ascending per chunk: the global
+                                       // loads / stores of a chunk walk memory in address order)
+    std::vector<uint16_t> tslot;       // same shape: slot of the node in the chunk's LDS tile (what `lid` refers to); the
+                                       // slot order is chosen against LDS bank conflicts, see ebe.cpp tile_key
     std::vector<int32_t> dst;          // same shape: >= 0: y offset 3*node (exclusive node); < 0: -(boundary slot + 1)
     int64_t n_slots = 0;               // boundary-buffer slots (one per (chunk, shared node))
     std::vector<int32_t> sh_node[2];   // per phase: shared nodes whose sum becomes final after that phase (ascending)

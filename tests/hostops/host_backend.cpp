@@ -60,7 +60,7 @@ public:
                 const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
                 acc.assign((size_t)nd * CE, 0.0);
                 for (int n = 0; n < nn; ++n)
-                    for (int d = 0; d < 3; ++d) { xs[3 * n + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
+                    for (int d = 0; d < 3; ++d) { xs[3 * C.tslot[off + n] + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
                 auto sbit = [&](int lane, int a) { return (K.sgn[((size_t)kci * W + a / 32) * CE + lane] >> (a % 32)) & 1u; };
                 auto subc = [&](int lane) { return (int)(K.sgn[((size_t)kci * W + W - 1) * CE + lane] >> 24); };
                 for (int lane = 0; lane < CE; ++lane) {
@@ -86,9 +86,10 @@ public:
                 for (int n = 0; n < nn; ++n) {
                     const int32_t dst = C.dst[off + n];
                     double *out = dst >= 0 ? y + dst : &ebuf_[(size_t)(-dst - 1) * 3];
+                    const int sl = C.tslot[off + n];
                     for (int d = 0; d < 3; ++d) {
-                        out[d] = ys[3 * n + d];
-                        if (fuse && dst >= 0 && dst + d >= dot_lo && own_free(dst + d)) dot_spmv_ += xs[3 * n + d] * ys[3 * n + d];
+                        out[d] = ys[3 * sl + d];
+                        if (fuse && dst >= 0 && dst + d >= dot_lo && own_free(dst + d)) dot_spmv_ += xs[3 * sl + d] * ys[3 * sl + d];
                     }
                 }
             }
