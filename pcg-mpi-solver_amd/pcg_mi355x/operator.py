@@ -287,6 +287,31 @@ class Operator:
             pass
 
 
+def _blocked_node_order(xyz, is_b, block=8):
+    """Old node ids in the order the matrix-free engine numbers them: interface nodes first (as always), then the
+    interior nodes block by block of the node lattice (block = 8 lattice units = the edge of a 512-element chunk,
+    csrc/ebe.cpp), inside a block the nodes strictly inside it before those on its low faces, x fastest.
+    A chunk's own (exclusive) nodes - coordinates 8i+1 .. 8i+7 - then occupy ONE contiguous index range, so the chunk's
+    x-tile load and y store are contiguous in memory instead of 9-node runs 1.2 kB apart."""
+    c = np.asarray(xyz, float).reshape(-1, 3)
+    lo = c.min(axis=0)
+    h = []
+    for d in range(3):                                     # lattice unit: smallest spacing between node planes
+        u = np.unique(c[:, d])
+        h.append(float(np.diff(u).min()) if len(u) > 1 else 1.0)
+    ijk = np.floor((c - lo) / np.array(h) + 1e-6).astype(np.int64)
+    if ijk.max() >= (1 << 20):
+        return None
+    blk = ijk // block
+    loc = ijk - blk * block
+    nb = blk.max(axis=0) + 1
+    on_face = (loc == 0).any(axis=1)
+    key = ((((blk[:, 2] * nb[1] + blk[:, 1]) * nb[0] + blk[:, 0]) * 2 + on_face) * block + loc[:, 2]) * block * block \
+        + loc[:, 1] * block + loc[:, 0]
+    interior = np.flatnonzero(~is_b)
+    return np.concatenate([np.flatnonzero(is_b), interior[np.argsort(key[interior], kind="stable")]])
+
+
 def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell", ebe_chunked=True):
     """Build the GPU operator of one RefMeshPart (see module docstring for the keys read).
     kind: "sell" = assembled SELL-BSR3 matrix (default), "ebe" = matrix-free element-by-element."""
@@ -300,17 +325,20 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
     node_perm = None
     dof_map = None
     n_bnd = 0
-    if len(nbr):
+    xyz = part.get("NodeCoordVec")              # (3*NNode,) x,y,z per node (partition_mesh.py:357); optional
+    blocked = kind == "ebe" and xyz is not None and os.environ.get("PCG_EBE_BLOCKED_ORDER", "1") == "1"
+    if len(nbr) or blocked:
         is_b = np.zeros(n_nodes, bool)
         for v in ovl:
             is_b[v // 3] = True
-        order = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])     # old ids, interface first
+        order = _blocked_node_order(xyz, is_b) if blocked else None
+        if order is None:
+            order = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])     # old ids, interface first
         node_perm = np.empty(n_nodes, np.int64)
         node_perm[order] = np.arange(n_nodes)
         n_bnd = int(is_b.sum())
         dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
     if kind == "ebe":
-        xyz = part.get("NodeCoordVec")          # (3*NNode,) x,y,z per node (partition_mesh.py:357); optional
         op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm,
                       node_coords=xyz, ebe_chunked=ebe_chunked)
     elif kind == "sell":

@@ -327,8 +327,10 @@ def test_ebe_matrix_core_kernel_vs_oracle(gpu_lib, monkeypatch, n_types, ept):
     op = from_refmeshpart(P, kind="ebe")
     rng = np.random.default_rng(21)
     x = rng.standard_normal(b.n_dof)
-    y = np.empty(b.n_dof); pxy = C.c_double()
-    check(op._L.pcg_k_spmv_local(op._h, x.ctypes.data, y.ctypes.data, C.byref(pxy)))
+    xe = op.to_engine(x)                                                      # the engine numbers nodes block-wise
+    ye = np.empty(b.n_dof); pxy = C.c_double()
+    check(op._L.pcg_k_spmv_local(op._h, xe.ctypes.data, ye.ctypes.data, C.byref(pxy)))
+    y = op.from_engine(ye)
     ref = pcg_oracle.matvec_local(P, x)
     assert relerr(y, ref) < 1e-13
     assert abs(pxy.value - np.dot(x[P["LocDofEff"]], ref[P["LocDofEff"]])) <= 1e-12 * np.dot(np.abs(x), np.abs(ref))
