@@ -19,3 +19,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o k -- python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-finish > "$OUT/pmc_${c}_bench.json" 2> "$OUT/pmc_$c.log"
   f=$(ls "$OUT/pmc_$c"/*.db 2>/dev/null | head -1); [ -n "$f" ] && python "$R/tools/rocpd_summary.py" "$f" "$OUT/pmc_$c/summary.md" && grep -E "k_spmv|k_ebe|k_fused|k_update" "$OUT/pmc_$c/summary.md" | grep "$c"
 done
+cd "$R"
+echo "== bench 1M dof (BASELINE configs[1])"; timeout 600 python bench.py --nodes-per-side 70 --steps 300 > "$OUT/bench_n70.json" 2> "$OUT/bench_n70.log"; cut -c1-300 "$OUT/bench_n70.json"; echo
