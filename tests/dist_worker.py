@@ -48,6 +48,13 @@ def main():
         P = pc.prepare_for_solve(partition_model(model, ele_part, only=[rank]))[0]
         x = np.cos(0.37 * P["DofVector"])
         out["DofVector"] = P["DofVector"]
+    elif case.startswith("brick:"):             # brick:<N>:<n_types>:<px>x<py>x<pz> - this rank's part only (make_parts(only=))
+        from pcg_mi355x.brick import Brick, make_parts, block_partition
+        _, n, nt, grid = case.split(":")
+        brick = Brick(int(n), n_types=int(nt))
+        P = make_parts(brick, block_partition(brick, *[int(v) for v in grid.split("x")]), only=[rank])[0]
+        x = np.cos(0.37 * P["DofVector"])
+        out["DofVector"] = P["DofVector"]
     else:
         brick, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
         assert len(parts) == world, (len(parts), world)

@@ -60,3 +60,28 @@ def test_multi_rank_raise(tmp_path):
     outs = run_dist("n9_p2_raise", 2, "gloo", "hostops", tmp_path, 29615)
     for o in outs:
         assert str(o["raised"]) == "PCG : TooSmallTolerance"
+
+
+@pytest.mark.parametrize("kind,port", [("sell", 29650), ("ebe", 29652)])
+def test_eight_ranks_match_one_rank_at_mid_size(tmp_path, hostops, kind, port):
+    """46 875 dof split 2x2x2 (face, edge and corner neighbours, every rank builds only ITS part) against the same
+    system on one rank: same Flag and iteration count (+-1), same solution, same operator on a probe vector."""
+    import pcg_mi355x as pm
+    from pcg_mi355x.brick import Brick, make_parts
+    b = Brick(25, n_types=2)
+    P = make_parts(b)[0]
+    pm.configure(comm=None, operator=kind)
+    try:
+        y1 = pm.calc_mpfint(np.cos(0.37 * P["DofVector"]), P)
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    finally:
+        pm.configure(comm=None)
+    i1 = P["_pcg_mi355x_info"]
+    outs = run_dist("brick:25:2:2x2x2", 8, "gloo", "hostops", tmp_path, port, extra=(kind,))
+    U, Y = np.zeros(b.n_dof), np.zeros(b.n_dof)
+    for o in reversed(outs):
+        U[o["DofVector"]] = o["Un"]; Y[o["DofVector"]] = o["y_probe"]
+    assert relerr(Y, y1) < 1e-13
+    assert int(outs[0]["flag"]) == i1.flag == 0 and abs(int(outs[0]["iter"]) - i1.iter) <= 1
+    assert relerr(U, P["Un"]) < 2e-7
+    assert all(int(o["iter"]) == int(outs[0]["iter"]) for o in outs)
