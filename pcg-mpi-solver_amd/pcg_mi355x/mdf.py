@@ -30,7 +30,7 @@ import numpy as np
 from .io import exportz, importz
 
 __all__ = ["ELEM_ARRAYS", "FLAT_ARRAYS", "NODAL_ARRAYS", "model_from_brick", "model_from_octree", "write_mdf", "read_mdf",
-           "config_glob_data", "write_mesh_part", "read_mesh_part"]
+           "config_glob_data", "write_mesh_part", "read_mesh_part", "main"]
 
 # name -> (dtype on disk, trailing shape); partition_mesh.py:172-175
 ELEM_ARRAYS = {"NodeGlbOffset": (np.int64, (2,)), "DofGlbOffset": (np.int64, (2,)), "SignOffset": (np.int64, (2,)),
@@ -192,3 +192,41 @@ def write_mesh_part(mdf_path, ele_part):
 
 def read_mesh_part(mdf_path, n_parts):
     return np.load(os.path.join(mdf_path, f"MeshPart_{int(n_parts)}.npy"))     # partition_mesh.py:104-105
+
+
+def main(argv=None):
+    """Write a synthetic model as a model archive (the `concrete.zip` role of examples/run_basic_script.bash:20):
+
+        python -m pcg_mi355x.mdf --brick 70 --out brick70.zip          # SURVEY 8(d) brick, 1 029 000 dof
+        python -m pcg_mi355x.mdf --octree 96 96 40 8 --out oct.zip     # two-level octree mesh with hanging nodes
+    """
+    import argparse
+    import shutil
+    import tempfile
+    ap = argparse.ArgumentParser(description=main.__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    g = ap.add_mutually_exclusive_group(required=True)
+    g.add_argument("--brick", type=int, metavar="N", help="N x N x N nodes")
+    g.add_argument("--octree", type=int, nargs=4, metavar=("NX", "NY", "NZ_FINE", "NZ_COARSE"))
+    ap.add_argument("--types", type=int, default=1, help="pattern types of the brick (sign frames)")
+    ap.add_argument("--out", required=True, help="archive to write (.zip) or directory")
+    args = ap.parse_args(argv)
+    if args.brick:
+        from .brick import Brick
+        model = model_from_brick(Brick(args.brick, n_types=args.types))
+    else:
+        from .octree import TwoLevelMesh
+        model = model_from_octree(TwoLevelMesh(*args.octree))
+    if args.out.endswith(".zip"):
+        tmp = tempfile.mkdtemp(prefix="mdf_")
+        try:
+            write_mdf(tmp, model)
+            shutil.make_archive(args.out[:-4], "zip", tmp)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        write_mdf(args.out, model)
+    print(f">elements:  {model['GlobNElem']}\n>nodes:     {model['GlobNNode']}\n>dofs:      {model['GlobNDof']}\n>written:   {args.out}")
+
+
+if __name__ == "__main__":
+    main()

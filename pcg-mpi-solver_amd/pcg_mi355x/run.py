@@ -86,7 +86,10 @@ def main(argv=None):
     ap.add_argument("--mdf", default=None, help="instead of partition files: an MDF directory (with MeshPart_<N>.npy or none "
                                                 "-> coordinate bisection); every rank builds ONLY its own part in memory")
     ap.add_argument("--n-parts", type=int, default=None, help="defaults to WORLD_SIZE")
-    ap.add_argument("--settings", default="__pycache__/GlobSettings.zpkl")
+    ap.add_argument("--settings", default=None, help="GlobSettings.zpkl (examples/run_basic_script.bash:30-49); default: "
+                                                     "one load step, --tol, --max-iter, export U")
+    ap.add_argument("--tol", type=float, default=1e-7)
+    ap.add_argument("--max-iter", type=int, default=10000)
     ap.add_argument("--results", required=True, help="result directory (Results_Run<R>)")
     ap.add_argument("--operator", choices=["sell", "ebe"], default="sell")
     ap.add_argument("--speed-test", action="store_true")
@@ -126,7 +129,11 @@ def main(argv=None):
         del model
     else:
         part = read_partition(args.partition_prefix, n_parts, rank, gd)   # :980
-    apply_settings(gd, importz(args.settings), args.speed_test)       # :981
+    settings = importz(args.settings) if args.settings else {                # examples/run_basic_script.bash:34-44
+        "TimeHistoryParam": {"ExportFlag": True, "ExportFrmRate": 1, "ExportFrms": [], "PlotFlag": False,
+                             "TimeStepDelta": [0, 1], "ExportVars": "U"},
+        "SolverParam": {"Tol": args.tol, "MaxIter": args.max_iter}}
+    apply_settings(gd, settings, args.speed_test)                            # :981
     gd["MP_TimeRecData"]["dT_FileRead"] += time.time() - t0
     res_vec = os.path.join(args.results, "ResVecData") + os.sep
     t_start = time.time()

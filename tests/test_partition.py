@@ -158,6 +158,18 @@ SETTINGS = {"TimeHistoryParam": {"ExportFlag": True, "ExportFrmRate": 1, "Export
             "SolverParam": {"Tol": 1e-7, "MaxIter": 10000}}                      # examples/run_basic_script.bash:34-44
 
 
+def test_model_archive_cli(tmp_path):
+    out = str(tmp_path / "oct.zip")
+    mdf.main(["--octree", "4", "4", "2", "2", "--out", out])
+    import shutil
+    shutil.unpack_archive(out, str(tmp_path / "x"))
+    m = mdf.read_mdf(str(tmp_path / "x"))
+    ref, _ = pc.build_model("part_octree_p3")                       # same mesh, no sign frames
+    assert m["GlobNElem"] == ref["GlobNElem"] and np.array_equal(m["NodeGlbFlat"], ref["NodeGlbFlat"])
+    mdf.main(["--brick", "5", "--types", "2", "--out", str(tmp_path / "b")])
+    assert mdf.read_mdf(str(tmp_path / "b"))["GlobNDof"] == 375
+
+
 def test_pipeline_from_model_archive(hostops, tmp_path):
     """model.zip -> prepare (stages 1-3) -> partition files -> load-step driver (stage 4) -> result vectors."""
     import shutil
