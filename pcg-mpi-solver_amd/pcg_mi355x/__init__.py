@@ -9,7 +9,7 @@ missing - there is no CPU path.
 from . import _lib
 from ._lib import PcgError
 from .operator import Operator, from_refmeshpart, assemble_bsr3
-from . import io, run  # noqa: F401  (partition / result files, load-step driver)
+from . import io  # noqa: F401  (partition / result files; the CLI stages run / prepare / mdf are imported on demand)
 from .solver import (configure, get_operator, solve, PCG, update_bc, updateBC, update_preconditioner,
                      updatePreconditioner, calc_matvec_prod, calcMatVecProd, calc_mpfint, calcMPFint,
                      solve_system, SolveInfo)
