@@ -107,7 +107,9 @@ def main():
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # a rank that dies must take the job down in minutes, not after the default 10-minute collective timeout
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
 
     import pcg_mi355x as pm
     from pcg_mi355x import _lib
