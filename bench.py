@@ -111,6 +111,11 @@ def main():
         # a rank that dies must take the job down in minutes, not after the default 10-minute collective timeout
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
 
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build_engine()      # no-op when the in-tree build is current (hipcc --offload-arch=gfx950 otherwise)
+    if world > 1:
+        dist.barrier()
     import pcg_mi355x as pm
     from pcg_mi355x import _lib
     from pcg_mi355x.brick import Brick, make_parts, block_partition, default_grid

@@ -63,6 +63,8 @@ def hostops():
 @pytest.fixture(scope="session")
 def gpu_lib():
     """The product library on a real GPU; fails (does not skip) when it is missing on a GPU box."""
+    import __graft_entry__
+    __graft_entry__.build_engine()          # no-op when the in-tree build is current; a clone without build products compiles it
     from pcg_mi355x import _lib
     _lib.use_library(None)
     assert _lib.backend_name() == "hip-gfx950"
