@@ -145,9 +145,8 @@ typedef struct {
 
 /* inv_diag may be NULL: use the Jacobi vector built by pcg_build_jacobi().
  * hist (may be NULL): rows [NormP, NormX, NormR] per iteration (the :507 allreduce). */
-/* The loop can keep ONE iteration in flight ahead of the host's tests (see pcg_driver.cpp): by default when the
- * part has <= 4 M dofs or communication hooks are set; environment PCG_LOOK_AHEAD=0/1 (read at engine creation)
- * forces it off/on.  Results are bit-identical either way. */
+/* The loop keeps ONE iteration in flight ahead of the host's tests (see pcg_driver.cpp); environment
+ * PCG_LOOK_AHEAD=0 (read at engine creation) turns that off.  Results are bit-identical either way. */
 int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const double *inv_diag,
                     double tol, int64_t max_iter, int64_t glob_n_eff);
 int pcg_solve_run(pcg_engine *e, int64_t n_iters /* <0 = to completion */, double *hist, int64_t hist_cap,

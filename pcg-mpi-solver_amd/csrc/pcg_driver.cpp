@@ -54,11 +54,10 @@ struct pcg_engine {
     bool profiling = false;
     // One-iteration look-ahead of the solve loop (iterate_once).  Measured on MI355X (profiles/r01_look_ahead_ab.json):
     // 1 M dof +5.6 % (assembled) / +10 % (matrix-free) iterations/s, with the Python all-reduce hooks in the loop
-    // +7..11 %; at 10 M dof the 13 us of host gap it removes per 1.4 ms iteration are lost again (the SpMV, now
-    // back-to-back, ran 3 % slower: -1.5 % overall).  Default: on when the part is small enough for the gap to
-    // matter or communication hooks are in the loop; PCG_LOOK_AHEAD=0/1 forces it.
+    // +7..11 %; at 10 M dof matrix-free +1.5 %, assembled between -1.5 % and +1.7 % depending on the box (the SpMV,
+    // then back-to-back with its neighbours, varies by 3 % itself).  On by default; PCG_LOOK_AHEAD=0 turns it off.
     int look_ahead_mode = std::getenv("PCG_LOOK_AHEAD") ? (std::getenv("PCG_LOOK_AHEAD")[0] == '0' ? 0 : 1) : -1;
-    bool look_ahead() const { return look_ahead_mode == 1 || (look_ahead_mode < 0 && (has_hooks || n <= 4000000)); }
+    bool look_ahead() const { return look_ahead_mode != 0; }
 
     double *d_send = nullptr, *d_recv = nullptr, *d_st = nullptr;
     double *v_b = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
