@@ -135,6 +135,11 @@ def main(argv=None):
         "SolverParam": {"Tol": args.tol, "MaxIter": args.max_iter}}
     apply_settings(gd, settings, args.speed_test)                            # :981
     gd["MP_TimeRecData"]["dT_FileRead"] += time.time() - t0
+    if rank == 0 and os.path.exists(args.results) and os.listdir(args.results):      # pcg_solver.py:67-72: never overwrite a run
+        from datetime import datetime
+        os.rename(args.results.rstrip(os.sep), args.results.rstrip(os.sep) + "_" + datetime.now().strftime("%d%m%Y_%H%M%S"))
+    if world > 1:
+        dist.barrier()
     res_vec = os.path.join(args.results, "ResVecData") + os.sep
     t_start = time.time()
     flag, relres, it = run_load_steps(part, res_vec, comm)
