@@ -86,6 +86,26 @@ def main():
         from pcg_mi355x.io import ResultExporter
         ex = ResultExporter(P, os.path.join(outdir, "ResVecData") + os.sep, comm)
         ex.export(1.0)
+    if backend == "nccl":
+        # the halo hook's collective on real RCCL: all_to_all_single on raw-pointer tensor views, issued asynchronously
+        # on the engine's HIP stream (wrapped as an ExternalStream) and waited for stream-side.  World size 1 sends to
+        # itself; the split-size form and the tensor / stream plumbing are the ones halo_begin / halo_end use.
+        op = P["_pcg_mi355x_operator"]
+        n_a2a = 4099
+        a = torch.arange(n_a2a, dtype=torch.float64, device=device) * 0.5
+        b = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        stream_ptr = op._L.pcg_stream(op._h)
+        comm._use_stream(stream_ptr)
+        send, recv = comm._tensor(a.data_ptr(), n_a2a), comm._tensor(b.data_ptr(), n_a2a)
+        splits = [0] * world
+        splits[rank] = n_a2a
+        work = dist.all_to_all_single(recv, send, splits, splits, async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        out["a2a_ok"] = bool(torch.equal(a, b))
+        del send, recv
+        comm._views.clear()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()

@@ -461,3 +461,4 @@ def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     o = outs[0]
     assert int(o["n_allreduce"]) > 200
     check_solution_against_golden(g, int(o["flag"]), int(o["iter"]), float(o["relres"]), o["Un"], o["history"])
+    assert bool(o["a2a_ok"])            # the halo collective (async all_to_all_single on pointer views, engine stream) on RCCL
