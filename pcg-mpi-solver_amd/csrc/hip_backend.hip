@@ -759,7 +759,10 @@ __device__ __forceinline__ void update_one(double alpha, double p, double q, dou
     if (w) { u.sqr += rn * rn; u.rho += z * rn; }                  // :506, :462
 }
 
-__global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restrict__ st, const double *__restrict__ p,
+// ALPHA: st[PQ] holds the all-reduced p.Ap; every block forms alpha / stop itself exactly like k_scalar_alpha (same two
+// doubles, same division), block 0 stores them - the separate one-thread launch of the multi-GPU loop is gone.
+template <bool ALPHA>
+__global__ __launch_bounds__(kBlock) void k_fused_update(double *st, double *mirror, const double *__restrict__ p,
                                                          const double *__restrict__ q, const double *__restrict__ r,
                                                          double *__restrict__ rn, const double *__restrict__ xo,
                                                          double *__restrict__ xn,
@@ -768,8 +771,17 @@ __global__ __launch_bounds__(kBlock) void k_fused_update(const double *__restric
 {
     __shared__ double lds[5 * kWavesPerBlock];
     Up u = {0, 0, 0, 0, 0};
-    if (st[ST_STOP] == 0.0) {                                      // frozen when pq/alpha broke down (:492-498)
-        const double alpha = st[ST_ALPHA];
+    double stop = st[ST_STOP], alpha = st[ST_ALPHA];
+    if constexpr (ALPHA) {                                         // :492-498; the sticky stop flag only ever goes 0 -> 1
+        const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
+        if (pq <= 0.0 || isinf(pq)) stop = 1.0;
+        else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st[ST_RHO] = rho; st[ST_ALPHA] = alpha; st[ST_STOP] = stop;
+            if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
+        }
+    }
+    if (stop == 0.0) {                                             // frozen when pq/alpha broke down (:492-498)
         const int64_t n2 = n >> 1;
         const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
         const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
@@ -1318,12 +1330,16 @@ public:
         hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, n_);
         HIP_CHECK(hipGetLastError());
     }
-    void fused_update(const double *st, const double *p, const double *q, const double *r, double *rn, const double *xo,
-                      double *xn, const double *minv) override
+    void fused_update(double *st, const double *p, const double *q, const double *r, double *rn, const double *xo, double *xn,
+                      const double *minv, bool with_alpha) override
     {
         cnt_vec_ = vec_grid(n_);
-        hipLaunchKernelGGL(k_fused_update, dim3(cnt_vec_), dim3(kBlock), 0, st_, st, p, q, r, rn, xo, xn, minv, d_flags_, d_part_,
-                           n_);
+        if (with_alpha)
+            hipLaunchKernelGGL((k_fused_update<true>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, mirror_of(st), p, q, r, rn, xo, xn, minv,
+                               d_flags_, d_part_, n_);
+        else
+            hipLaunchKernelGGL((k_fused_update<false>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, (double *)nullptr, p, q, r, rn, xo, xn,
+                               minv, d_flags_, d_part_, n_);
         HIP_CHECK(hipGetLastError());
     }
     void reduce_update(double *red5) override

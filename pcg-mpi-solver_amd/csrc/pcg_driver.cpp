@@ -212,14 +212,15 @@ struct pcg_engine {
         be->set_status_slot(slot);
         be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first);     // :447, :472-479
         apply(p_out, v_q, true);                                            // :482-484
+        bool alpha_in_update = false;
         if (!has_hooks && !(kind == 1 && !ebe_dot_fused)) {
             be->reduce_dot_alpha(d_st);                                     // :487-498, one launch (no all-reduce in between)
         } else {
             reduce_apply_dot(d_st + ST_PQ);                                 // :487
             allreduce(d_st + ST_PQ, 1);                                     // :488
-            be->scalar_alpha(d_st);                                         // :492-498 (device side)
+            alpha_in_update = true;                                         // :492-498 inside the update kernel
         }
-        be->fused_update(d_st, p_out, v_q, r_in, r_out, x_in, x_out, s.minv);   // :501-516 (+ :447-462 of i+1)
+        be->fused_update(d_st, p_out, v_q, r_in, r_out, x_in, x_out, s.minv, alpha_in_update);   // :501-516 (+ :447-462 of i+1)
         be->reduce_update(d_st + ST_SQP);
         allreduce(d_st + ST_SQP, 5);                                        // :507 (+ next rho, inf count)
         be->publish_status(has_hooks);

@@ -186,8 +186,10 @@ public:
                           double rho_prev, bool first) = 0;
     // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r_new = r_old - alpha q ; sum r^2 w ; x_new = x_old + alpha p ;
     // z = M^-1 r ; sum z r w ; count of inf in z.  Partials -> reduce_update().   (:501-516,:447-462)
-    virtual void fused_update(const double *st, const double *p, const double *q, const double *r_old, double *r_new,
-                              const double *x_old, double *x_new, const double *minv) = 0;
+    // with_alpha: alpha / stop are formed here from st[PQ] (already all-reduced) and st[RHO_NEXT] exactly like
+    // scalar_alpha(), by every block for itself; the separate one-thread launch disappears from the multi-GPU loop.
+    virtual void fused_update(double *st, const double *p, const double *q, const double *r_old, double *r_new,
+                              const double *x_old, double *x_new, const double *minv, bool with_alpha = false) = 0;
     virtual void reduce_update(double *red5) = 0;
     // r = b - ax ; sums r^2 w, (M^-1 r) r w, inf count                      (:413-416,:530-533)
     virtual void residual(const double *b, const double *ax, double *r, const double *minv) = 0;

@@ -214,9 +214,10 @@ public:
             po[i] = first ? z : z + beta * pi[i];
         }
     }
-    void fused_update(const double *st, const double *p, const double *q, const double *r, double *rnew, const double *xo,
-                      double *xn, const double *minv) override
+    void fused_update(double *st, const double *p, const double *q, const double *r, double *rnew, const double *xo,
+                      double *xn, const double *minv, bool with_alpha) override
     {
+        if (with_alpha) scalar_alpha(st);
         for (double &v : up_) v = 0;
         if (st[ST_STOP] != 0) return;
         const double alpha = st[ST_ALPHA];
