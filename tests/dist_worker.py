@@ -48,6 +48,12 @@ def main():
         P = pc.prepare_for_solve(partition_model(model, ele_part, only=[rank]))[0]
         x = np.cos(0.37 * P["DofVector"])
         out["DofVector"] = P["DofVector"]
+    elif case.startswith("files:"):             # files:<partition prefix>: this rank's <N>_<rank>.mpidat, as pcg_solver.py:88-110 reads it
+        import partition_cases as pc
+        from pcg_mi355x.io import read_partition
+        P = pc.prepare_for_solve([read_partition(case.split(":", 1)[1], world, rank)])[0]
+        x = np.cos(0.37 * P["DofVector"])
+        out["DofVector"] = P["DofVector"]
     elif case.startswith("brick:"):             # brick:<N>:<n_types>:<px>x<py>x<pz> - this rank's part only (make_parts(only=))
         from pcg_mi355x.brick import Brick, make_parts, block_partition
         _, n, nt, grid = case.split(":")

@@ -153,6 +153,23 @@ def test_mdf_to_solution_matches_reference_pipeline(hostops, name, kind, tmp_pat
                                       tol_iter=tol_iter)
 
 
+def test_partition_files_feed_a_multi_rank_solve(hostops, tmp_path):
+    """Stage 3 -> stage 4 through the files: prepare() writes 3 partition files (the fixture's ElePart), three ranks
+    read ONE file each like the reference's readModelData and solve; result = the reference pipeline's solution."""
+    from pcg_mi355x import prepare
+    from util import run_dist
+    g = golden("part_octree_p3")
+    model, ele_part = pc.build_model("part_octree_p3")
+    mdf.write_mdf(str(tmp_path / "model"), model)
+    prefix = prepare.prepare(str(tmp_path / "model"), str(tmp_path / "scratch"), 3, ele_part=ele_part, log=lambda m: None)
+    assert sorted(f for f in os.listdir(prefix) if f.endswith(".mpidat")) == ["3_0.mpidat", "3_1.mpidat", "3_2.mpidat"]
+    res = run_dist("files:" + prefix, 3, "gloo", "hostops", tmp_path, 29690)
+    un = np.zeros(model["GlobNDof"])
+    for r in reversed(res):
+        un[r["DofVector"]] = r["Un"]
+    check_solution_against_golden(g, int(res[0]["flag"]), int(res[0]["iter"]), float(res[0]["relres"]), un, None, tol_iter=1)
+
+
 SETTINGS = {"TimeHistoryParam": {"ExportFlag": True, "ExportFrmRate": 1, "ExportFrms": [], "PlotFlag": False,
                                  "TimeStepDelta": [0, 1], "ExportVars": "U"},
             "SolverParam": {"Tol": 1e-7, "MaxIter": 10000}}                      # examples/run_basic_script.bash:34-44
