@@ -80,6 +80,25 @@ def test_randomised_load_steps_vs_oracle(hostops, oracle_c, seed, kind):
         assert np.abs(info.history[:m, 2] / ref["history"][:m, 2] - 1).max() < 1e-10
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("N", [2, 3])
+def test_smallest_meshes(hostops, N, kind):
+    """One element (8 nodes, 4 of them fixed: one SELL slice, one chunk, one padded tile) and eight elements."""
+    import copy
+    import pcg_oracle
+    from pcg_mi355x.brick import Brick, make_parts
+    P = make_parts(Brick(N))[0]
+    Q = copy.deepcopy(P)
+    ref = pcg_oracle.solve_step([Q])
+    pm.configure(comm=None, operator=kind)
+    try:
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    finally:
+        pm.configure(comm=None)
+    info = P["_pcg_mi355x_info"]
+    assert (info.flag, info.iter) == (ref["flag"], ref["iter"]) and relerr(P["Un"], Q["Un"]) < 1e-10
+
+
 def test_functional_api_and_resume(hostops):
     """solve_system() + begin/run/end in several chunks gives the identical result."""
     brick, parts = golden_cases.build_case("n9_p1")

@@ -230,6 +230,22 @@ def test_look_ahead_changes_nothing_on_gpu(gpu_lib, monkeypatch, case, kind):
     assert 0 <= on[3] - off[3] <= 2
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("N", [2, 3])
+def test_smallest_meshes_on_gpu(gpu_lib, N, kind):
+    """One element and eight elements: grids of one block, one partly filled slice / chunk / tile."""
+    P = make_parts(Brick(N))[0]
+    Q = copy.deepcopy(P)
+    ref = pcg_oracle.solve_step([Q])
+    pm.configure(comm=None, device=0, operator=kind)
+    try:
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    finally:
+        pm.configure(comm=None, device=0, operator="sell")
+    info = P["_pcg_mi355x_info"]
+    assert (info.flag, info.iter) == (ref["flag"], ref["iter"]) and relerr(P["Un"], Q["Un"]) < 1e-10
+
+
 def test_full_size_1m_properties(gpu_lib, oracle_c):
     """BASELINE configs[1] size (N=70, 1 029 000 dof): oracle mat-vec parity on one vector, linearity,
     symmetry, rigid-body null space, and a full solve whose TRUE residual is re-checked by the oracle."""
