@@ -85,3 +85,20 @@ def test_eight_ranks_match_one_rank_at_mid_size(tmp_path, hostops, kind, port):
     assert int(outs[0]["flag"]) == i1.flag == 0 and abs(int(outs[0]["iter"]) - i1.iter) <= 1
     assert relerr(U, P["Un"]) < 2e-7
     assert all(int(o["iter"]) == int(outs[0]["iter"]) for o in outs)
+
+
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("case", ["n9_p2", "n9_p8", "oct_p3"])
+def test_parts_in_threads_on_the_test_double(hostops, case, kind):
+    """tests/thread_comm.py (the in-process communicator the GPU suite uses to run several parts on one GPU) checked
+    here on the CPU double against the same fixtures as the gloo runs."""
+    from thread_comm import solve_parts_in_threads
+    mesh, parts = golden_cases.build_case(case)
+    g = golden(case)
+    infos = solve_parts_in_threads(parts, kind, on_gpu=False)
+    U = np.zeros(len(g["Un"]))
+    for p in reversed(parts):
+        U[p["DofVector"]] = p["Un"]
+    i0 = infos[0]
+    assert all((i.flag, i.iter) == (i0.flag, i0.iter) for i in infos)
+    check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0)

@@ -469,6 +469,25 @@ def test_octree_mesh_with_hanging_nodes(gpu_lib, oracle_c, kind):
     assert relerr(P["Un"], R["Un"]) < 2e-7
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("case", ["n9_p2", "n9_p8", "n9_p2_flag4", "oct_p3", "oct_p2_z"])
+def test_multi_part_kernels_on_one_gpu(gpu_lib, case, kind):
+    """2..8 mesh parts as 2..8 engines on THE SAME GPU, one thread per part, exchanging through tests/thread_comm.py:
+    interface-first ordering, k_halo_pack, k_fixup (+ its dot), the boundary / interior launches of both operators and
+    the all-reduce hooks inside the look-ahead loop run on the real device and must reproduce the reference fixtures."""
+    from thread_comm import solve_parts_in_threads
+    mesh, parts = golden_cases.build_case(case)
+    g = golden(case)
+    infos = solve_parts_in_threads(parts, kind, on_gpu=True)
+    U = np.zeros(len(g["Un"]))
+    for p in reversed(parts):
+        U[p["DofVector"]] = p["Un"]
+    i0 = infos[0]
+    assert all((i.flag, i.iter) == (i0.flag, i0.iter) for i in infos)
+    tol_u = 1e-8 if i0.flag == 0 else 1e-6
+    check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0, tol_u=tol_u)
+
+
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     """The RCCL comm hooks on the GPU (world_size 1 on the 1-GPU box): device-pointer views, the
     engine stream as ExternalStream, all_reduce in place.  Must equal the hook-free run."""
