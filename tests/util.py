@@ -37,11 +37,19 @@ def run_dist(case, nproc, backend, libkind, outdir, port, timeout=600, extra=())
     return [np.load(os.path.join(outdir, f"rank{k}.npz")) for k in range(nproc)]
 
 
-def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol_u=1e-8, n_hist=100):
+def check_solution_against_golden(g, flag, it, relres, Un, hist, tol_iter=0, tol_u=1e-8, n_hist=100, tol=1e-7):
     """Parity gates: same Flag, same iteration count, final relres <= Tol when
     converged, solution <= tol_u relative, residual history <= 1e-10 relative over the first iterations
     (CG's rounding sensitivity makes late recurrence residuals incomparable on any hardware)."""
     assert flag == int(g["flag"])
+    # Exit iteration: exact, unless the reference itself passed Tol by a hair: its last relres within 5 % below Tol
+    # (oct_p3: 0.9995e-7 at iteration 71) or the one before within 5 % above (part_octree_p3: 1.018e-7 at 52 of 53).
+    # That late in a CG run rounding decides on which side a run lands (reference 1 part vs 2 parts: 2e-2 at 100/118).
+    if flag == 0 and "history" in g and len(g["history"]) > 1 and float(g["relres"]) > 0:
+        h = g["history"][:, 2]
+        normb = h[-1] / float(g["relres"])
+        if h[-1] / normb > 0.95 * tol or h[-2] / normb < 1.05 * tol:
+            tol_iter = max(tol_iter, 1)
     assert abs(it - int(g["iter"])) <= tol_iter, (it, int(g["iter"]))
     # a +-1 iteration exit returns a neighbouring iterate: both satisfy Tol, they differ at the Tol * cond level
     assert relerr(Un, g["Un"]) < (tol_u if it == int(g["iter"]) else 20 * tol_u), relerr(Un, g["Un"])
