@@ -488,6 +488,33 @@ def test_multi_part_kernels_on_one_gpu(gpu_lib, case, kind):
     check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0, tol_u=tol_u)
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_eight_parts_on_one_gpu_match_one_part_at_mid_size(gpu_lib, kind):
+    """107 811 dof split 2x2x2 (interfaces of several thousand dofs: multi-block halo kernels, boundary and interior
+    launches of real size) as eight engines on one GPU against the same system as ONE engine."""
+    from thread_comm import solve_parts_in_threads
+    from pcg_mi355x.brick import block_partition
+    b = Brick(33, n_types=2)
+    one = make_parts(b)[0]
+    pm.configure(comm=None, device=0, operator=kind)
+    try:
+        pm.update_bc(one); pm.update_preconditioner(one); pm.solve(one)
+    finally:
+        pm.configure(comm=None, device=0, operator="sell")
+    i1 = one["_pcg_mi355x_info"]
+    parts = make_parts(b, block_partition(b, 2, 2, 2))
+    infos = solve_parts_in_threads(parts, kind, on_gpu=True)
+    U = np.zeros(b.n_dof)
+    for p in reversed(parts):
+        U[p["DofVector"]] = p["Un"]
+    assert infos[0].flag == i1.flag == 0 and abs(infos[0].iter - i1.iter) <= 1
+    assert all(i.iter == infos[0].iter for i in infos)
+    assert relerr(U, one["Un"]) < 2e-7
+    eff = one["LocDofEff"]
+    r = (one["Fext"] - pcg_oracle.matvec_local(one, U))[eff]                  # the assembled 8-part solution solves the system
+    assert np.linalg.norm(r) / np.linalg.norm(one["Fext"][eff]) < 1.1e-7
+
+
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     """The RCCL comm hooks on the GPU (world_size 1 on the 1-GPU box): device-pointer views, the
     engine stream as ExternalStream, all_reduce in place.  Must equal the hook-free run."""
