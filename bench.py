@@ -2,27 +2,40 @@
 """bench.py - PCG iterations/sec + SpMV achieved HBM GB/s on the BASELINE.json workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+      N = 1 runs in this process.  N > 1: bench.py launches its own N ranks (python -m torch.distributed.run ...
+      bench.py, one rank per GPU) unless it already runs inside such a launch (RANK / WORLD_SIZE in the environment),
+      so both `python bench.py --gpus 8` and `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` work.
 
-A "step" is ONE full PCG iteration of the reference algorithm (src/solver/pcg_solver.py:438-562:
-operator apply + interface exchange, the weighted dots, the vector updates, the status read-back)
-on the synthetic 10M-DOF elasticity brick of SURVEY.md 8(d) (N=150 nodes per side, n=10 125 000,
-nnz=809 238 528), with every input already resident in HBM.  W warm-up iterations, then exactly K
-timed iterations between barrier+synchronize fences; the max over ranks is reported.  N>1 runs the
-SAME 10M system split into N parts, one part per GPU (strong scaling, BASELINE configs[3]).
+A "step" is ONE full PCG iteration of the reference algorithm (src/solver/pcg_solver.py:438-562: operator apply +
+interface exchange, the weighted dots, the vector updates, the status read-back) on the synthetic elasticity brick of
+SURVEY.md 8(d) (default N=150 nodes per side: n = 10 125 000, nnz = 809 238 528 = the metric's configuration;
+--nodes-per-side 322 is the 100 M-dof system of BASELINE configs[4]), inputs resident in HBM.  W warm-up iterations,
+then exactly K timed iterations between barrier + synchronize fences; the max over ranks is reported.  N > 1 splits the
+SAME system into N parts, one per GPU (strong scaling); every rank builds only its own part and operator.  The
+multi-GPU data path is the engine's native communicator (csrc/rccl_comm.hip): grouped ncclSend/ncclRecv on a
+communication stream overlapped with the interior rows, two ncclAllReduce per iteration - no Python in the loop.
 
-Extra objects on the JSON line:
-  roofline     - the SpMV kernel (dominant): ALGORITHMIC bytes 12*nnz + 20*n (the stored
-                 SELL-BSR3 format moves fewer bytes, reported as impl_*) / mean kernel time measured
-                 with HIP events on the engine stream inside the timed region; peak 8 TB/s.
-  cpu_baseline - the oracle (C port of the reference's EBE mat-vec + NumPy vector ops, 1 thread, as
-                 the reference pins its BLAS) timed on a bounded sample of the same system.
+Objects on the JSON line besides the contract's fields:
+  roofline     - dominant kernel k_spmv: PHYSICAL bytes of the stored operator per launch (pcg_operator_cost: 76 B per
+                 stored 3x3 block + x in + y out) / mean launch time from HIP events on the engine stream inside the
+                 timed region -> achieved GB/s, frac = achieved / 8 TB/s (<= 1 by construction).  The SURVEY 8(d)
+                 CSR-equivalent figure (12 nnz + 20 n: what a scalar-CSR kernel would have to move) is reported
+                 separately as csr_equivalent_*; `hbm_copy_GBps` is a device copy measured in this run on this box.
+  matrix_free  - the reference's element-by-element operator on the same system, with its own roofline object
+                 (flops vs the 78.6 TF f64 vector peak and bytes vs 8 TB/s).
+  comm         - N > 1: transport, ranks seen by RCCL, per-iteration exchange wait / all-reduce time (HIP events,
+                 measured in a second, separately timed window), per-rank ms per step.
+  cpu_baseline - the oracle (reference algorithm, kind "port") on the node's host cores: R = min(cores, 64) processes,
+                 one part and one thread each - the reference's own mode - plus the 1-core figure.
+  box          - GPU clocks / power cap / partition modes of the box the numbers come from.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,21 +47,84 @@ for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(k, "1")          # the reference's mode (pcg_solver.py:10-15); set before NumPy loads
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
+F64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: f64 vector = f64 matrix peak
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(part, budget_s=20.0):
-    """Reference algorithm on the host: oracle (kind 'port'), 1 rank x 1 thread, bounded sample."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nodes-per-side", type=int, default=int(os.environ.get("PCG_BENCH_N", "150")),
+                    help="brick size N (150 -> 10M dof = the metric's configuration; 70 -> 1M; 322 -> 100M = BASELINE configs[4])")
+    ap.add_argument("--workload", choices=["brick", "octree"], default="brick",
+                    help="brick = SURVEY 8(d) uniform brick (the metric's configuration); octree = two-level 2:1 graded mesh with "
+                         "hanging-node transition patterns, ~1.2 M dof (BASELINE configs[1] names an octree mesh)")
+    ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
+    ap.add_argument("--operator", choices=["sell", "ebe", "both"], default="both",
+                    help="sell = assembled SELL-BSR3 matrix (the headline value/roofline); both = also time the matrix-free operator")
+    ap.add_argument("--comm", choices=["native", "torch"], default=os.environ.get("PCG_BENCH_COMM", "native"),
+                    help="N > 1: native = RCCL calls issued by the engine (default); torch = torch.distributed callbacks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ranks", type=int, default=0, help="processes of the multi-core CPU baseline (0 = min(cores, 64))")
+    ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` outside any distributed launch spawns the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    def run(extra_env):
+        env = dict(os.environ)
+        env.update(extra_env)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log("launching", args.gpus, "ranks:", " ".join(cmd[1:8]), "...")
+        return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    r = run({})
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if (r.returncode != 0 or not line) and args.comm == "native" and os.environ.get("PCG_BENCH_NO_RETRY") != "1":
+        # keep the scaling point measurable if the native communicator cannot come up on this node: same kernels, same
+        # RCCL, but the collectives are issued through torch.distributed callbacks; the line says which transport ran
+        log(f"native-communicator run failed (rc {r.returncode}); retrying with --comm torch")
+        r = run({"PCG_BENCH_COMM": "torch", "PCG_BENCH_NATIVE_FAILED": "1"})
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    return r.returncode if r.returncode != 0 else (0 if line else 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-side reference timings
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_single(part, budget_s=10.0):
+    """Reference algorithm on ONE host core: oracle (kind 'port'), 1 rank x 1 thread, bounded sample."""
     import copy
-    import subprocess
+    import numpy as np
     import pcg_oracle
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     P = {k: v for k, v in part.items() if not k.startswith("_pcg_mi355x")}
@@ -63,53 +139,107 @@ def cpu_baseline(part, budget_s=20.0):
     t0 = time.perf_counter()
     out = pcg_oracle.pcg([P], use_c=True, record=False)
     t = time.perf_counter() - t0
-    return {"value": m / t, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"first {m} PCG iterations of the same system (MaxIter={m}, {out['n_matvec']} EBE mat-vecs incl. "
-                      f"initial and final residual), oracle/pcg_oracle.py + oracle/ebe_matvec.c, 1 thread",
-            "matvec_ms": t_mv * 1e3, "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count()}
+    return {"value": m / t, "unit": "iterations/s", "cores": 1,
+            "sample": f"first {m} PCG iterations of the same system ({out['n_matvec']} EBE mat-vecs), 1 process x 1 thread",
+            "matvec_ms": t_mv * 1e3}
 
 
-def _cpu_model():
+def cpu_baseline(part, N, ranks=0, workload="brick"):
+    """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core."""
+    avail = len(os.sched_getaffinity(0))
+    single = cpu_baseline_single(part)
+    out = {"kind": "port", "unit": "iterations/s", "host_cpu": _cpu_model(), "host_cores_available": avail,
+           "single_core": single}
+    R = ranks or min(avail, 64)
+    if workload != "brick" or R < 2:
+        out.update(value=single["value"], cores=1, sample=single["sample"])
+        return out
+    iters = int(max(10, min(200, 15.0 * single["value"] * R * 0.5)))     # ~15 s of solve at half-ideal speed-up
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mp_baseline.py"), "--nodes-per-side", str(N), "--ranks", str(R),
+                            "--iters", str(iters)], capture_output=True, text=True, timeout=600)
+        mp = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out.update(value=mp["value"], cores=R,
+                   sample=f"first {iters} PCG iterations of the same system split into {R} parts ({'x'.join(map(str, mp['grid']))} blocks), "
+                          f"{R} processes x 1 thread = the reference's one-part-per-rank mode (oracle/mp_baseline.py: pcg_oracle.py + "
+                          f"ebe_matvec.c per rank, shared-memory exchange)",
+                   calc_s_mean=mp["calc_s_mean"], comm_wait_s_mean=mp["comm_wait_s_mean"], t_solve_s=mp["t_solve_s"],
+                   dofs_per_rank_max=mp["dofs_per_rank_max"])
+    except Exception as ex:      # noqa: BLE001 - the GPU line must survive a failure of the CPU side measurement
+        log(f"multi-process CPU baseline failed: {ex!r}")
+        out.update(value=single["value"], cores=1, sample=single["sample"], multi_core_error=repr(ex))
+    return out
+
+
+def box_identity(dev):
+    """What distinguishes one MI355X box from another for a bandwidth-bound kernel."""
+    import torch
+    info = {"hostname": socket.gethostname()}
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        info.update(name=p.name, arch=getattr(p, "gcnArchName", ""), cus=p.multi_processor_count, hbm_GiB=round(p.total_memory / 2**30, 1))
+    except Exception:      # noqa: BLE001
         pass
-    return "unknown"
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(dev), "--showclocks", "--showmaxpower", "--showpower", "--showmemorypartition",
+                            "--showcomputepartition", "--showperflevel", "--json"], capture_output=True, text=True, timeout=30)
+        js = json.loads(r.stdout[r.stdout.index("{"):])
+        card = next(iter(js.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "partition", "performance level")):
+                keep[k] = v
+        info["rocm_smi"] = keep
+    except Exception as ex:      # noqa: BLE001
+        info["rocm_smi_error"] = repr(ex)[:200]
+    return info
 
 
+def hbm_copy_GBps(dev, gib=1.0, reps=20):
+    """Device-to-device copy bandwidth of THIS box (read + write bytes / time): the practical HBM ceiling beside 8 TB/s."""
+    import torch
+    n = int(gib * 2**30) // 8
+    a = torch.empty(n, dtype=torch.float64, device=f"cuda:{dev}").normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    del a, b
+    torch.cuda.empty_cache()
+    ts.sort()
+    return 2.0 * n * 8 / (ts[len(ts) // 2] * 1e-3) / 1e9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nodes-per-side", type=int, default=int(os.environ.get("PCG_BENCH_N", "150")),
-                    help="brick size N (150 -> 10M dof = the metric's configuration; 70 -> 1M; 322 -> 100M)")
-    ap.add_argument("--workload", choices=["brick", "octree"], default="brick",
-                    help="brick = SURVEY 8(d) uniform brick (the metric's configuration); octree = two-level 2:1 graded mesh with "
-                         "hanging-node transition patterns, ~1.2 M dof (BASELINE configs[1] names an octree mesh)")
-    ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
-    ap.add_argument("--operator", choices=["sell", "ebe", "both"], default="both",
-                    help="sell = assembled SELL-BSR3 matrix (the headline value/roofline); both = also time the matrix-free operator")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    if world == 1 and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    comm = None
+    share = os.environ.get("PCG_BENCH_SHARE_GPU") == "1"      # dry run: all ranks on device 0 (1-GPU box, RCCL stand-in)
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         import datetime
-        # a rank that dies must take the job down in minutes, not after the default 10-minute collective timeout
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+        # control plane (barriers, the max over ranks, the unique-id broadcast); a rank that dies takes the job down in minutes
+        if share:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=datetime.timedelta(seconds=300))
 
     import __graft_entry__
     if rank == 0:
@@ -119,12 +249,23 @@ def main():
     import pcg_mi355x as pm
     from pcg_mi355x import _lib
     from pcg_mi355x.brick import Brick, make_parts, block_partition, default_grid
-    from pcg_mi355x.dist import TorchComm
+    from pcg_mi355x.dist import RcclComm, TorchComm
     _lib.use_library(None)
     assert _lib.backend_name() == "hip-gfx950"
+    comm, transport = None, "none (one part)"
     if world > 1:
-        comm = TorchComm(device=torch.device("cuda", local_rank))
-    pm.configure(comm=comm, device=local_rank, rows_per_lane=args.rows_per_lane)
+        if args.comm == "native":
+            comm = RcclComm.from_torch(dev)
+            assert comm.world == world
+            transport = "native: engine-issued RCCL (grouped ncclSend/ncclRecv on a comm stream, ncclAllReduce on the compute stream)"
+            if os.environ.get("PCG_RCCL_LIB"):
+                transport += f" [PCG_RCCL_LIB={os.path.basename(os.environ['PCG_RCCL_LIB'])}]"
+        else:
+            comm = TorchComm(device=torch.device("cuda", dev))
+            transport = "torch.distributed callbacks (all_to_all_single + all_reduce, backend %s)" % comm.backend
+            if os.environ.get("PCG_BENCH_NATIVE_FAILED") == "1":
+                transport += " - the native communicator failed on this node, see stderr"
+    pm.configure(comm=comm, device=dev, rows_per_lane=args.rows_per_lane)
 
     N = args.nodes_per_side
     t0 = time.perf_counter()
@@ -148,10 +289,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_max(x):
+        if world == 1:
+            return float(x), [float(x)]
+        box = [None] * world
+        dist.all_gather_object(box, float(x))
+        return max(box), box
+
     def measure(kind):
         """Set up the operator of `kind`, run W warm-up + K timed PCG iterations, finish the solve."""
         part.pop("_pcg_mi355x_operator", None)
-        pm.configure(comm=comm, device=local_rank, rows_per_lane=args.rows_per_lane, operator=kind)
+        pm.configure(comm=comm, device=dev, rows_per_lane=args.rows_per_lane, operator=kind)
         t0 = time.perf_counter()
         op = pm.get_operator(part)                   # native host set-up + upload (not timed)
         t_setup = time.perf_counter() - t0
@@ -165,7 +313,8 @@ def main():
         gd = part["GlobData"]
         eff = np.asarray(part["LocDofEff"], np.int64)
         inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
-        max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + 1)
+        extra = args.steps if world > 1 else 0       # N > 1: a second window with the communication timers on
+        max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + extra + 1)
         op.solve_begin(part["Fext"], np.zeros(op.n), inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
         r = op.solve_run(args.warmup)
         assert r.status == 4 and r.iters_done == args.warmup, "solve ended inside the warm-up window"
@@ -174,16 +323,31 @@ def main():
         t0 = time.perf_counter()
         r = op.solve_run(args.steps)                  # exactly K PCG iterations
         fence()
-        elapsed = time.perf_counter() - t0
+        elapsed_local = time.perf_counter() - t0
         assert r.iters_done == args.warmup + args.steps and r.status == 4, \
             f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
         op_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
         n_op = int(r.spmv_count)
         op.set_profiling(False)
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed, per_rank = gather_max(elapsed_local)
+        comm_info = None
+        if world > 1 and getattr(comm, "native", False):   # second window: HIP events around the exchange wait / all-reduces
+            s0 = comm.stats()
+            comm.set_timing(True)
+            fence()
+            t0 = time.perf_counter()
+            r2 = op.solve_run(args.steps)
+            fence()
+            t_win = time.perf_counter() - t0
+            comm.set_timing(False)
+            s1 = comm.stats()
+            if r2.status == 4:
+                k = max(1, args.steps)
+                comm_info = {"halo_wait_ms_per_iter": (s1["halo_wait_ms"] - s0["halo_wait_ms"]) / k,
+                             "allreduce_ms_per_iter": (s1["allreduce_ms"] - s0["allreduce_ms"]) / k,
+                             "exchanges_per_iter": (s1["n_halo"] - s0["n_halo"]) / k,
+                             "allreduces_per_iter": (s1["n_allreduce"] - s0["n_allreduce"]) / k,
+                             "ms_per_step_with_timers": t_win / k * 1e3}
         final = None
         if not args.no_finish:                        # not timed: convergence evidence
             t0 = time.perf_counter()
@@ -197,37 +361,52 @@ def main():
         if world == 1:
             ms = op.bench_spmv(10, 100)
             standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
-        return {"op": op, "elapsed": elapsed, "op_ms": op_ms, "n_op": n_op, "final": final, "standalone": standalone,
-                "t_setup": t_setup}
+        return {"op": op, "elapsed": elapsed, "per_rank_s": per_rank, "op_ms": op_ms, "n_op": n_op, "final": final,
+                "standalone": standalone, "t_setup": t_setup, "comm": comm_info}
 
-    m = measure("sell")
-    op, elapsed, spmv_ms, n_spmv, final, standalone = m["op"], m["elapsed"], m["op_ms"], m["n_op"], m["final"], m["standalone"]
-    info = op.matrix_info()
-    if rank == 0:
-        if brick.nnz is None:
-            brick.nnz = op.nnz if world == 1 else None
-        log(f"{args.workload} N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
-            f"RefMeshPart {t_parts:.1f}s, assemble+upload {m['t_setup']:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
-            f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
-    n_loc, nnz_loc = op.n, op.nnz
+    copy_GBps = hbm_copy_GBps(dev) if rank == 0 else None
+    box = box_identity(dev) if rank == 0 else None
+
+    m = None
+    if args.operator in ("both", "sell"):
+        m = measure("sell")
+        op = m["op"]
+        info = op.matrix_info()
+        n_loc, nnz_loc = op.n, op.nnz
+        sell_bytes, sell_flops = op.operator_cost()
+        if rank == 0:
+            if brick.nnz is None:
+                brick.nnz = op.nnz if world == 1 else None
+            log(f"{args.workload} N={N}: {brick.n_dof} dof, nnz {brick.nnz}; parts {world} grid {grid}; local dof {op.n}, local nnz {op.nnz}; "
+                f"RefMeshPart {t_parts:.1f}s, assemble+upload {m['t_setup']:.1f}s; SELL slices {info['n_slices']} x {info['slice_rows']} rows, "
+                f"padding {info['stored_blocks'] / info['nnzb'] - 1:.2%}")
+        op.close()
+    e = None
     matrix_free = None
     if args.operator in ("both", "ebe"):
-        op.close()
         try:
             e = measure("ebe")
         except Exception as ex:              # the headline line must survive a failure of the optional second measurement
+            if m is None:
+                raise
             log(f"matrix-free measurement failed: {ex!r}")
-            e = None
             matrix_free = {"error": repr(ex)}
-    if args.operator in ("both", "ebe") and e is not None:
+    if e is not None:
         oi = e["op"].operator_info()
-        matrix_free = {"note": "SURVEY 8(f)-1: the reference's element-by-element operator kept matrix-free (k_ebe, colour-ordered, "
-                               "deterministic); same PCG driver, same inputs", "value": args.steps / e["elapsed"],
-                       "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3, "operator_avg_ms": e["op_ms"],
-                       "operator_launches_timed": e["n_op"], "colors": oi["n_colors"], "n_elem": oi["n_elem"],
-                       "standalone_operator": e["standalone"], "solve": e["final"],
-                       "flops_per_apply": 2.0 * 24 * oi["n_slots"], "achieved_TFLOPs": 2.0 * 24 * oi["n_slots"] / (e["op_ms"] * 1e-3) / 1e12,
-                       "csr_equivalent_GBps": (12.0 * nnz_loc + 20.0 * n_loc) / (e["op_ms"] * 1e-3) / 1e9}
+        eb, ef = e["op"].operator_cost()
+        t_op = e["op_ms"] * 1e-3
+        matrix_free = {"note": "SURVEY 8(f)-1: the reference's element-by-element operator kept matrix-free; same PCG driver, same inputs",
+                       "value": args.steps / e["elapsed"], "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3,
+                       "operator_avg_ms": e["op_ms"], "operator_launches_timed": e["n_op"], "n_elem": oi["n_elem"], "n_chunks": oi["n_chunks"],
+                       "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"],
+                       "roofline": {"kernel": "k_ebe_chunk + k_ebe_shared (one operator apply)", "avg_apply_ms": e["op_ms"],
+                                    "flops_per_apply": ef, "achieved_TFLOPs": ef / t_op / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
+                                    "frac_flops": ef / t_op / 1e12 / F64_PEAK_TFLOPS,
+                                    "bytes_per_apply": eb, "achieved_GBps": eb / t_op / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                    "frac_hbm": eb / t_op / 1e9 / HBM_PEAK_GBS,
+                                    "bound": "neither saturated: latency / LDS-phase bound (DESIGN.md 4b)"}}
+        if m is None:
+            n_loc = e["op"].n
         e["op"].close()
 
     if rank != 0:
@@ -235,41 +414,57 @@ def main():
             dist.barrier(); dist.destroy_process_group()
         return
 
-    alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                     # f64 val + i32 col per nnz; x, y, i32 rowptr
-    impl_bytes = info["stored_blocks"] * (72.0 + 4.0) + 16.0 * n_loc + 8.0 * (info["n_slices"] + 1)
-    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    head = m if m is not None else e
+    elapsed = head["elapsed"]
     iters_per_s = args.steps / elapsed
-    iter_bytes = alg_bytes + 176.0 * n_loc                         # SURVEY 8(d) B_iter
-    traffic, traffic_src = None, None
-    try:        # HBM bytes per SpMV launch from the PMC passes (separate rocprofv3 runs, see profiles/pmc_traffic.json)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}")
-        if pmc and world == 1:
-            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
-    except OSError:
-        pass
     out = {
         "metric": "PCG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3D elastostatic CSR",
         "value": iters_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{wl_name}, Jacobi-PCG Tol 1e-7, {world} part(s) {grid[0]}x{grid[1]}x{grid[2]}",
-                   "dofs": brick.n_dof, "nnz": brick.nnz, "parts": world, "format": f"SELL-{info['slice_rows']} over 3x3 blocks",
-                   "spmv_achieved_GBps": achieved, "iter_algorithmic_GBps": iter_bytes * world / (elapsed / args.steps) / 1e9},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL-BSR3 SpMV + fused p.Ap)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": n_spmv,
-                     "impl_bytes_per_launch": impl_bytes, "impl_achieved": impl_bytes / (spmv_ms * 1e-3) / 1e9,
-                     "impl_frac": impl_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "standalone_spmv": standalone,
-                     "note": "achieved/frac use SURVEY 8(d)'s CSR-algorithmic bytes (12*nnz + 20*n); the stored SELL-BSR3 operator moves "
-                             "fewer bytes (impl_*, one i32 column per 3x3 block), so frac can exceed 1; impl_frac and the PMC traffic are "
-                             "the physical HBM utilisation"},
-        "solve": final,
-        "matrix_free": matrix_free,
+                   "dofs": brick.n_dof, "nnz": brick.nnz, "parts": world,
+                   "operator": "assembled SELL-BSR3" if m is not None else "matrix-free (EBE)"},
+        "solve": head["final"],
+        "matrix_free": matrix_free if m is not None else None,
+        "box": box,
     }
+    if m is not None:
+        t_k = m["op_ms"] * 1e-3
+        achieved = sell_bytes / t_k / 1e9
+        alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                 # what scalar CSR (f64 value + i32 column per nnz) would move
+        out["config"]["format"] = f"SELL-{info['slice_rows']} over 3x3 blocks"
+        out["config"]["spmv_achieved_GBps"] = achieved
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_spmv<1,true> (SELL-BSR3 SpMV + fused p.Ap)" + (" - this rank's part" if world > 1 else ""),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_launch": sell_bytes,
+            "bytes_definition": "stored operator: 76 B per stored 3x3 block (72 B values + one i32 column) + x in + y out (16 B/dof) + slice "
+                                "pointers - the algorithmic traffic of the block format (pcg_operator_cost)",
+            "avg_launch_ms": m["op_ms"], "launches_timed": m["n_op"],
+            "traffic": None,
+            "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 passes of their own; the committed passes for this kernel are under "
+                            "profiles/ (DESIGN.md section 8) - traffic / bytes_per_launch = 1.03",
+            "hbm_copy_GBps": copy_GBps, "frac_of_copy": achieved / copy_GBps if copy_GBps else None,
+            "csr_equivalent_bytes": alg_bytes, "csr_equivalent_GBps": alg_bytes / t_k / 1e9,
+            "csr_equivalent_note": "SURVEY 8(d) formula 12 nnz + 20 n: a scalar-CSR kernel's traffic for the same product; NOT what this "
+                                   "kernel moves (it can exceed the HBM peak) - kept for comparison with CSR codes only",
+            "standalone_spmv": m["standalone"]}
+        try:        # PMC traffic of an identical launch, collected by separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}")
+            if pmc and world == 1:
+                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = ("from profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch "
+                                                   "(gfx950-corrected), collected on another box in another session - not a measurement of this run")
+        except OSError:
+            pass
+    if world > 1:
+        out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]]}
+        if head["comm"]:
+            out["comm"].update(head["comm"])
     if not args.no_cpu_baseline and world == 1:
-        log("timing the CPU baseline (oracle port, 1 thread) ...")
-        out["cpu_baseline"] = cpu_baseline(part)
+        log("timing the CPU baseline (oracle port: 1 core, then R processes x 1 thread) ...")
+        out["cpu_baseline"] = cpu_baseline(part, N, args.cpu_ranks, args.workload)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

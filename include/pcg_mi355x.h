@@ -13,8 +13,8 @@
  *   updatePreconditioner                  :346-352        pcg_build_jacobi()
  *   updateBC                              :226-238        pcg_update_bc()
  *   PCG(RefMeshPart)                      :356-598        pcg_solve_begin/_run/_end, pcg_solve()
- *   MPI_SUM                               :622-628        pcg_comm_hooks.allreduce
- *   Isend/Recv/Waitall interface sums     :318-334        pcg_comm_hooks.halo_begin/halo_end
+ *   MPI_SUM                               :622-628        pcg_comm_create_rccl(): ncclAllReduce issued by the engine  | pcg_comm_hooks.allreduce
+ *   Isend/Recv/Waitall interface sums     :318-334        pcg_comm_create_rccl(): grouped ncclSend/ncclRecv, comm stream | pcg_comm_hooks.halo_*
  *   np.dot(a, b*w)                        :381,415,462..  pcg_dot_w()
  *   element tables -> operator            (partition_mesh.py:443-491,576-581 data contract)
  *                                                          pcg_asm_*() + pcg_create()   assembled, SELL over 3x3 blocks
@@ -101,8 +101,9 @@ int pcg_set_masks(pcg_engine *e, const uint8_t *flags /* n */);
 int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const int64_t *send_ptr /* n_peers+1 */,
                  const int32_t *send_idx /* send_ptr[n_peers] local dofs */);
 
-/* Communication hooks (one process per GPU; the Python shim implements them with
- * torch.distributed = RCCL over xGMI).  All buffers are DEVICE pointers, `stream` is the
+/* Communication hooks: the callback seam (CPU test-suite with gloo, in-process thread communicators, or a host
+ * language that wants to own the transport, e.g. torch.distributed).  The product's multi-GPU path is the native
+ * communicator below, which needs no callbacks.  All buffers are DEVICE pointers, `stream` is the
  * engine's hipStream_t.  halo_begin is called once the send buffer has been packed on `stream`;
  * halo_end must make `stream` wait until the receive buffer is complete.  allreduce sums
  * `count` doubles in place across ranks.  NULL hooks = single part. */
@@ -114,6 +115,36 @@ typedef struct {
 } pcg_comm_hooks;
 int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks);
 void *pcg_stream(pcg_engine *e);
+
+/* ---- native communicator: RCCL over xGMI, issued by the engine --------------------------------
+ * Replaces the reference's mpi4py calls on the hot path without any callback into the host language:
+ *   Isend / Recv / Waitall per neighbour (pcg_solver.py:318-328) -> one ncclGroupStart..ncclSend/ncclRecv..ncclGroupEnd
+ *       on a dedicated communication stream, fenced with events against the engine's compute stream
+ *       (interface rows -> pack -> exchange || interior rows -> wait -> add in neighbour order);
+ *   MPI_SUM -> Comm.allreduce (:622-628) -> ncclAllReduce(ncclDouble, ncclSum) in place on the device status block.
+ * One process per GPU, one part per process, part id == rank (pcg_solver.py:91,:320); neighbour ids passed to
+ * pcg_set_halo() are peer ranks.  A communicator may serve several engines of the process, one solve at a time.
+ * Bootstrap: rank 0 calls pcg_rccl_unique_id(), the bytes reach the other ranks by any means the launcher has
+ * (MPI_Bcast in the reference's mpiexec world, torch.distributed / a file under torchrun), every rank then calls
+ * pcg_comm_create_rccl() (collective).  When a native communicator is attached it takes precedence over
+ * pcg_comm_hooks; the hooks remain as the seam for the CPU (gloo) test-suite. */
+typedef struct pcg_comm pcg_comm;
+enum { PCG_RCCL_ID_BYTES = 256 };                 /* two ncclUniqueId: exchange communicator, reduction communicator */
+int pcg_rccl_unique_id(void *out /* PCG_RCCL_ID_BYTES */);
+int pcg_comm_create_rccl(int32_t device, int32_t rank, int32_t nranks, const void *unique_id, pcg_comm **out);
+void pcg_comm_destroy(pcg_comm *c);
+int pcg_comm_rank(const pcg_comm *c);
+int pcg_comm_size(const pcg_comm *c);
+int pcg_set_comm_native(pcg_engine *e, pcg_comm *c /* NULL detaches */);
+/* The reference's two timer buckets (updateTime :631-641: everything outside a communication call is 'calculation').
+ * With timing on, HIP events bracket the compute stream's wait for the exchange and every all-reduce: the time the
+ * GPU was BLOCKED in communication, which is what dT_CommWait means; pcg_result.t_comm_s then reports it per solve. */
+typedef struct {
+    double halo_wait_ms, allreduce_ms;
+    int64_t n_halo, n_allreduce, n_halo_timed, n_allreduce_timed;
+} pcg_comm_stats;
+int pcg_comm_set_timing(pcg_comm *c, int32_t on);
+int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out);
 
 /* ---- operator-level calls (host vectors, length n) ----------------------------------------- */
 int pcg_apply(pcg_engine *e, const double *x, double *y);            /* y = A x, interface-summed */
@@ -162,6 +193,9 @@ int pcg_set_profiling(pcg_engine *e, int32_t on);
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
 int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free */, int64_t *n_elem, int64_t *n_slots,
                       int32_t *n_colors, int64_t *n_chunks);
+/* What ONE local operator apply has to move (bytes of the stored operator + x in + y out, counted from the uploaded
+ * structures) and compute (flops of the un-padded operator): the denominators of the roofline report (bench.py). */
+int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply);
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
 /* single fused kernels on host vectors, for per-kernel parity tests */
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first);

@@ -39,9 +39,9 @@ struct Assembler {
 };
 
 template <class F>
-static void parallel_for(int64_t n, int n_threads, F f)
+static void parallel_for(int64_t n, int n_threads, F f, int64_t serial_below = 1024)
 {
-    if (n_threads <= 1 || n < 1024) { f(0, n); return; }
+    if (n_threads <= 1 || n < serial_below) { f(0, n); return; }
     std::vector<std::thread> th;
     int64_t chunk = (n + n_threads - 1) / n_threads;
     for (int t = 0; t < n_threads; ++t) {
@@ -120,7 +120,7 @@ static int build(Assembler &A, int32_t n_groups, const pcg_elem_group *gs, const
     int nt = std::max(1, A.n_threads);
     int64_t chunk = (nn + nt - 1) / nt;
     chunk_cols.resize(nt);
-    parallel_for(nt, nt, [&](int64_t tlo, int64_t thi) {
+    auto pattern_of_chunks = [&](int64_t tlo, int64_t thi) {
         for (int64_t t = tlo; t < thi; ++t) {
             int64_t lo = t * chunk, hi = std::min(nn, lo + chunk);
             std::vector<int32_t> cand;
@@ -138,7 +138,8 @@ static int build(Assembler &A, int32_t n_groups, const pcg_elem_group *gs, const
                 out.insert(out.end(), cand.begin(), cand.end());
             }
         }
-    });
+    };
+    parallel_for(nt, nn < 4096 ? 1 : nt, pattern_of_chunks, 0);      // one thread per node chunk (nt of them, however few)
     for (int64_t i = 0; i < nn; ++i) A.rowptr[i + 1] += A.rowptr[i];
     A.cols.resize(A.rowptr[nn]);
     {

@@ -1184,6 +1184,7 @@ public:
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (phi == 2) ++ev_applies_; }
         return fuse;
     }
+    bool ebe_can_split() const override { return ebe_ranges_[0].empty() && ebe_ranges_[1].empty(); }
     void upload_masks(const uint8_t *f, int64_t n) override { h2d(d_flags_, f, (size_t)n); }
     void upload_halo(const HaloHost &h) override
     {

@@ -36,6 +36,11 @@ const double kEps = std::numeric_limits<double>::epsilon();   // np.finfo(float)
 
 }  // namespace
 
+struct pcg_comm {
+    std::unique_ptr<Comm> impl;
+    int32_t device = 0;
+};
+
 struct pcg_engine {
     std::unique_ptr<Backend> be;
     int64_t n_nodes = 0, n = 0, n_slices = 0, n_bnd_slices = 0;
@@ -45,11 +50,15 @@ struct pcg_engine {
     int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
     int32_t n_colors = 0;
     int64_t n_chunks = 0;
+    double op_bytes = 0, op_flops = 0;    // what one local operator apply has to move / compute (stored structures)
     HaloHost halo;
     bool has_halo = false;
     bool has_masks = false;
     pcg_comm_hooks hooks{};
-    bool has_hooks = false;
+    bool has_hooks = false;               // callbacks (the gloo / thread test seam, or torch.distributed)
+    Comm *comm = nullptr;                 // native RCCL communicator (not owned; pcg_comm handle), takes precedence
+    CommStats comm0;                      // its counters at pcg_solve_begin
+    bool multi() const { return comm != nullptr || has_hooks; }
     bool jacobi_built = false;
     bool profiling = false;
     // One-iteration look-ahead of the solve loop (iterate_once).  Measured on MI355X (profiles/r01_look_ahead_ab.json):
@@ -112,6 +121,7 @@ struct pcg_engine {
     // ---- communication -----------------------------------------------------------------------------
     void allreduce(double *dev, int count)
     {
+        if (comm) { comm->allreduce(dev, count, be->stream()); return; }      // ncclAllReduce on the compute stream
         if (!has_hooks || !hooks.allreduce) return;
         double t0 = now_s();
         if (hooks.allreduce(hooks.ctx, dev, count, be->stream()) != 0) throw std::runtime_error("allreduce hook failed");
@@ -119,7 +129,8 @@ struct pcg_engine {
     }
     void halo_begin()
     {
-        if (!has_hooks || !hooks.halo_begin) throw std::runtime_error("part has neighbours but no halo hook is set");
+        if (comm) { comm->halo_begin(d_send, d_recv, halo, be->stream()); return; }   // grouped ncclSend/ncclRecv, comm stream
+        if (!has_hooks || !hooks.halo_begin) throw std::runtime_error("part has neighbours but no communicator is set");
         double t0 = now_s();
         if (hooks.halo_begin(hooks.ctx, d_send, d_recv, (int64_t)halo.send_idx.size(), be->stream()) != 0)
             throw std::runtime_error("halo_begin hook failed");
@@ -127,7 +138,20 @@ struct pcg_engine {
     }
     void halo_end()
     {
+        if (comm) { comm->halo_end(be->stream()); return; }
         double t0 = now_s();
+        if (hooks.halo_end(hooks.ctx, be->stream()) != 0) throw std::runtime_error("halo_end hook failed");
+        t_comm += now_s() - t0;
+    }
+    // A part without neighbours in a multi-part job: the native exchange is point-to-point (nothing to do, like the
+    // reference's Isend/Recv loops over an empty NbrMPIdVector), but a callback communicator may implement the exchange
+    // as a group-wide collective (torch all_to_all_single) which EVERY rank has to enter.
+    bool lone_in_collective() const { return !has_halo && !comm && has_hooks && hooks.halo_begin && hooks.halo_end; }
+    void empty_exchange()
+    {
+        if (!lone_in_collective()) return;
+        double t0 = now_s();
+        if (hooks.halo_begin(hooks.ctx, nullptr, nullptr, 0, be->stream()) != 0) throw std::runtime_error("halo_begin hook failed");
         if (hooks.halo_end(hooks.ctx, be->stream()) != 0) throw std::runtime_error("halo_end hook failed");
         t_comm += now_s() - t0;
     }
@@ -141,6 +165,16 @@ struct pcg_engine {
             bool fused;
             if (!has_halo) {
                 fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0);
+                empty_exchange();
+            } else if (!be->ebe_can_split()) {
+                // Pattern types outside the chunked form add into y with '+=' (one colour per launch) while chunk and
+                // shared-node stores assign: a phase-0 colour launch followed by a phase-1 chunk store would lose
+                // contributions.  Such mixed parts run the whole operator first, then exchange (no overlap).
+                fused = be->ebe_apply(x, y, 0, 2, true, with_dot, n_bnd_dofs);
+                be->halo_pack(y, d_send);
+                halo_begin();
+                halo_end();
+                be->boundary_fixup(y, d_recv, x, with_dot && fused);
             } else {
                 fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs);
                 be->halo_pack(y, d_send);
@@ -156,6 +190,7 @@ struct pcg_engine {
         if (with_dot) be->begin_dot();
         if (!has_halo) {
             be->spmv(x, y, 0, n_slices, with_dot);
+            empty_exchange();
         } else {
             be->spmv(x, y, 0, n_bnd_slices, false);
             be->halo_pack(y, d_send);                         // :307-309
@@ -167,7 +202,7 @@ struct pcg_engine {
     }
     void halo_sum(double *y)
     {
-        if (!has_halo) return;
+        if (!has_halo) { empty_exchange(); return; }
         be->halo_pack(y, d_send);
         halo_begin();
         halo_end();
@@ -182,7 +217,7 @@ struct pcg_engine {
     void read_status()
     {
         // with hooks the all-reduce rewrites the device block after the kernels mirrored it: copy then
-        if (has_hooks || !be->read_status(h_st)) be->d2h(h_st, d_st, sizeof(double) * ST_COUNT);
+        if (multi() || !be->read_status(h_st)) be->d2h(h_st, d_st, sizeof(double) * ST_COUNT);
     }
 
     // r = b - A x, then [sum r^2 w, rho_next, ninf] -> h_st[SQR..NINF]   (:412-416, :528-533, :569-574)
@@ -213,7 +248,7 @@ struct pcg_engine {
         be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first);     // :447, :472-479
         apply(p_out, v_q, true);                                            // :482-484
         bool alpha_in_update = false;
-        if (!has_hooks && !(kind == 1 && !ebe_dot_fused)) {
+        if (!multi() && !(kind == 1 && !ebe_dot_fused)) {
             be->reduce_dot_alpha(d_st);                                     // :487-498, one launch (no all-reduce in between)
         } else {
             reduce_apply_dot(d_st + ST_PQ);                                 // :487
@@ -223,7 +258,7 @@ struct pcg_engine {
         be->fused_update(d_st, p_out, v_q, r_in, r_out, x_in, x_out, s.minv, alpha_in_update);   // :501-516 (+ :447-462 of i+1)
         be->reduce_update(d_st + ST_SQP);
         allreduce(d_st + ST_SQP, 5);                                        // :507 (+ next rho, inf count)
-        be->publish_status(has_hooks);
+        be->publish_status(multi());
     }
 };
 
@@ -297,7 +332,14 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     s.normr_act = normr;                                       // :518
     s.i = i + 1;
     if (normr <= s.tolb || s.stag >= 3 || s.more > 0) {        // :527
-        s.ahead = false;                                       // r is about to be replaced: the look-ahead is void
+        if (s.ahead) {
+            // r is about to be replaced: the look-ahead is void.  It may have raised the sticky device stop flag (its
+            // p.Ap formed from the recurrence residual, e.g. <= 0 once that has underflowed); iteration i itself did
+            // not (tested above), so if the loop goes on, iteration i+1 - enqueued again from the true residual -
+            // must start from a clear flag, as the reference evaluates PQ afresh (:487-498).
+            e->be->zero(e->d_st + ST_STOP, sizeof(double));
+            s.ahead = false;
+        }
         e->true_residual(e->v_x[s.cur]);                       // :528-533 (R is REPLACED, :531)
         s.normr_act = std::sqrt(e->h_st[ST_SQR]);
         s.rho_next = e->h_st[ST_RHO_NEXT];
@@ -340,7 +382,11 @@ void fill_result(pcg_engine *e, pcg_result *res)
     res->norm_b = s.n2b;
     res->normr_act = s.normr_act;
     res->t_total_s = s.t_total;
-    res->t_comm_s = e->t_comm - s.t_comm0;
+    res->t_comm_s = e->t_comm - s.t_comm0;           // callbacks: host time inside the hooks
+    if (e->comm) {                                   // native: GPU time the compute stream spent blocked in the exchange or
+        const CommStats c = e->comm->stats();        // inside the all-reduce (HIP events; 0 unless pcg_comm_set_timing is on)
+        res->t_comm_s = ((c.halo_wait_ms - e->comm0.halo_wait_ms) + (c.allreduce_ms - e->comm0.allreduce_ms)) * 1e-3;
+    }
     double ms = 0;
     int64_t cnt = 0;
     if (e->profiling) e->be->collect_profile(&ms, &cnt);
@@ -373,6 +419,11 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
     return guarded("pcg_create", [&]() -> int {
         if (!out || !rowptr || !cols || !vals || n_nodes <= 0) return set_error("pcg_create: bad argument");
         if (n_boundary_nodes < 0 || n_boundary_nodes > n_nodes) return set_error("pcg_create: bad n_boundary_nodes");
+        if (rowptr[0] != 0) return set_error("pcg_create: rowptr[0] must be 0");
+        for (int64_t i = 0; i < n_nodes; ++i)
+            if (rowptr[i + 1] < rowptr[i]) return set_error("pcg_create: rowptr must be non-decreasing");
+        for (int64_t k = 0; k < rowptr[n_nodes]; ++k)
+            if (cols[k] < 0 || cols[k] >= n_nodes) return set_error("pcg_create: block column index out of range");
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);                       // throws when no usable device: no fallback
         SellHost m;
@@ -385,6 +436,9 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->C = m.C;
         e->nnzb = m.nnzb;
         e->stored_blocks = m.slice_ptr.back() * m.C;
+        // 72 B of values + one 4 B column per stored 3x3 block, x read and y written once, the slice pointers
+        e->op_bytes = 76.0 * (double)e->stored_blocks + 16.0 * (double)e->n + 8.0 * (double)(m.n_slices + 1);
+        e->op_flops = 18.0 * (double)m.nnzb;
         e->be->upload_matrix(m);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
@@ -419,6 +473,8 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
             e->C = m.C;
             e->nnzb = m.nnzb;
             e->stored_blocks = m.slice_ptr.back() * m.C;
+            e->op_bytes = 12.0 * (double)e->stored_blocks + 16.0 * (double)e->n + 8.0 * (double)(m.n_slices + 1);
+            e->op_flops = 2.0 * (double)m.nnzb;
             e->be->upload_matrix(m);
             e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
             e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
@@ -478,6 +534,24 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         e->n_slots = m.n_slots;
         e->n_colors = std::max(m.n_colors[0], m.n_colors[1]);
         e->n_chunks = m.chunked.n_chunks;
+        {   // bytes one apply moves, from the uploaded structures (Ke itself stays in the scalar / L2 caches)
+            double b = 0, f = 0;
+            const auto &Ch = m.chunked;
+            b += 34.0 * (double)Ch.nodes.size();             // per tile node: id 4 + dst 4 + slot 2, x tile in 24
+            b += 24.0 * (double)Ch.nodes.size();             //                y (exclusive) or boundary slot out 24
+            for (const auto &K : Ch.cls)                     // per element slot: local node ids, Ck, sign words
+                b += (double)K.n_chunks * kChunkThreads * K.ept * (2.0 * K.nnp + 8.0 + 4.0 * K.words);
+            b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
+            for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size() + 4.0 * (double)Ch.sh_slot[ph].size();   // ... y out 24 + lists
+            b += 32.0 * (double)Ch.n_chunks;                 // chunk headers
+            for (int g = 0; g < n_groups; ++g) {
+                f += 2.0 * (double)groups[g].nd * groups[g].nd * (double)groups[g].ne;
+                if (m.groups[g].ne > 0)                      // colour-by-colour groups: index 4 + sign 1 + x 8 + y read-modify-write 16 per slot
+                    b += (double)m.groups[g].nd * (double)m.groups[g].ne * 29.0 + 8.0 * (double)m.groups[g].ne;
+            }
+            e->op_bytes = b;
+            e->op_flops = f;
+        }
         e->be->upload_ebe(m);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
@@ -552,6 +626,60 @@ int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks)
 }
 
 void *pcg_stream(pcg_engine *e) { return e ? e->be->stream() : nullptr; }
+
+// ---- native RCCL communicator ----------------------------------------------------------------------
+int pcg_rccl_unique_id(void *out)
+{
+    return guarded("pcg_rccl_unique_id", [&]() -> int {
+        if (!out) return set_error("pcg_rccl_unique_id: null");
+        return rccl_unique_ids(out);
+    });
+}
+
+int pcg_comm_create_rccl(int32_t device, int32_t rank, int32_t nranks, const void *unique_id, pcg_comm **out)
+{
+    return guarded("pcg_comm_create_rccl", [&]() -> int {
+        if (!out || !unique_id) return set_error("pcg_comm_create_rccl: null");
+        auto c = std::unique_ptr<pcg_comm>(new pcg_comm());
+        c->device = device;
+        c->impl = make_rccl_comm(device, rank, nranks, unique_id);
+        *out = c.release();
+        return 0;
+    });
+}
+
+void pcg_comm_destroy(pcg_comm *c) { delete c; }
+
+int pcg_comm_rank(const pcg_comm *c) { return c && c->impl ? c->impl->rank() : -1; }
+int pcg_comm_size(const pcg_comm *c) { return c && c->impl ? c->impl->size() : -1; }
+
+int pcg_set_comm_native(pcg_engine *e, pcg_comm *c)
+{
+    if (!e) return set_error("pcg_set_comm_native: null engine");
+    e->comm = c ? c->impl.get() : nullptr;
+    return 0;
+}
+
+int pcg_comm_set_timing(pcg_comm *c, int32_t on)
+{
+    return guarded("pcg_comm_set_timing", [&]() -> int {
+        if (!c || !c->impl) return set_error("pcg_comm_set_timing: null");
+        c->impl->set_timing(on != 0);
+        return 0;
+    });
+}
+
+int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out)
+{
+    return guarded("pcg_comm_get_stats", [&]() -> int {
+        if (!c || !c->impl || !out) return set_error("pcg_comm_get_stats: null");
+        const CommStats s = c->impl->stats();
+        out->halo_wait_ms = s.halo_wait_ms; out->allreduce_ms = s.allreduce_ms;
+        out->n_halo = s.n_halo; out->n_allreduce = s.n_allreduce;
+        out->n_halo_timed = s.n_halo_timed; out->n_allreduce_timed = s.n_allreduce_timed;
+        return 0;
+    });
+}
 
 int pcg_apply(pcg_engine *e, const double *x, double *y)
 {
@@ -641,6 +769,7 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         be.set_status_slot(0);
         be.zero(e->d_st, sizeof(double) * ST_COUNT);                        // STOP is sticky within a solve
         s.t_comm0 = e->t_comm;
+        if (e->comm) e->comm0 = e->comm->stats();
         s.tol = tol;
         s.max_iter = max_iter;
         const size_t bytes = sizeof(double) * (size_t)e->n;
@@ -772,6 +901,14 @@ int pcg_operator_info(pcg_engine *e, int32_t *kind, int64_t *n_elem, int64_t *n_
     if (n_elem) *n_elem = e->n_elem;
     if (n_slots) *n_slots = e->n_slots;
     if (n_colors) *n_colors = e->n_colors;
+    return 0;
+}
+
+int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply)
+{
+    if (!e) return set_error("null");
+    if (bytes_per_apply) *bytes_per_apply = e->op_bytes;
+    if (flops_per_apply) *flops_per_apply = e->op_flops;
     return 0;
 }
 

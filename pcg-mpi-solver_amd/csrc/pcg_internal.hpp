@@ -150,6 +150,9 @@ public:
     // operator cannot fuse the dot (then the caller runs dot_w).  reduce with reduce_dot().
     virtual bool ebe_apply(const double *x, double *y, int phase_lo, int phase_hi, bool zero_first, bool with_dot,
                            int64_t dot_lo) = 0;
+    // false when some pattern type runs outside the chunked form (its colour launches ADD into y, chunk stores assign):
+    // the two phases may then not be interleaved with the interface exchange (pcg_driver.cpp apply())
+    virtual bool ebe_can_split() const = 0;
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;
 
@@ -206,6 +209,34 @@ public:
     virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
     virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;
 };
+
+// ---- native inter-GPU communication ---------------------------------------------------------------
+// One process per GPU, one part per process (pcg_solver.py:91).  The product implements this with RCCL
+// calls issued by the engine itself (rccl_comm.hip): the interface exchange Isend/Recv/Waitall (:318-328)
+// is ONE group of ncclSend/ncclRecv per neighbour on a dedicated communication stream, fenced against
+// the compute stream with events; MPI_SUM (:622-628) is ncclAllReduce(ncclDouble, ncclSum) in place on
+// the device status block, on the compute stream.  No Python frame, no host copy.
+struct CommStats {
+    double halo_wait_ms = 0, allreduce_ms = 0;      // GPU-side: compute stream stalled for the exchange / inside all-reduce
+    int64_t n_halo = 0, n_allreduce = 0;            // calls issued
+    int64_t n_halo_timed = 0, n_allreduce_timed = 0;
+};
+class Comm {
+public:
+    virtual ~Comm() {}
+    virtual int rank() const = 0;
+    virtual int size() const = 0;
+    // `send` has been packed on `compute_stream`; starts the exchange with every neighbour of `h` on the comm stream
+    virtual void halo_begin(double *send, double *recv, const HaloHost &h, void *compute_stream) = 0;
+    // makes `compute_stream` wait until `recv` is complete (and `send` may be overwritten)
+    virtual void halo_end(void *compute_stream) = 0;
+    virtual void allreduce(double *buf, int count, void *compute_stream) = 0;
+    virtual void set_timing(bool on) = 0;           // HIP events around the waits (the reference's dT_CommWait, :631-641)
+    virtual CommStats stats() = 0;                  // synchronises the streams it reads events from
+};
+// defined by the HIP side of the product library; the CPU test double has no native communicator
+std::unique_ptr<Comm> make_rccl_comm(int device, int rank, int nranks, const void *unique_ids /* 2 x 128 B */);
+int rccl_unique_ids(void *out /* 2 x 128 B */);
 
 std::unique_ptr<Backend> make_backend(int device);   // defined by exactly one back end per library
 int backend_device_count();

@@ -47,6 +47,13 @@ class Result(C.Structure):
                 ("spmv_ms_sum", C.c_double), ("spmv_count", C.c_int64), ("iters_enqueued", C.c_int64)]
 
 
+class CommStats(C.Structure):
+    _fields_ = [("halo_wait_ms", C.c_double), ("allreduce_ms", C.c_double), ("n_halo", C.c_int64),
+                ("n_allreduce", C.c_int64), ("n_halo_timed", C.c_int64), ("n_allreduce_timed", C.c_int64)]
+
+
+RCCL_ID_BYTES = 256
+
 STATUS_NORMAL, STATUS_ZERO_RHS, STATUS_GOOD_X0, STATUS_TOO_SMALL_TOL, STATUS_RUNNING = range(5)
 
 _P = C.c_void_p
@@ -67,6 +74,14 @@ _SIGS = {
     "pcg_set_halo": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "pcg_set_comm": (C.c_int, [_P, C.POINTER(CommHooks)]),
     "pcg_stream": (_P, [_P]),
+    "pcg_rccl_unique_id": (C.c_int, [_P]),
+    "pcg_comm_create_rccl": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
+    "pcg_comm_destroy": (None, [_P]),
+    "pcg_comm_rank": (C.c_int, [_P]),
+    "pcg_comm_size": (C.c_int, [_P]),
+    "pcg_set_comm_native": (C.c_int, [_P, _P]),
+    "pcg_comm_set_timing": (C.c_int, [_P, C.c_int32]),
+    "pcg_comm_get_stats": (C.c_int, [_P, C.POINTER(CommStats)]),
     "pcg_apply": (C.c_int, [_P, _P, _P]),
     "pcg_diag": (C.c_int, [_P, _P]),
     "pcg_build_jacobi": (C.c_int, [_P, _P]),
@@ -79,6 +94,7 @@ _SIGS = {
     "pcg_set_profiling": (C.c_int, [_P, C.c_int32]),
     "pcg_bench_spmv": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "pcg_operator_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "pcg_operator_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcg_matrix_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "pcg_k_update_p": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32]),
     "pcg_k_fused_update": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P, _P]),

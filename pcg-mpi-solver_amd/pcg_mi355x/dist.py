@@ -1,5 +1,10 @@
-"""Inter-GPU communication of the PCG hot path: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPU node; "gloo" in the CPU test-suite).
+"""Inter-GPU communication of the PCG hot path, one process per GPU.
+
+RcclComm  - the product path: a handle to the engine's NATIVE communicator (csrc/rccl_comm.hip).  The engine itself
+            issues grouped ncclSend/ncclRecv on its communication stream and ncclAllReduce on its compute stream;
+            Python only bootstraps (carries the ncclUniqueId from rank 0 to the others) and is not in the loop.
+TorchComm - the callback seam (pcg_comm_hooks) implemented with torch.distributed: "gloo" in the CPU test-suite,
+            "nccl" as an alternative transport on the GPU node.
 
 Replaces the reference's mpi4py calls (src/solver/pcg_solver.py):
   * interface sum-exchange  Isend / Recv / Waitall  (:318-328)  -> ONE all_to_all_single with the
@@ -25,7 +30,88 @@ import torch.distributed as dist
 
 from . import _lib
 
-__all__ = ["TorchComm"]
+__all__ = ["RcclComm", "TorchComm"]
+
+
+class RcclComm:
+    """Native RCCL communicator of this process (pcg_comm in include/pcg_mi355x.h).
+
+    Replaces the reference's module globals Comm / Rank / N_Workers (pcg_solver.py:968-970); part id == rank (:91).
+    Creation is collective: every rank must call it with the same `unique_id` (from rank 0's `new_unique_id()`).
+    """
+    native = True
+    backend = "rccl-native"
+
+    def __init__(self, rank, world, device, unique_id):
+        if len(unique_id) != _lib.RCCL_ID_BYTES:
+            raise ValueError("unique_id must be the bytes returned by RcclComm.new_unique_id()")
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
+        _lib.check(_lib.lib().pcg_comm_create_rccl(self.device, self.rank, self.world, buf, C.byref(h)), "pcg_comm_create_rccl")
+        self._h = h
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        _lib.check(_lib.lib().pcg_rccl_unique_id(buf), "pcg_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, device, group=None):
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, device, box[0])
+
+    @classmethod
+    def from_file(cls, rank, world, device, path, timeout_s=120.0):
+        """Bootstrap without torch.distributed: rank 0 writes the id to `path` (atomically), the others wait for it."""
+        import os
+        if rank == 0:
+            uid = cls.new_unique_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"no RCCL unique id at {path}")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = f.read()
+        return cls(rank, world, device, uid)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_timing(self, on=True):
+        _lib.check(_lib.lib().pcg_comm_set_timing(self._h, 1 if on else 0), "pcg_comm_set_timing")
+
+    def stats(self):
+        st = _lib.CommStats()
+        _lib.check(_lib.lib().pcg_comm_get_stats(self._h, C.byref(st)), "pcg_comm_get_stats")
+        return {k: getattr(st, k) for k, _ in _lib.CommStats._fields_}
+
+    def reraise(self):          # no callbacks, nothing to re-raise
+        pass
+
+    def release_stream(self, stream_ptr):
+        pass
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().pcg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _DevView:
@@ -56,6 +142,8 @@ class TorchComm:
 
     # -- pointer -> tensor ------------------------------------------------------------------------
     def _tensor(self, ptr, n):
+        if not n:                       # a part without neighbours still enters the collective (empty splits)
+            return torch.empty(0, dtype=torch.float64, device=(self.device if self.device is not None else "cuda") if self.on_gpu else "cpu")
         key = (ptr, n)
         t = self._views.get(key)
         if t is None:
@@ -98,12 +186,12 @@ class TorchComm:
     def make_hooks(self, op):
         """Build the pcg_comm_hooks struct for one Operator (its neighbour ids and counts)."""
         splits = [0] * self.world
-        for pid, cnt in zip(op.peer_ids, op.peer_counts):
+        for pid, cnt in zip(getattr(op, "peer_ids", []), getattr(op, "peer_counts", [])):
             if not (0 <= pid < self.world) or pid == self.rank:
                 raise ValueError(f"neighbour part id {pid} is not a valid peer rank")
             splits[pid] = cnt
         # the send buffer is ordered by neighbour list position; all_to_all needs rank order
-        if list(op.peer_ids) != sorted(op.peer_ids):
+        if list(getattr(op, "peer_ids", [])) != sorted(getattr(op, "peer_ids", [])):
             raise ValueError("NbrMPIdVector must be ascending (partition_mesh.py builds it in part-id order)")
 
         def halo_begin(ctx, send_p, recv_p, count, stream_p):

@@ -47,8 +47,14 @@ def importz(file_name):
 
 def write_partition(prefix, parts):
     """Write `<prefix><N>_<id>.mpidat` + `<prefix><N>_metadat.npy` like exportMP (partition_mesh.py:1303-1385).
-    Private engine entries (keys starting with '_') are not exported."""
+    Private engine entries (keys starting with '_') are not exported.  `parts` must be the COMPLETE partition (ids
+    0..N-1, any order): the metadata arrays are indexed by part id, as readModelData reads them (pcg_solver.py:100-106)."""
     n = len(parts)
+    ids = sorted(int(p["Id"]) for p in parts)
+    if ids != list(range(n)):
+        raise ValueError(f"write_partition needs every part of the partition exactly once (ids 0..{n - 1}), got {ids}; "
+                         "a rank that built only its own part (partition_model(only=[rank])) cannot write the metadata")
+    parts = sorted(parts, key=lambda p: int(p["Id"]))
     base = f"{prefix}{n}"
     os.makedirs(os.path.dirname(os.path.abspath(base)), exist_ok=True)
     meta = []

@@ -167,11 +167,16 @@ class Operator:
         self.peer_counts = [int(c) for c in np.diff(ptr)]
 
     def set_comm(self, comm):
-        """comm: pcg_mi355x.dist.TorchComm (or None)."""
+        """comm: pcg_mi355x.dist.RcclComm (native: the engine issues the RCCL calls itself), a callback communicator
+        with make_hooks() (pcg_mi355x.dist.TorchComm, the tests' thread communicator), or None."""
         self._comm = comm
+        check(self._L.pcg_set_comm_native(self._h, None), "pcg_set_comm_native")
+        check(self._L.pcg_set_comm(self._h, None), "pcg_set_comm")
+        self._hooks = None
         if comm is None:
-            check(self._L.pcg_set_comm(self._h, None), "pcg_set_comm")
-            self._hooks = None
+            return
+        if getattr(comm, "native", False):
+            check(self._L.pcg_set_comm_native(self._h, comm.handle), "pcg_set_comm_native")
             return
         self._hooks = comm.make_hooks(self)
         check(self._L.pcg_set_comm(self._h, C.byref(self._hooks)), "pcg_set_comm")
@@ -269,6 +274,12 @@ class Operator:
         check(self._L.pcg_operator_info(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_operator_info")
         return {"kind": "ebe" if k.value == 1 else "sell", "n_elem": a.value, "n_slots": b.value, "n_colors": c.value,
                 "n_chunks": d.value}
+
+    def operator_cost(self):
+        """(bytes, flops) one local operator apply has to move / compute, counted from the stored structures."""
+        b, f = C.c_double(), C.c_double()
+        check(self._L.pcg_operator_cost(self._h, C.byref(b), C.byref(f)), "pcg_operator_cost")
+        return b.value, f.value
 
     def matrix_info(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()

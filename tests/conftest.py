@@ -36,6 +36,22 @@ def build_hostops():
     return HOSTOPS_LIB
 
 
+FAKENCCL_SRC = os.path.join(ROOT, "tests", "fakenccl", "fakenccl.cpp")
+FAKENCCL_LIB = os.path.join(ROOT, "tests", "fakenccl", "_build", "libfakenccl.so")
+
+
+def build_fakenccl():
+    """The shared-GPU stand-in for librccl (tests/fakenccl): several ranks on ONE device drive the engine's native
+    communicator code.  Host-only code, compiled with hipcc for the HIP runtime headers."""
+    import subprocess
+    if os.path.exists(FAKENCCL_LIB) and os.path.getmtime(FAKENCCL_LIB) >= os.path.getmtime(FAKENCCL_SRC):
+        return FAKENCCL_LIB
+    os.makedirs(os.path.dirname(FAKENCCL_LIB), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                           FAKENCCL_SRC, "-o", FAKENCCL_LIB])
+    return FAKENCCL_LIB
+
+
 def build_oracle_c():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

@@ -61,6 +61,12 @@ def main():
         P = make_parts(brick, block_partition(brick, *[int(v) for v in grid.split("x")]), only=[rank])[0]
         x = np.cos(0.37 * P["DofVector"])
         out["DofVector"] = P["DofVector"]
+    elif case == "island":                      # two neighbouring parts + one part WITHOUT neighbours (tests/util.island_parts)
+        from util import island_parts
+        parts = island_parts()
+        assert len(parts) == world
+        P = parts[rank]
+        x = np.cos(0.37 * P["DofVector"])
     else:
         brick, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
         assert len(parts) == world, (len(parts), world)

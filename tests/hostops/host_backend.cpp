@@ -122,6 +122,7 @@ public:
             }
         return fuse;
     }
+    bool ebe_can_split() const override { return std::getenv("PCG_TEST_FORCE_SPLIT") || (ebe_.ranges[0].empty() && ebe_.ranges[1].empty()); }
     void upload_masks(const uint8_t *f, int64_t n) override { flags_.assign(f, f + n); }
     void upload_halo(const HaloHost &h) override { h_ = h; }
 
@@ -185,7 +186,11 @@ public:
         }
     }
     void begin_dot() override { dot_spmv_ = dot_fix_ = 0; }
-    void reduce_dot(double *red) override { red[0] = dot_spmv_ + dot_fix_; }
+    // Fault injection for the look-ahead tests: the PCG_TEST_NEG_PQ_AT-th p.Ap reduction of this engine (1-based count of
+    // enqueued iterations) reports -1, as a speculative iteration formed from a stale residual may on real data.
+    int64_t n_pq_ = 0;
+    const int64_t neg_pq_at_ = std::getenv("PCG_TEST_NEG_PQ_AT") ? std::atoll(std::getenv("PCG_TEST_NEG_PQ_AT")) : -1;
+    void reduce_dot(double *red) override { red[0] = (++n_pq_ == neg_pq_at_) ? -1.0 : dot_spmv_ + dot_fix_; }
     void scalar_alpha(double *st) override
     {
         const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
@@ -276,5 +281,8 @@ public:
 std::unique_ptr<Backend> make_backend(int) { return std::unique_ptr<Backend>(new HostBackend()); }
 int backend_device_count() { return 0; }
 const char *backend_static_name() { return "hostops-test"; }
+// the test double has no native communicator: the CPU suite drives the callback seam (pcg_set_comm) with gloo
+std::unique_ptr<Comm> make_rccl_comm(int, int, int, const void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
+int rccl_unique_ids(void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
 
 }  // namespace pcg

@@ -1,0 +1,112 @@
+"""Worker for the tests of the engine's NATIVE communicator (csrc/rccl_comm.hip) on the GPU.
+
+usage: python tests/native_comm_worker.py threads <case[,case..]> <kind[,kind..]> <outdir>
+           every part of a golden case in THIS process, one thread per part, each thread with its own RcclComm
+       python tests/native_comm_worker.py proc <case> <kind> <outdir> <rank> <world> <idfile> [device]
+           this process is rank <rank> of <world> (one part per process, as in production)
+The RCCL library is whatever csrc/rccl_comm.hip resolves: the real librccl (one rank per GPU), or - with
+PCG_RCCL_LIB=tests/fakenccl/_build/libfakenccl.so - the shared-GPU test double.  Results go to
+<outdir>/<case>_<kind>_rank<r>.npz in the layout of tests/dist_worker.py.
+"""
+import os
+import sys
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "pcg-mpi-solver_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+
+
+def run_rank(P, x_probe, comm, kind, device, timing):
+    import pcg_mi355x as pm
+    from pcg_mi355x.operator import from_refmeshpart
+    out = {"rank": comm.rank, "dofs": P["DofVector"]}
+    op = from_refmeshpart(P, device=device, comm=comm, kind=kind)
+    try:
+        out["y_probe"] = op.apply(x_probe)
+        out["diag"] = op.diag()
+        fext, udi = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        inv = op.build_jacobi()
+        out["Fext"] = fext
+        gd = P["GlobData"]
+        s0 = comm.stats()
+        if timing:
+            comm.set_timing(True)
+        x, res, hist = op.solve(fext, P["Un"], inv, gd["Tol"], gd["MaxIter"], gd["GlobNDofEff"], history=True)
+        s1 = comm.stats()
+        comm.set_timing(False)
+        info = pm.solver.SolveInfo(res, hist)
+        out["Un"] = x + udi
+        out["history"] = info.history
+        out["flag"], out["iter"], out["relres"], out["status"] = info.flag, info.iter, info.relres, info.status
+        out["iters_done"], out["iters_enqueued"] = info.iters_done, info.iters_enqueued
+        out["t_comm"], out["t_total"] = info.t_comm_s, info.t_total_s
+        for k in s1:
+            out["stat_" + k] = s1[k] - s0[k]
+    finally:
+        op.close()
+    return out
+
+
+def build(case):
+    import golden_cases
+    mesh, parts = golden_cases.build_case(case, os.path.join(ROOT, "tests", "golden"))
+    probe = golden_cases.probe_for(mesh, parts)
+    return parts, probe
+
+
+def main():
+    mode = sys.argv[1]
+    from pcg_mi355x import _lib
+    from pcg_mi355x.dist import RcclComm
+    _lib.use_library(None)
+    timing = os.environ.get("PCG_TEST_COMM_TIMING", "1") == "1"
+    if mode == "threads":
+        cases, kinds, outdir = sys.argv[2].split(","), sys.argv[3].split(","), sys.argv[4]
+        for case in cases:
+            parts, probe = build(case)
+            world = len(parts)
+            uid = RcclComm.new_unique_id()
+            comms = [None] * world
+            for kind in kinds:
+                outs, errs = [None] * world, [None] * world
+
+                def run(r):
+                    try:
+                        if comms[r] is None:
+                            comms[r] = RcclComm(r, world, 0, uid)          # collective: all threads are in here together
+                        P = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in parts[r].items()}
+                        outs[r] = run_rank(P, probe[P["DofVector"]], comms[r], kind, 0, timing)
+                    except BaseException as e:      # noqa: BLE001
+                        errs[r] = e
+                ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                for e in errs:
+                    if e is not None:
+                        raise e
+                for r, o in enumerate(outs):
+                    np.savez(os.path.join(outdir, f"{case}_{kind}_rank{r}.npz"), **o)
+            for c in comms:
+                c.close()
+    elif mode == "proc":
+        case, kind, outdir = sys.argv[2:5]
+        rank, world, idfile = int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+        device = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+        parts, probe = build(case)
+        assert len(parts) == world
+        comm = RcclComm.from_file(rank, world, device, idfile)
+        P = parts[rank]
+        o = run_rank(P, probe[P["DofVector"]], comm, kind, device, timing)
+        np.savez(os.path.join(outdir, f"{case}_{kind}_rank{rank}.npz"), **o)
+        comm.close()
+    else:
+        raise SystemExit("mode must be threads or proc")
+
+
+if __name__ == "__main__":
+    main()

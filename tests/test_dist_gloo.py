@@ -102,3 +102,19 @@ def test_parts_in_threads_on_the_test_double(hostops, case, kind):
     i0 = infos[0]
     assert all((i.flag, i.iter) == (i0.flag, i0.iter) for i in infos)
     check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0)
+
+
+def test_rank_without_neighbours_enters_the_collective_exchange(tmp_path):
+    """the callback communicator's exchange is a group-wide all_to_all_single; a rank whose part has no
+    neighbours must enter it too (empty splits) or the other ranks hang.  3 ranks, part 2 is an island; checked against
+    the oracle run with the same three parts as virtual ranks."""
+    import copy
+    import pcg_oracle
+    from util import island_parts
+    ref = island_parts()
+    out = pcg_oracle.solve_step(ref)
+    outs = run_dist("island", 3, "gloo", "hostops", tmp_path, 29619, timeout=300)
+    for o, R in zip(outs, ref):
+        assert int(o["flag"]) == out["flag"] == 0 and abs(int(o["iter"]) - out["iter"]) <= 1
+        assert relerr(o["Un"], R["Un"]) < 1e-8
+    assert int(outs[2]["n_halo"]) > 0            # the island rank took part in every exchange

@@ -148,6 +148,36 @@ def test_look_ahead_changes_nothing(hostops, monkeypatch, case, kind):
     assert 0 <= on[5] - off[5] <= 2                               # on: plus the dropped look-aheads of a break / the :527 branch
 
 
+def test_dropped_look_ahead_leaves_no_stop_flag_behind(hostops, monkeypatch):
+    """the device stop flag is sticky within a solve.  A look-ahead iteration that is DROPPED because its
+    predecessor entered the true-residual branch (:527) and the loop goes on (:544-546) may have raised it (p.Ap <= 0
+    formed from the recurrence residual); the iteration enqueued again from the true residual must not inherit it, or
+    the solve ends with a spurious Flag 4.  The test double injects p.Ap = -1 into exactly that dropped iteration."""
+    from pcg_mi355x.operator import from_refmeshpart
+
+    def run():
+        _, parts = golden_cases.build_case("n9_stagnate")          # Tol 1e-15: enters the :527 branch, not converged, continues
+        P = parts[0]
+        op = from_refmeshpart(P)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"],
+                                P["GlobData"]["GlobNDofEff"], history=True)
+        op.close()
+        return x, res, hist
+    monkeypatch.setenv("PCG_LOOK_AHEAD", "1")
+    x0, r0, h0 = run()
+    tolb = P_tol = 1e-15 * r0.norm_b
+    first = int(np.flatnonzero(h0[:, 2] <= tolb)[0])               # loop index i of the first entry into the branch
+    assert first + 1 < r0.iters_done                                # ... after which the loop went on
+    monkeypatch.setenv("PCG_TEST_NEG_PQ_AT", str(first + 2))       # enqueue i+2 = the look-ahead behind iteration i, dropped
+    x1, r1, h1 = run()
+    assert (r1.flag, r1.iter, r1.relres, r1.iters_done) == (r0.flag, r0.iter, r0.relres, r0.iters_done)
+    assert np.array_equal(x0, x1) and np.array_equal(h0, h1)
+    monkeypatch.setenv("PCG_TEST_NEG_PQ_AT", str(first + 1))       # control: the same fault in the REAL iteration i is a Flag 4
+    x2, r2, h2 = run()
+    assert r2.flag == 4 and r2.iters_done == first
+
+
 def test_look_ahead_windows_enqueue_exactly_k(hostops):
     """pcg_solve_run(K) must leave nothing in flight: a timed window of K passes is K iterations of device work."""
     _, parts = golden_cases.build_case("n9_p1")

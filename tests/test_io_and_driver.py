@@ -106,3 +106,30 @@ def test_multiple_load_steps_reuse_previous_solution_as_x0(hostops):
     assert list(flag[1:]) == [0, 0] and [int(v) for v in it[1:]] == its
     assert its[1] < its[0]                                              # the warm start pays off: x0 matters
     assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
+def test_write_partition_needs_the_complete_set_and_sorts_by_id(tmp_path):
+    """the metadata arrays are indexed by part id (pcg_solver.py:100-106); a subset must be refused and an
+    unsorted list must still give files every rank can read back."""
+    import golden_cases
+    from pcg_mi355x.io import write_partition, read_partition
+    _, parts = golden_cases.build_case("n9_p8")
+    with pytest.raises(ValueError):
+        write_partition(str(tmp_path) + "/sub_", parts[2:5])
+    shuffled = [parts[k] for k in (5, 0, 7, 2, 1, 6, 3, 4)]
+    prefix = str(tmp_path) + "/all_"
+    write_partition(prefix, shuffled)
+    for k in range(8):
+        q = read_partition(prefix, 8, k)
+        assert int(q["Id"]) == k and np.array_equal(q["DofVector"], parts[k]["DofVector"])
+
+
+def test_multi_process_cpu_baseline_matches_one_process(oracle_c):
+    """oracle/mp_baseline.py (bench.py's multi-core cpu_baseline): R real processes exchanging through shared memory
+    must walk the same PCG as one process - the residual after a fixed number of iterations agrees to rounding."""
+    import mp_baseline
+    one = mp_baseline.run(13, 1, 25)
+    four = mp_baseline.run(13, 4, 25)
+    assert one["n_matvec"] == four["n_matvec"] == 27
+    assert abs(one["relres_after"] / four["relres_after"] - 1) < 1e-9
+    assert four["cores"] == 4 and four["comm_wait_s_mean"] > 0

@@ -108,3 +108,55 @@ def test_empty_group_and_isolated_nodes(hostops):
         y = op.apply(x)
         assert relerr(y, ref) < 1e-13 and np.all(y[ref == 0] == 0)
         op.close()
+
+
+def _mixed_layout_parts(N=9, grid=(1, 1, 2)):
+    """Brick parts whose hex8 group is split in two: the first half keeps the node-major slot order (chunked kernels),
+    the second half is rewritten direction-major (x dofs of the 8 nodes, then y, then z): the same elements for the
+    oracle, but a pattern type the chunked form does not take (colour-by-colour launches that ADD into y)."""
+    from pcg_mi355x.brick import Brick, make_parts, block_partition
+    b = Brick(N, seed=0)
+    parts = make_parts(b, block_partition(b, *grid))
+    axis = int(np.argmax(grid))
+    perm = np.array([3 * a + d for d in range(3) for a in range(8)])          # new slot -> old slot
+    for P in parts:
+        g = P["SubDomainData"]["StrucDataList"][0]
+        # split by layer parity across the interface direction: the layer next to the interface is colour-launched
+        # (interface phase) and shares its lower nodes with chunked elements that do NOT touch the interface
+        # (interior phase) - the configuration in which a phase-0 `+=` was overwritten by a phase-1 store
+        zlay = np.rint(np.asarray(P["NodeCoordVec"], float)[g["ElemList_LocDofVector"][0] // 3 * 3 + axis]).astype(int)
+        top = zlay.max()
+        out = []
+        for t, (sl, pm_) in enumerate([(np.flatnonzero((top - zlay) % 2 == 1), None), (np.flatnonzero((top - zlay) % 2 == 0), perm)]):
+            tbl = np.ascontiguousarray(g["ElemList_LocDofVector"][:, sl])
+            sgn = np.ascontiguousarray(g["ElemList_SignVector"][:, sl])
+            Ke = g["ElemStiffMat"]
+            if pm_ is not None:
+                tbl, sgn, Ke = np.ascontiguousarray(tbl[pm_]), np.ascontiguousarray(sgn[pm_]), np.ascontiguousarray(Ke[np.ix_(pm_, pm_)])
+            out.append({"ElemTypeId": t, "ElemList_LocDofVector": tbl, "ElemList_LocDofVector_Flat": tbl.ravel(),
+                        "ElemList_SignVector": sgn, "ElemList_Ck": g["ElemList_Ck"][sl].copy(), "ElemStiffMat": Ke,
+                        "ElemDiagStiffMat": np.diag(Ke).copy(), "N_Elem": tbl.shape[1]})
+        P["SubDomainData"] = {"StrucDataList": out, "MixedDataList": {}}
+        P["Flat_ElemLocDof"] = np.concatenate([q["ElemList_LocDofVector_Flat"] for q in out])
+        P["NCountDof"] = len(P["Flat_ElemLocDof"])
+    return b, parts
+
+
+def check_mixed_layout_multi_part(on_gpu):
+    from thread_comm import solve_parts_in_threads
+    for N, grid in [(9, (2, 1, 1)), (25, (1, 1, 2))]:
+        b, parts = _mixed_layout_parts(N, grid)
+        ref = copy.deepcopy(parts)
+        out = pcg_oracle.solve_step(ref)
+        infos = solve_parts_in_threads(parts, "ebe", on_gpu=on_gpu)
+        assert all((i.flag, i.iter) == (infos[0].flag, infos[0].iter) for i in infos)
+        assert infos[0].flag == out["flag"] == 0 and abs(infos[0].iter - out["iter"]) <= 1
+        for P, R in zip(parts, ref):
+            assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
+def test_mixed_chunked_and_colour_groups_with_neighbours(hostops):
+    """a part WITH neighbours whose groups are partly chunkable, partly not.  The colour launches of the
+    interface phase add into y, the chunk stores of the interior phase assign: interleaving the phases with the
+    exchange would drop contributions, so such parts run the whole operator before the exchange."""
+    check_mixed_layout_multi_part(False)

@@ -1,0 +1,127 @@
+"""The engine's native communicator (csrc/rccl_comm.hip: grouped ncclSend/ncclRecv on a comm stream, ncclAllReduce on
+the compute stream - no Python in the loop) on the GPU, against the fixtures the reference produced with the same
+partitions (pcg_solver.py:303-334 Isend/Recv/Waitall, :622-628 MPI_SUM).
+
+  * real librccl at world size 1 (the test box has one GPU): bootstrap, ncclCommInitRank x2, ncclAllReduce in place on
+    the status block inside the look-ahead loop, the event timers;
+  * real librccl across GPUs when the box has >= 2 / >= 8 of them (auto-skipped otherwise);
+  * 2..8 parts on ONE GPU through tests/fakenccl (a stand-in for librccl between ranks that share a device): the engine's
+    whole multi-part path - fences, comm stream, per-neighbour offsets, k_halo_pack / k_fixup, phase split of both
+    operators - as threads of one process and as separate processes.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import ROOT, golden, relerr, check_solution_against_golden
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "native_comm_worker.py")
+
+
+def _env(fake):
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.pop("PCG_RCCL_LIB", None)
+    if fake:
+        import conftest
+        env["PCG_RCCL_LIB"] = conftest.build_fakenccl()
+    return env
+
+
+def _collect(case, kind, outdir, world):
+    outs = [np.load(os.path.join(outdir, f"{case}_{kind}_rank{r}.npz")) for r in range(world)]
+    g = golden(case)
+    n = len(g["Fext"])
+    U = np.zeros(n); Y = np.zeros(n); F = np.zeros(n); D = np.zeros(n)
+    for o in reversed(outs):
+        U[o["dofs"]] = o["Un"]; Y[o["dofs"]] = o["y_probe"]; F[o["dofs"]] = o["Fext"]; D[o["dofs"]] = o["diag"]
+    return outs, g, U, Y, F, D
+
+
+def _check(case, kind, outdir, world):
+    outs, g, U, Y, F, D = _collect(case, kind, outdir, world)
+    assert relerr(Y, g["y_probe"]) < 1e-13
+    assert relerr(D, g["diag"]) < 1e-14
+    assert relerr(F, g["Fext"]) < 1e-13
+    o0 = outs[0]
+    for o in outs:                                      # every rank took the same decisions
+        assert (int(o["flag"]), int(o["iter"])) == (int(o0["flag"]), int(o0["iter"]))
+        assert float(o["relres"]) == float(o0["relres"])
+    tol_u = 1e-8 if int(g["flag"]) == 0 else 1e-6
+    check_solution_against_golden(g, int(o0["flag"]), int(o0["iter"]), float(o0["relres"]), U, o0["history"],
+                                  tol_iter=1 if kind == "ebe" else 0, tol_u=tol_u)
+    # two all-reduces per enqueued iteration + the true-residual / norm ones; one exchange per operator apply
+    for o in outs:
+        assert int(o["stat_n_allreduce"]) >= 2 * int(o["iters_done"])
+        if world > 1:
+            assert int(o["stat_n_halo"]) >= int(o["iters_done"])
+    return outs
+
+
+def test_real_rccl_world_size_1(gpu_lib, tmp_path):
+    """librccl itself, one rank: the product's bootstrap + the all-reduce path; must equal the communicator-free run."""
+    idf = str(tmp_path / "id")
+    for kind in ("sell", "ebe"):
+        r = subprocess.run([sys.executable, WORKER, "proc", "n9_p1", kind, str(tmp_path), "0", "1", idf + kind], env=_env(False),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs = _check("n9_p1", kind, tmp_path, 1)
+        assert int(outs[0]["stat_n_allreduce_timed"]) > 0 and float(outs[0]["stat_allreduce_ms"]) > 0     # a7: GPU-side comm time
+        assert 0 < float(outs[0]["t_comm"]) < float(outs[0]["t_total"])
+
+
+@pytest.mark.parametrize("cases", ["n9_p2,n9_p8", "n9_p2_flag4,n9_p2_maxiter", "oct_p3,oct_p2_z,n13_t3_p4_ud"])
+def test_parts_as_threads_on_one_gpu(gpu_lib, tmp_path, cases):
+    r = subprocess.run([sys.executable, WORKER, "threads", cases, "sell,ebe", str(tmp_path)], env=_env(True),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for case in cases.split(","):
+        world = len([f for f in os.listdir(tmp_path) if f.startswith(case + "_sell_rank")])
+        for kind in ("sell", "ebe"):
+            _check(case, kind, tmp_path, world)
+
+
+def _run_procs(case, kind, world, outdir, fake, devices):
+    idf = os.path.join(str(outdir), f"id_{case}_{kind}")
+    procs = [subprocess.Popen([sys.executable, WORKER, "proc", case, kind, str(outdir), str(r), str(world), idf, str(devices[r])],
+                              env=_env(fake), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+
+
+@pytest.mark.parametrize("case,world,kind", [("n9_p2", 2, "sell"), ("oct_p3", 3, "ebe")])
+def test_parts_as_processes_sharing_one_gpu(gpu_lib, tmp_path, case, world, kind):
+    """One process per part as in production (file bootstrap of the unique id), all on device 0."""
+    _run_procs(case, kind, world, tmp_path, True, [0] * world)
+    _check(case, kind, tmp_path, world)
+
+
+@pytest.mark.parametrize("case,world", [("n9_p2", 2), ("oct_p3", 3), ("n13_t3_p4_ud", 4), ("n9_p8", 8)])
+def test_real_rccl_across_gpus(gpu_lib, tmp_path, case, world):
+    """RCCL over xGMI between DIFFERENT GPUs: one process per GPU, grouped ncclSend/ncclRecv + ncclAllReduce."""
+    if gpu_lib.lib().pcg_device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    for kind in ("sell", "ebe"):
+        _run_procs(case, kind, world, tmp_path, False, list(range(world)))
+        _check(case, kind, tmp_path, world)
+
+
+def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
+    """`python bench.py --gpus 2` (no torchrun around it) spawns its two ranks itself.  On the 1-GPU box the ranks share
+    the device (PCG_BENCH_SHARE_GPU=1) and talk through the RCCL stand-in; the line it prints has the driver's shape."""
+    env = _env(True)
+    env["PCG_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--nodes-per-side", "31", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0
+    assert out["comm"]["ranks"] == 2 and out["comm"]["transport"].startswith("native")
+    assert out["solve"]["flag"] == 0

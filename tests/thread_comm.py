@@ -41,6 +41,8 @@ class ThreadComm:
             raise e
 
     def _view(self, ptr, n):
+        if not n:                   # a part without neighbours enters the exchange with nothing to send
+            return np.zeros(0)
         if self.w.on_gpu:
             import torch
             from pcg_mi355x.dist import _DevView
@@ -53,9 +55,11 @@ class ThreadComm:
             torch.cuda.ExternalStream(int(stream_p or 0)).synchronize()
 
     def _host(self, v):
-        return v.cpu().numpy().copy() if self.w.on_gpu else np.array(v, copy=True)
+        return v.cpu().numpy().copy() if (self.w.on_gpu and not isinstance(v, np.ndarray)) else np.array(v, copy=True)
 
     def _store(self, v, values):
+        if isinstance(v, np.ndarray) and not v.size:
+            return
         if self.w.on_gpu:
             import torch
             v.copy_(torch.from_numpy(np.ascontiguousarray(values)))
@@ -64,7 +68,7 @@ class ThreadComm:
             v[...] = values
 
     def make_hooks(self, op):
-        peers, counts = list(op.peer_ids), list(op.peer_counts)
+        peers, counts = list(getattr(op, "peer_ids", [])), list(getattr(op, "peer_counts", []))
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
 
         def halo_begin(ctx, send_p, recv_p, count, stream_p):

@@ -122,3 +122,23 @@ def make_super_part(N, seed=0):
     P["Flat_ElemLocDof"] = np.concatenate([g["ElemList_LocDofVector_Flat"] for g in groups])
     P["NCountDof"] = len(P["Flat_ElemLocDof"])
     return b, P
+
+
+def island_parts():
+    """Three parts for a 3-rank job: the two halves of a 9^3 brick (neighbours) and a separate 5^3 brick as part 2,
+    which has NO neighbours (a disconnected component of the model).  The reference's Isend/Recv loops simply run over
+    an empty NbrMPIdVector for such a rank (pcg_solver.py:318-328); a communicator that implements the exchange as a
+    group-wide collective must still be entered by it."""
+    import golden_cases
+    from pcg_mi355x.brick import Brick, make_parts
+    b9, parts = golden_cases.build_case("n9_p2")
+    isl = make_parts(Brick(5, seed=3))[0]
+    isl["Id"] = 2
+    isl["DofVector"] = isl["DofVector"] + b9.n_dof
+    n_eff = parts[0]["GlobData"]["GlobNDofEff"] + isl["GlobData"]["GlobNDofEff"]
+    n_all = parts[0]["GlobData"]["GlobNDof"] + isl["GlobData"]["GlobNDof"]
+    for p in parts + [isl]:
+        p["GlobData"]["GlobNDofEff"] = n_eff
+        p["GlobData"]["GlobNDof"] = n_all
+        p["GlobData"]["Tol"], p["GlobData"]["MaxIter"] = 1e-7, 10000
+    return parts + [isl]
