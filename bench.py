@@ -20,7 +20,8 @@ Objects on the JSON line besides the contract's fields:
                  stored 3x3 block + x in + y out) / mean launch time from HIP events on the engine stream inside the
                  timed region -> achieved GB/s, frac = achieved / 8 TB/s (<= 1 by construction).  The SURVEY 8(d)
                  CSR-equivalent figure (12 nnz + 20 n: what a scalar-CSR kernel would have to move) is reported
-                 separately as csr_equivalent_*; `hbm_copy_GBps` is a device copy measured in this run on this box.
+                 separately as csr_equivalent_*; `hbm_stream_this_box` is a plain read / copy stream measured in this run
+                 on this box (pcg_bench_hbm), the practical ceiling beside the spec.
   matrix_free  - the reference's element-by-element operator on the same system, with its own roofline object
                  (flops vs the 78.6 TF f64 vector peak and bytes vs 8 TB/s).
   comm         - N > 1: transport, ranks seen by RCCL, per-iteration exchange wait / all-reduce time (HIP events,
@@ -146,7 +147,8 @@ def cpu_baseline_single(part, budget_s=10.0):
 
 def cpu_baseline(part, N, ranks=0, workload="brick"):
     """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core."""
-    avail = len(os.sched_getaffinity(0))
+    import mp_baseline
+    avail = mp_baseline.available_cores()
     single = cpu_baseline_single(part)
     out = {"kind": "port", "unit": "iterations/s", "host_cpu": _cpu_model(), "host_cores_available": avail,
            "single_core": single}
@@ -194,25 +196,6 @@ def box_identity(dev):
     except Exception as ex:      # noqa: BLE001
         info["rocm_smi_error"] = repr(ex)[:200]
     return info
-
-
-def hbm_copy_GBps(dev, gib=1.0, reps=20):
-    """Device-to-device copy bandwidth of THIS box (read + write bytes / time): the practical HBM ceiling beside 8 TB/s."""
-    import torch
-    n = int(gib * 2**30) // 8
-    a = torch.empty(n, dtype=torch.float64, device=f"cuda:{dev}").normal_()
-    b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ts = []
-    for _ in range(reps):
-        e0.record(); b.copy_(a); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    del a, b
-    torch.cuda.empty_cache()
-    ts.sort()
-    return 2.0 * n * 8 / (ts[len(ts) // 2] * 1e-3) / 1e9
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -364,8 +347,8 @@ def main():
         return {"op": op, "elapsed": elapsed, "per_rank_s": per_rank, "op_ms": op_ms, "n_op": n_op, "final": final,
                 "standalone": standalone, "t_setup": t_setup, "comm": comm_info}
 
-    copy_GBps = hbm_copy_GBps(dev) if rank == 0 else None
     box = box_identity(dev) if rank == 0 else None
+    stream = None
 
     m = None
     if args.operator in ("both", "sell"):
@@ -374,6 +357,9 @@ def main():
         info = op.matrix_info()
         n_loc, nnz_loc = op.n, op.nnz
         sell_bytes, sell_flops = op.operator_cost()
+        if rank == 0:                                # what THIS box's HBM delivers to a plain stream kernel on the engine's stream
+            stream = {"read_GBps": op.bench_hbm(2 << 30, "read"), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
+                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 2 GiB (read) / 1 + 1 GiB (copy)"}
         if rank == 0:
             if brick.nnz is None:
                 brick.nnz = op.nnz if world == 1 else None
@@ -407,6 +393,8 @@ def main():
                                     "bound": "neither saturated: latency / LDS-phase bound (DESIGN.md 4b)"}}
         if m is None:
             n_loc = e["op"].n
+            if rank == 0:
+                stream = {"read_GBps": e["op"].bench_hbm(2 << 30, "read"), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
         e["op"].close()
 
     if rank != 0:
@@ -427,7 +415,7 @@ def main():
                    "operator": "assembled SELL-BSR3" if m is not None else "matrix-free (EBE)"},
         "solve": head["final"],
         "matrix_free": matrix_free if m is not None else None,
-        "box": box,
+        "box": dict(box or {}, hbm_stream=stream),
     }
     if m is not None:
         t_k = m["op_ms"] * 1e-3
@@ -445,7 +433,7 @@ def main():
             "traffic": None,
             "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 passes of their own; the committed passes for this kernel are under "
                             "profiles/ (DESIGN.md section 8) - traffic / bytes_per_launch = 1.03",
-            "hbm_copy_GBps": copy_GBps, "frac_of_copy": achieved / copy_GBps if copy_GBps else None,
+            "hbm_stream_this_box": stream, "frac_of_stream_read": achieved / stream["read_GBps"] if stream else None,
             "csr_equivalent_bytes": alg_bytes, "csr_equivalent_GBps": alg_bytes / t_k / 1e9,
             "csr_equivalent_note": "SURVEY 8(d) formula 12 nnz + 20 n: a scalar-CSR kernel's traffic for the same product; NOT what this "
                                    "kernel moves (it can exceed the HBM peak) - kept for comparison with CSR codes only",

@@ -37,6 +37,24 @@ for p in (os.path.join(ROOT, "pcg-mpi-solver_amd"), HERE):
 RED_W = 8                                     # doubles per all-reduce slot
 
 
+def available_cores():
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota when the container has one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                   # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def grid_for(r):
     """px*py*pz = r, as cubic as possible (the reference would get its parts from METIS, run_metis.py:88)."""
     best = (1, 1, r)
@@ -86,8 +104,11 @@ def worker(rank, R, N, iters, prefix, use_c):
         epoch[0] += 1
         arrive[rank] = epoch[0]
         e = epoch[0]
+        spins = 0
         while int(arrive.min()) < e:
-            pass
+            spins += 1
+            if spins > 2000:                      # a late rank: stop burning the core it may need
+                time.sleep(5e-5)
 
     brick = Brick(N, seed=0)
     P = make_parts(brick, block_partition(brick, *grid_for(R)) if R > 1 else None, only=[rank])[0]
@@ -207,7 +228,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--numpy", action="store_true", help="NumPy EBE mat-vec (the reference's expressions) instead of the C port")
     a = ap.parse_args()
-    R = a.ranks or min(len(os.sched_getaffinity(0)), 64)
+    R = a.ranks or min(available_cores(), 64)
     print(json.dumps(run(a.nodes_per_side, R, a.iters, not a.numpy)), flush=True)
 
 

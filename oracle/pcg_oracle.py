@@ -147,8 +147,12 @@ class TooSmallTolerance(Warning):
     """The reference does `raise Warning('PCG : TooSmallTolerance')` (pcg_solver.py:549)."""
 
 
-def pcg(parts, use_c=False, record=True):
+def pcg(parts, use_c=False, record=True, observer=None):
     """PCG(RefMeshPart) on all parts in lock-step.  pcg_solver.py:356-598.
+
+    observer (tests only, no effect on the arithmetic): called once per completed iteration with the vectors of that
+    iteration (copies of R and X from before the updates, P, Q, the updated R and X, rho, beta, pq, alpha and the three
+    sums of :504-507), so a lock-step test can feed the SAME inputs to the engine's kernels iteration by iteration.
 
     Mutates the part dicts like the reference (`Un`, rank-0 GlobData['TimeList_*']).  Returns a
     dict with flag/relres/iter (as stored), history (rows [NormP, NormX, NormR] per iteration,
@@ -242,6 +246,8 @@ def pcg(parts, use_c=False, record=True):
         if np.isinf(alpha):
             flag = 4
             break
+        if observer is not None:
+            r_before, x_before = [r.copy() for r in R], [x.copy() for x in X]
         for r, q in zip(R, Q):                                          # :501
             r -= alpha * q
         sq = _allreduce([np.array([np.dot(pv, pv * w), np.dot(x, x * w), np.dot(r, r * w)])
@@ -255,6 +261,9 @@ def pcg(parts, use_c=False, record=True):
             stag = 0
         for x, pv in zip(X, Pv):                                        # :516 (in place: XMin aliases X until :557)
             x += alpha * pv
+        if observer is not None:
+            observer(dict(i=i, beta=(None if i == 0 else beta), rho=rho, pq=pq, alpha=alpha, sq=np.array(sq), P=Pv, Q=Q,
+                          R_before=r_before, X_before=x_before, R_after=R, X_after=X, Minv=Minv, W=W, eff=eff))
         normr_act = normr                                               # :518
         if normr <= tolb or stag >= max_stag or more > 0:               # :527
             for xu, e, x in zip(X_unq, eff, X):                         # :528

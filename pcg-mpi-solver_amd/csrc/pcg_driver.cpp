@@ -893,6 +893,14 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
     });
 }
 
+int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each)
+{
+    return guarded("pcg_bench_hbm", [&]() -> int {
+        if (!e || bytes < 16 || reps < 1 || !ms_each || (mode != 0 && mode != 1)) return set_error("pcg_bench_hbm: bad argument");
+        return e->be->bench_hbm((size_t)bytes, mode, reps, ms_each);
+    });
+}
+
 int pcg_operator_info(pcg_engine *e, int32_t *kind, int64_t *n_elem, int64_t *n_slots, int32_t *n_colors, int64_t *n_chunks)
 {
     if (!e) return set_error("null");

@@ -41,6 +41,7 @@ class RcclComm:
     """
     native = True
     backend = "rccl-native"
+    group = None                # result-file offsets etc. go over the default torch.distributed group when there is one
 
     def __init__(self, rank, world, device, unique_id):
         if len(unique_id) != _lib.RCCL_ID_BYTES:

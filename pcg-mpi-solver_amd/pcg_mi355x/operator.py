@@ -269,6 +269,12 @@ class Operator:
         check(self._L.pcg_bench_spmv(self._h, warmup, reps, ms.ctypes.data), "pcg_bench_spmv")
         return ms
 
+    def bench_hbm(self, nbytes=2 << 30, mode="read", reps=20):
+        """GB/s of a device stream over `nbytes`: mode "read" (read-only) or "copy" (traffic = 2 * nbytes)."""
+        ms = np.zeros(reps, np.float32)
+        check(self._L.pcg_bench_hbm(self._h, int(nbytes), 1 if mode == "copy" else 0, reps, ms.ctypes.data), "pcg_bench_hbm")
+        return (2 if mode == "copy" else 1) * nbytes / (float(np.median(ms)) * 1e-3) / 1e9
+
     def operator_info(self):
         k, a, b, c, d = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
         check(self._L.pcg_operator_info(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_operator_info")

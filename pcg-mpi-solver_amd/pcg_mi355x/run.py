@@ -92,6 +92,8 @@ def main(argv=None):
     ap.add_argument("--max-iter", type=int, default=10000)
     ap.add_argument("--results", required=True, help="result directory (Results_Run<R>)")
     ap.add_argument("--operator", choices=["sell", "ebe"], default="sell")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="N > 1: native = RCCL calls issued by the engine (default); torch = torch.distributed callbacks")
     ap.add_argument("--speed-test", action="store_true")
     args = ap.parse_args(argv)
 
@@ -103,13 +105,24 @@ def main(argv=None):
     n_parts = args.n_parts or world
     if n_parts != world:
         raise SystemExit("one process (GPU) per mesh part: launch with --nproc-per-node <n_parts> (pcg_solver.py:91)")
-    torch.cuda.set_device(local_rank)
+    share = os.environ.get("PCG_RUN_SHARE_GPU") == "1"      # dry run on a 1-GPU box: all ranks on device 0 (needs PCG_RCCL_LIB)
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
     comm = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from .dist import TorchComm
-        comm = TorchComm(device=torch.device("cuda", local_rank))
-    solver.configure(comm=comm, device=local_rank, operator=args.operator)
+        # torch.distributed is the control plane only (unique-id broadcast, result-file offsets, barriers)
+        if share:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        from .dist import RcclComm, TorchComm
+        if args.comm == "native":
+            comm = RcclComm.from_torch(dev)
+            comm.set_timing(True)                          # the reference always keeps its calc / comm-wait split (:631-641)
+        else:
+            comm = TorchComm(device=torch.device("cuda", dev))
+    solver.configure(comm=comm, device=dev, operator=args.operator)
 
     gd = init_glob_data()
     t0 = time.time()

@@ -65,6 +65,29 @@ def _account(GlobData, t_total, t_comm):
         rec["t0"] = time.time()
 
 
+class _Timed:
+    """updateTime around a set-up call (updateBC / updatePreconditioner contain one mat-vec + exchange each): wall time
+    goes to 'calculation' except what the native communicator measured as blocked in communication."""
+
+    def __init__(self, GlobData):
+        self.gd = GlobData
+
+    def __enter__(self):
+        c = _cfg["comm"]
+        self.c0 = c.stats() if getattr(c, "native", False) else None
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        t = time.perf_counter() - self.t0
+        t_comm = 0.0
+        if self.c0 is not None:
+            c1 = _cfg["comm"].stats()
+            t_comm = 1e-3 * ((c1["halo_wait_ms"] - self.c0["halo_wait_ms"]) + (c1["allreduce_ms"] - self.c0["allreduce_ms"]))
+        _account(self.gd, t, min(t, t_comm))
+        return False
+
+
 def calc_matvec_prod(RefMeshPart, ComputeReference="Strain", MP_Xn=None):
     """calcMatVecProd (:242-336): interface-summed A.x ('Strain') or diag(A) ('Preconditioner')."""
     op = get_operator(RefMeshPart)
@@ -85,7 +108,8 @@ def update_bc(RefMeshPart):
     gd = RefMeshPart["GlobData"]
     delta = gd["TimeStepDelta"][gd["TimeStepCount"]]
     op = get_operator(RefMeshPart)
-    fext, udi = op.update_bc(RefMeshPart["RefLoadVector"], RefMeshPart["Ud"], delta)
+    with _Timed(gd):
+        fext, udi = op.update_bc(RefMeshPart["RefLoadVector"], RefMeshPart["Ud"], delta)
     RefMeshPart["Fext"] = fext
     RefMeshPart["Udi"] = udi
 
@@ -93,7 +117,8 @@ def update_bc(RefMeshPart):
 def update_preconditioner(RefMeshPart):
     """updatePreconditioner (:346-352): InvDiagPreCondVector0 = (1/diag(A))[LocDofEff]."""
     op = get_operator(RefMeshPart)
-    inv = op.build_jacobi()
+    with _Timed(RefMeshPart.get("GlobData")):
+        inv = op.build_jacobi()
     RefMeshPart["InvDiagPreCondVector0"] = inv[np.asarray(RefMeshPart["LocDofEff"], np.int64)]
 
 

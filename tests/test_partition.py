@@ -227,3 +227,71 @@ def test_mdf_to_solution_on_gpu(gpu_lib, name, kind, tmp_path):
     un = pio.read_result_vector(os.path.join(results, "ResVecData", "U_1"))
     check_solution_against_golden(g, int(td["Flag"][1]), int(td["Iter"][1]), float(td["RelRes"][1]), un, None,
                                   tol_iter=1 if kind == "ebe" else 0)
+
+
+def _oracle_load_steps(model, ele_part, deltas):
+    """The reference's load-step loop (pcg_solver.py:1002-1008) on the oracle: per step the global solution."""
+    import pcg_oracle
+    parts = pc.prepare_for_solve(partition.partition_model(model, ele_part))
+    n = len(deltas)
+    for p in parts:
+        p["GlobData"]["TimeStepDelta"] = list(deltas)
+        p["GlobData"]["TimeList_Flag"], p["GlobData"]["TimeList_RelRes"], p["GlobData"]["TimeList_Iter"] = np.zeros(n), np.zeros(n), np.zeros(n)
+    sols, its = [], []
+    for step in range(1, n):
+        for p in parts:
+            p["GlobData"]["TimeStepCount"] = step
+        out = pcg_oracle.solve_step(parts)
+        assert out["flag"] == 0
+        un = np.zeros(model["GlobNDof"])
+        for p in reversed(parts):
+            un[p["DofVector"]] = p["Un"]
+        sols.append(un); its.append(out["iter"])
+    return sols, its
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("name,ranks", [("part_brick_p1", 1), ("part_octree_p3", 3)])
+def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
+    """SURVEY 8(f)-4 on the HIP engine: MDF -> `python -m pcg_mi355x.run` with TWO load steps (warm start from the
+    previous Un, :358,:378) -> U_<k>.mpidat / TimeData in the layout export_vtk.py reads, vs the oracle's loop.
+    3 ranks: one process per part with the engine's native communicator; on the 1-GPU box they share the device and talk
+    through the RCCL stand-in (tests/fakenccl), with >= 3 GPUs through librccl.  The calc / comm-wait split (a7) comes
+    from HIP events around the exchange wait and the all-reduces."""
+    import subprocess
+    import sys
+    import conftest
+    from pcg_mi355x import io as pio
+    from util import ROOT
+    deltas = [0, 0.5, 1.0]
+    model, ele_part = pc.build_model(name)
+    path = mdf.write_mdf(str(tmp_path / "MDF"), model)
+    if ranks > 1:
+        mdf.write_mesh_part(path, ele_part)
+    settings = {"TimeHistoryParam": dict(SETTINGS["TimeHistoryParam"], TimeStepDelta=deltas), "SolverParam": SETTINGS["SolverParam"]}
+    pio.exportz(str(tmp_path / "GlobSettings.zpkl"), settings)
+    results = str(tmp_path / "Results_Run1")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "pcg-mpi-solver_amd"))
+    cmd = [sys.executable]
+    if ranks > 1:
+        if gpu_lib.lib().pcg_device_count() < ranks:
+            env.update(PCG_RUN_SHARE_GPU="1", PCG_RCCL_LIB=conftest.build_fakenccl())
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                "--master-port", str(29700 + (kind == "ebe"))]
+    cmd += ["-m", "pcg_mi355x.run", "--mdf", path, "--settings", str(tmp_path / "GlobSettings.zpkl"), "--results", results,
+            "--operator", kind]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    sols, its = _oracle_load_steps(model, ele_part, deltas)
+    td = np.load(os.path.join(results, "PlotData", "TimeData.npz"))
+    dof = pio.read_result_vector(os.path.join(results, "ResVecData", "Dof"))
+    assert len(np.unique(dof)) == len(dof) == model["GlobNDof"]
+    for k in (1, 2):
+        u = pio.read_result_vector(os.path.join(results, "ResVecData", f"U_{k}"))
+        assert int(td["Flag"][k]) == 0 and abs(int(td["Iter"][k]) - its[k - 1]) <= 1
+        assert relerr(u, sols[k - 1][dof]) < 2e-7
+    assert list(np.load(os.path.join(results, "ResVecData", "Time_T.npy"))) == [0.0, 1.0, 2.0]
+    assert float(td["CalcTime"]) > 0
+    if ranks > 1:
+        assert 0 < float(td["CommWaitTime"]) < float(td["TotalTime"])         # a7: time blocked in communication (GPU side)
