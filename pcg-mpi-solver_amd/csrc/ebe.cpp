@@ -428,18 +428,25 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             for (size_t k = 0; k < C.sh_node[ph].size(); ++k) C.sh_ptr[ph][k + 1] = C.sh_ptr[ph][k] + cnt[C.sh_node[ph][k]];
             C.sh_slot[ph].assign((size_t)C.sh_ptr[ph].back(), 0);
         }
+        // Boundary slots are numbered NODE-major: the slots of one shared node are consecutive (ascending chunk id =
+        // the summation order), the nodes of a phase follow each other in ascending node id.  The shared-node kernel
+        // then streams the buffer front to back (consecutive threads read consecutive runs) instead of chasing one
+        // slot index per addend; a chunk's stores scatter a little more, but stores are fire-and-forget.
+        const int32_t phase_base[2] = {0, C.sh_ptr[0].back()};
+        C.n_slots = (int64_t)C.sh_ptr[0].back() + C.sh_ptr[1].back();
         std::vector<int32_t> fill[2];
         for (int ph = 0; ph < 2; ++ph) fill[ph].assign(C.sh_ptr[ph].begin(), C.sh_ptr[ph].end() - 1);
+        for (int ph = 0; ph < 2; ++ph)
+            for (size_t q = 0; q < C.sh_slot[ph].size(); ++q) C.sh_slot[ph][q] = phase_base[ph] + (int32_t)q;
         C.dst.resize(C.nodes.size());
         for (int64_t c = 0; c < C.n_chunks; ++c) {                     // ascending chunk id = summation order
             const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1];
             for (int k = 0; k < nn; ++k) {
                 const int32_t nd = C.nodes[off + k];
                 if (cnt[nd] == 1) { C.dst[off + k] = 3 * nd; continue; }
-                const int32_t slot = (int32_t)C.n_slots++;
-                C.dst[off + k] = -(slot + 1);
                 const int ph = final_phase[nd];
-                C.sh_slot[ph][fill[ph][sh_index[nd]]++] = slot;
+                const int32_t slot = phase_base[ph] + fill[ph][sh_index[nd]]++;
+                C.dst[off + k] = -(slot + 1);
             }
         }
         for (int ph = 0; ph < 2; ++ph) {

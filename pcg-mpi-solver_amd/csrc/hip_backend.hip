@@ -599,10 +599,11 @@ __global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
 }
 
 
-// nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id
+// nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id.  Slots are numbered node-major
+// (ebe.cpp): node k of the phase owns slots slot0 + [sh_ptr[k], sh_ptr[k+1]) - consecutive threads stream consecutive runs.
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
-                                                       const int *__restrict__ sh_slot, const double *__restrict__ buf,
+                                                       int slot0, const double *__restrict__ buf,
                                                        double *__restrict__ y, int count, const double *__restrict__ x,
                                                        const uint8_t *__restrict__ flags, double *__restrict__ partials,
                                                        long long dot_lo)
@@ -611,10 +612,9 @@ __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ s
     double dot = 0.0;
     if (k < count) {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int q = sh_ptr[k]; q < sh_ptr[k + 1]; ++q) {
-            const double *b = buf + 3 * (size_t)sh_slot[q];
-            s0 += b[0]; s1 += b[1]; s2 += b[2];
-        }
+        const int q0 = sh_ptr[k], q1 = sh_ptr[k + 1];
+        const double *b = buf + 3 * (size_t)(slot0 + q0);
+        for (int q = q0; q < q1; ++q, b += 3) { s0 += ntload(b); s1 += ntload(b + 1); s2 += ntload(b + 2); }
         const size_t d0 = 3 * (size_t)sh_node[k];
         double *yp = y + d0;
         yp[0] = s0; yp[1] = s1; yp[2] = s2;
@@ -928,7 +928,8 @@ class HipBackend : public Backend {
     } chc_[kChunkClasses];
     int n_chunks_total_[2] = {0, 0};
     int sh_count_[2] = {0, 0};
-    int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr}, *d_sh_slot_[2] = {nullptr, nullptr};
+    int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr};
+    int sh_slot0_[2] = {0, 0};
     int *d_ch_dst_ = nullptr;
     double *d_ch_buf_ = nullptr;
     double *d_part_ebe_ = nullptr;    // fused-dot partials of the chunk / shared launches of one apply
@@ -1012,7 +1013,7 @@ public:
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke})
                 if (p) (void)hipFree(p);
         for (void *p : {(void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_tslot_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
-                        (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1], (void *)d_sh_slot_[0], (void *)d_sh_slot_[1]})
+                        (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1]})
             if (p) (void)hipFree(p);
         for (auto &D : ebe_groups_)
             for (void *p : {(void *)D.dof, (void *)D.sgn_bits, (void *)D.sgn_bytes, (void *)D.ck, (void *)D.ke})
@@ -1123,7 +1124,8 @@ public:
             for (int ph = 0; ph < 2; ++ph) {
                 sh_count_[ph] = (int)C.sh_node[ph].size();
                 np += (C.sh_node[ph].size() + kBlock - 1) / kBlock;
-                if (sh_count_[ph]) { up(d_sh_node_[ph], C.sh_node[ph]); up(d_sh_ptr_[ph], C.sh_ptr[ph]); up(d_sh_slot_[ph], C.sh_slot[ph]); }
+                sh_slot0_[ph] = ph ? (int)C.sh_ptr[0].back() : 0;
+                if (sh_count_[ph]) { up(d_sh_node_[ph], C.sh_node[ph]); up(d_sh_ptr_[ph], C.sh_ptr[ph]); }
             }
             d_part_ebe_ = (double *)alloc(sizeof(double) * np);
         }
@@ -1196,10 +1198,10 @@ public:
                 double *part = d_part_ebe_ + cnt_ebe_;
                 if (fuse)
                     hipLaunchKernelGGL((k_ebe_shared<true>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
-                                       d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
+                                       sh_slot0_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
                 else
                     hipLaunchKernelGGL((k_ebe_shared<false>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
-                                       d_sh_slot_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
+                                       sh_slot0_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
                 if (fuse) cnt_ebe_ += grid;
             }
         }

@@ -542,7 +542,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
             for (const auto &K : Ch.cls)                     // per element slot: local node ids, Ck, sign words
                 b += (double)K.n_chunks * kChunkThreads * K.ept * (2.0 * K.nnp + 8.0 + 4.0 * K.words);
             b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
-            for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size() + 4.0 * (double)Ch.sh_slot[ph].size();   // ... y out 24 + lists
+            for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size();   // ... y out 24 + node id + run pointer
             b += 32.0 * (double)Ch.n_chunks;                 // chunk headers
             for (int g = 0; g < n_groups; ++g) {
                 f += 2.0 * (double)groups[g].nd * groups[g].nd * (double)groups[g].ne;

@@ -90,7 +90,8 @@ struct EbeChunkedHost {
     int64_t n_slots = 0;               // boundary-buffer slots (one per (chunk, shared node))
     std::vector<int32_t> sh_node[2];   // per phase: shared nodes whose sum becomes final after that phase (ascending)
     std::vector<int32_t> sh_ptr[2];    //            CSR over their slots
-    std::vector<int32_t> sh_slot[2];   //            slots in ascending chunk order
+    std::vector<int32_t> sh_slot[2];   //            slots in ascending chunk order; node-major numbering: sh_slot[ph][q] ==
+                                       //            (ph ? sh_ptr[0].back() : 0) + q, so a device kernel needs no slot list
     bool needs_zero = false;           // some node is touched by no chunk (isolated, or only by non-chunked groups)
     EbeClassHost cls[kChunkClasses];
     int32_t max_subcolors = 0;
