@@ -217,6 +217,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         K.full = c == 0;
         K.ept = c == 0 ? ept : 1;
         K.words = 3 * K.nnp / 32 + 1;
+        K.max_nodes = (c == 0 && ept == 1) ? 512 : kChunkMaxNodes;      // 8x8x4 hex cells -> 405 nodes: a 2-nodes-per-thread tile
     }
     for (int g = 0; g < n_groups; ++g)
         if (chunkable[g]) {
@@ -360,7 +361,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     }
                     o.elems.push_back(L[k].e);
                 }
-                if ((int)keyed.size() > kChunkMaxNodes) return false;
+                if ((int)keyed.size() > C.cls[cls_of[g]].max_nodes) return false;
                 std::sort(keyed.begin(), keyed.end());
                 for (size_t k = 0; k < keyed.size(); ++k) {
                     o.nodes.push_back(keyed[k].second);

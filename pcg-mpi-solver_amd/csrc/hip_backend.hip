@@ -118,6 +118,7 @@ template <> struct VecT<2> { using d = double2; using i = int2; };
 
 __device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ int ntload(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ unsigned ntload(const unsigned *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ double2 ntload(const double2 *p)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
@@ -442,6 +443,141 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
             }
         }
     }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// hex8 chunks, second form (k_ebe_hex).  Same algorithm, same summation order per node and the same host-side chunk
+// structures as k_ebe_chunk; what changes is how a workgroup gets to its arithmetic and back:
+//   * per-LAUNCH tables (HexTab): block b finds its header, node list (padded to MAXN entries, -1 = none) and element
+//     slots at fixed strides of b - no chunk-id list, no header -> offsets dependency: the node ids, the element data
+//     and the header are three independent loads issued together, the x gather is the only dependent round trip
+//     (k_ebe_chunk: chunk id -> header -> node ids -> x);
+//   * element slot of thread t, copy j: ((t >> 6) * EPT + j) * 64 + (t & 63): a wave owns EPT consecutive 64-slot runs,
+//     so slot order = (wave, j) order, and the LDS accumulation runs wave after wave (each wave its sub-colours in
+//     ascending order, LDS operations of one wave are ordered) with ONE block barrier per wave instead of one per
+//     sub-colour: 4 instead of 8-10 per chunk, same order of additions;
+//   * a sign is an XOR of the sign bit (shift, and, xor) instead of compare + select + two moves.
+// EPT / NPT (tile nodes per thread) / LB (blocks per CU asked of the register allocator) are template parameters so that
+// the occupancy trade-off can be measured (PCG_EBE_HEX, tools/ebe_lab.py).
+// ------------------------------------------------------------------------------------------------
+struct HexTab {
+    const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, -
+    const int *nodes;             // [n][MAXN]  node id, -1 = padding
+    const int *dst;               // [n][MAXN]  >= 0: y offset (exclusive node); < 0: -(boundary slot + 1)
+    const unsigned short *tslot;  // [n][MAXN]  slot in the LDS tile
+    const unsigned short *lid;    // [n][8][CE]
+    const double *ck;             // [n][CE]
+    const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
+};
+
+__device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
+{
+    const unsigned long long m = (unsigned long long)((sg >> b) & 1u) << 63;
+    return __longlong_as_double(__double_as_longlong(v) ^ (long long)m);
+}
+
+template <int EPT, int NPT, int LB, bool DOT>
+__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                               double *__restrict__ y, double *__restrict__ buf,
+                                                               const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                               long long dot_lo)
+{
+    constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int4 h = T.hdr[b];
+    // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
+    unsigned sg[EPT];
+    double c[EPT];
+    int l3[EPT][8];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const size_t slot = (size_t)b * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63);
+        sg[j] = ntload(T.sgn + slot);
+        c[j] = ntload(T.ck + slot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            l3[j][k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63));
+    }
+    int g[NPT], dst[NPT], sl3[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+        g[j] = ntload(T.nodes + n);
+        dst[j] = ntload(T.dst + n);
+        sl3[j] = 3 * (int)__builtin_nontemporal_load(T.tslot + n);
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            const double *xp = x + 3 * (size_t)g[j];
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    __syncthreads();
+    const double *K = ke_col + (size_t)h.z * ND * ND;
+    double acc[EPT][ND];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[j][a] = 0.0;
+#pragma unroll
+    for (int bb = 0; bb < ND; ++bb) {
+        double u[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) u[j] = c[j] * flip_sign(xs[l3[j][bb / 3] + bb % 3], sg[j], bb);    // :277-279 gather, sign, Ck
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            const double k = K[bb * ND + a];                                                             // wave-uniform -> SGPR pair
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);                           // :279 Ke @ (.)
+        }
+    }
+    // ---- LDS-staged partial sums, wave after wave (slot order = sub-colour order) ----------------------------------
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave == w)
+            for (int s = 0; s < h.y; ++s) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j)
+                    if ((int)(sg[j] >> 24) == s) {
+#pragma unroll
+                        for (int q0 = 0; q0 < ND; q0 += 12) {
+                            double old[12];
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[l3[j][a / 3] + a % 3]; }
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) {
+                                const int a = q0 + q;
+                                ys[l3[j][a / 3] + a % 3] = old[q] + flip_sign(acc[j][a], sg[j], a);     // :280, :300
+                            }
+                        }
+                    }
+            }
+        __syncthreads();
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                const uint8_t *fp = flags + dst[j];
+                if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
+                if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
+                if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
     if constexpr (DOT) {
         __shared__ double lds[kWavesPerBlock];
         double v[1] = {dot};
@@ -926,6 +1062,10 @@ class HipBackend : public Backend {
         double *ck = nullptr, *ke = nullptr;
         unsigned *sgn = nullptr;
     } chc_[kChunkClasses];
+    // per-launch tables of the hex8 class for k_ebe_hex (hex_mode_ > 0)
+    HexTab hex_tab_[2] = {};
+    std::vector<void *> hex_allocs_;
+    int hex_mode_ = 0, hex_ept_ = 2, hex_npt_ = 3;
     int n_chunks_total_[2] = {0, 0};
     int sh_count_[2] = {0, 0};
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr};
@@ -1001,6 +1141,7 @@ public:
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
+        if (const char *e = getenv("PCG_EBE_HEX")) hex_mode_ = atoi(e);
     }
     ~HipBackend() override
     {
@@ -1018,6 +1159,7 @@ public:
         for (auto &D : ebe_groups_)
             for (void *p : {(void *)D.dof, (void *)D.sgn_bits, (void *)D.sgn_bytes, (void *)D.ck, (void *)D.ke})
                 if (p) (void)hipFree(p);
+        for (void *p : hex_allocs_) (void)hipFree(p);
         for (auto e : ev0_) (void)hipEventDestroy(e);
         for (auto e : ev1_) (void)hipEventDestroy(e);
         if (h_mirror_) {
@@ -1121,6 +1263,7 @@ public:
                     if (D.count[ph]) up(D.list[ph], K.list[ph]);
                 }
             }
+            if (hex_mode_ > 0 && C.cls[0].n_chunks > 0 && !ebe_mfma_) build_hex_tables(C);
             for (int ph = 0; ph < 2; ++ph) {
                 sh_count_[ph] = (int)C.sh_node[ph].size();
                 np += (C.sh_node[ph].size() + kBlock - 1) / kBlock;
@@ -1129,6 +1272,51 @@ public:
             }
             d_part_ebe_ = (double *)alloc(sizeof(double) * np);
         }
+    }
+    // k_ebe_hex: the hex8 class laid out per launch (phase): block b's data at fixed strides of b
+    void build_hex_tables(const EbeChunkedHost &C)
+    {
+        const auto &K = C.cls[0];
+        hex_ept_ = K.ept;
+        hex_npt_ = (K.max_nodes + kChunkThreads - 1) / kChunkThreads;
+        const int CE = kChunkThreads * K.ept, MAXN = kChunkThreads * hex_npt_;
+        auto up = [&](const auto &v) {
+            void *d = alloc(sizeof(v[0]) * std::max<size_t>(1, v.size()));
+            h2d(d, v.data(), sizeof(v[0]) * v.size());
+            hex_allocs_.push_back(d);
+            return d;
+        };
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t n = K.list[ph].size();
+            if (!n) continue;
+            std::vector<int> hdr(4 * n), nodes(n * MAXN, -1), dst(n * MAXN, 0);
+            std::vector<unsigned short> tslot(n * MAXN, 0), lid(n * 8 * CE);
+            std::vector<double> ck(n * CE);
+            std::vector<unsigned> sgn(n * CE);
+            for (size_t b = 0; b < n; ++b) {
+                const int32_t *h = &C.hdr[(size_t)K.list[ph][b] * 8];
+                const int32_t off = h[0], nn = h[1], kci = h[4];
+                hdr[4 * b] = nn; hdr[4 * b + 1] = h[2]; hdr[4 * b + 2] = h[3]; hdr[4 * b + 3] = 0;
+                for (int k = 0; k < nn; ++k) {
+                    nodes[b * MAXN + k] = C.nodes[off + k]; dst[b * MAXN + k] = C.dst[off + k]; tslot[b * MAXN + k] = C.tslot[off + k];
+                }
+                std::copy(&K.ck[(size_t)kci * CE], &K.ck[(size_t)kci * CE] + CE, &ck[b * CE]);
+                std::copy(&K.sgn[(size_t)kci * CE], &K.sgn[(size_t)kci * CE] + CE, &sgn[b * CE]);
+                std::copy(&K.lid[(size_t)kci * 8 * CE], &K.lid[(size_t)kci * 8 * CE] + 8 * CE, &lid[b * 8 * CE]);
+            }
+            hex_tab_[ph] = HexTab{(const int4 *)up(hdr), (const int *)up(nodes), (const int *)up(dst), (const unsigned short *)up(tslot),
+                                  (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn)};
+        }
+    }
+    template <int EPT, int NPT, int LB>
+    void launch_hex(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, true>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_,
+                               d_flags_, part, dot_lo);
+        else
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, false>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_,
+                               d_flags_, part, dot_lo);
     }
     void ebe_launch_range(const EbeRange &r, const double *x, double *y)
     {
@@ -1165,6 +1353,21 @@ public:
     {
         switch (D.nnp) {
         case 8:
+            if (D.full && hex_mode_ > 0 && hex_tab_[ph].hdr) {     // hex8 class through the per-launch tables
+                // hex_mode_: 1 = the register budget of k_ebe_chunk (3 / 4 blocks per CU), 2 = one block more, 3 = two more
+                const int lb = (hex_ept_ == 2 ? 3 : 4) + (hex_mode_ - 1);
+                if (hex_ept_ == 2 && hex_npt_ == 3) {
+                    if (lb == 3) launch_hex<2, 3, 3>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
+                    else launch_hex<2, 3, 4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
+                } else if (hex_ept_ == 1 && hex_npt_ == 2) {
+                    if (lb == 4) launch_hex<1, 2, 4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
+                    else if (lb == 5) launch_hex<1, 2, 5>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
+                    else launch_hex<1, 2, 6>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
+                } else {
+                    throw std::runtime_error("k_ebe_hex: unexpected chunk shape");
+                }
+                break;
+            }
             if (D.full && ebe_mfma_) {                          // hex8 class on the matrix cores
                 if (D.ept == 2) launch_mfma<2>(D, ph, x, y, dot, part, dot_lo);
                 else launch_mfma<1>(D, ph, x, y, dot, part, dot_lo);

@@ -71,6 +71,7 @@ struct EbeClassHost {
     bool full = false;                 // every element of the class has exactly nnp nodes (no padding guards needed)
     int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (2 only for nnp == 8)
     int32_t words = 1;                 // sign words per element = NDP/32 + 1; bits 24..31 of the last word = sub-colour
+    int32_t max_nodes = kChunkMaxNodes; // tile nodes a chunk of this class may have (512 for the 256-element hex8 chunks)
     int64_t n_chunks = 0;
     std::vector<uint16_t> lid;         // (n_chunks, nnp, 256*ept) local node index of element-node l (0 for padding)
     std::vector<double> ck;            // (n_chunks, 256*ept)   (0 for padding slots)
