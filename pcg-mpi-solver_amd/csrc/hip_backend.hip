@@ -467,11 +467,15 @@ __global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_c
 // EPT / NPT (tile nodes per thread) / LB (blocks per CU asked of the register allocator) are template parameters so that
 // the occupancy trade-off can be measured (PCG_EBE_HEX, tools/ebe_lab.py).
 // ------------------------------------------------------------------------------------------------
+#ifndef PCG_EBE_ABL
+#define PCG_EBE_ABL 0      // development builds only (tools/ebe_ablation.sh): 1 = no contraction, 2 = no LDS accumulation, 4 = no stores, 8 = no x gather
+#endif
 struct HexTab {
-    const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, -
+    const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, any sign bit set
     const int *nodes;             // [n][MAXN]  node id, -1 = padding
     const int *dst;               // [n][MAXN]  >= 0: y offset (exclusive node); < 0: -(boundary slot + 1)
-    const unsigned short *tslot;  // [n][MAXN]  slot in the LDS tile
+    const unsigned short *tslot;  // [n][MAXN]  bits 0..9 slot in the LDS tile; bits 12..14: dof 0..2 of the node is owned and free
+                                  //            (the weight of the fused p.Ap, patched in by upload_masks: no flag loads in the kernel)
     const unsigned short *lid;    // [n][8][CE]
     const double *ck;             // [n][CE]
     const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
@@ -483,16 +487,28 @@ __device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
     return __longlong_as_double(__double_as_longlong(v) ^ (long long)m);
 }
 
-template <int EPT, int NPT, int LB, bool DOT>
+// TIM (development, pcg_ebe_phase_cycles): thread 0 and thread 192 of every block stamp s_memtime at the phase boundaries.
+#define EBE_STAMP(k)                                                                             \
+    if constexpr (TIM) {                                                                         \
+        if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 3))                                 \
+            stamps[((size_t)blockIdx.x * 2 + (wave == 3)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
+    }
+// ACCM: how a lane adds its 24 outputs into the LDS y tile.  0: read - add - write in two batches of 12 (the signs are
+// applied beforehand, outside the serial part, and the wave whose turn it is runs at raised priority: its few VALU adds
+// must not queue behind the other workgroups' FMA streams while three waves wait at the barrier).  1: ds_add_f64 - the
+// LDS unit adds in place, the serial part of a wave is 24 * EPT LDS instructions and no VALU work at all.  The order of
+// additions per node is the same in both modes (wave after wave, sub-colour after sub-colour): bit-reproducible.
+template <int EPT, int NPT, int LB, bool DOT, bool TIM = false, int ACCM = 0>
 __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
                                                                double *__restrict__ y, double *__restrict__ buf,
                                                                const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                               long long dot_lo)
+                                                               long long dot_lo, long long *__restrict__ stamps = nullptr)
 {
     constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
     const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    EBE_STAMP(0)
     const int4 h = T.hdr[b];
     // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
     unsigned sg[EPT];
@@ -507,77 +523,119 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
         for (int k = 0; k < 8; ++k)
             l3[j][k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63));
     }
-    int g[NPT], dst[NPT], sl3[NPT];
+    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
         g[j] = ntload(T.nodes + n);
         dst[j] = ntload(T.dst + n);
-        sl3[j] = 3 * (int)__builtin_nontemporal_load(T.tslot + n);
+        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
+        sl3[j] = 3 * (ts & 0x3ff);
+        wmask[j] = ts >> 12;
     }
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
         if (g[j] >= 0) {
             const double *xp = x + 3 * (size_t)g[j];
-            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            const double x0 = (PCG_EBE_ABL & 8) ? 1.0 : xp[0], x1 = (PCG_EBE_ABL & 8) ? 2.0 : xp[1], x2 = (PCG_EBE_ABL & 8) ? 3.0 : xp[2];
             xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
             ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
         }
+    EBE_STAMP(1)                                   // own loads landed, tile written
     __syncthreads();
+    EBE_STAMP(2)
     const double *K = ke_col + (size_t)h.z * ND * ND;
     double acc[EPT][ND];
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
 #pragma unroll
         for (int a = 0; a < ND; ++a) acc[j][a] = 0.0;
+    // h.w: some element of this chunk has a sign bit set (ElemList_SignVector, :278,:280); chunks without any - every chunk
+    // of a mesh whose patterns are in reference orientation - skip the two sign passes (block-uniform branch)
+    auto contract = [&](auto with_signs) {
+        constexpr bool SIG = decltype(with_signs)::value;
 #pragma unroll
-    for (int bb = 0; bb < ND; ++bb) {
-        double u[EPT];
+        for (int bb = 0; bb < ND; ++bb) {
+            double u[EPT];
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) u[j] = c[j] * flip_sign(xs[l3[j][bb / 3] + bb % 3], sg[j], bb);    // :277-279 gather, sign, Ck
+            for (int j = 0; j < EPT; ++j) {
+                const double xv = xs[l3[j][bb / 3] + bb % 3];                                            // :277 gather
+                u[j] = c[j] * (SIG ? flip_sign(xv, sg[j], bb) : xv);                                     // :278-279 sign, Ck
+            }
+            if constexpr ((PCG_EBE_ABL & 1) != 0) {
 #pragma unroll
-        for (int a = 0; a < ND; ++a) {
-            const double k = K[bb * ND + a];                                                             // wave-uniform -> SGPR pair
+                for (int j = 0; j < EPT; ++j) acc[j][bb] += u[j];
+            } else {
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);                           // :279 Ke @ (.)
+                for (int a = 0; a < ND; ++a) {
+                    const double k = K[bb * ND + a];                                                     // wave-uniform -> SGPR pair
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);                   // :279 Ke @ (.)
+                }
+            }
         }
-    }
+        if constexpr (SIG) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[j][a] = flip_sign(acc[j][a], sg[j], a);                 // :280 (every wave at once)
+        }
+    };
+    if (h.w) contract(std::true_type());
+    else contract(std::false_type());
+    EBE_STAMP(3)                                   // contraction done
     // ---- LDS-staged partial sums, wave after wave (slot order = sub-colour order) ----------------------------------
+    if constexpr ((PCG_EBE_ABL & 2) != 0) {           // keep the values alive without the serial LDS part
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+#pragma unroll
+            for (int a = 0; a < ND; ++a) t += acc[j][a];
+        if (t == 1.2345e-300) ys[0] = t;
+        __syncthreads();
+    } else
     for (int w = 0; w < kWavesPerBlock; ++w) {
-        if (wave == w)
+        if (wave == w) {
+            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
             for (int s = 0; s < h.y; ++s) {
 #pragma unroll
                 for (int j = 0; j < EPT; ++j)
                     if ((int)(sg[j] >> 24) == s) {
+                        if constexpr (ACCM == 1) {
 #pragma unroll
-                        for (int q0 = 0; q0 < ND; q0 += 12) {
-                            double old[12];
+                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
+                                __hip_atomic_fetch_add(&ys[l3[j][a / 3] + a % 3], acc[j][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
 #pragma unroll
-                            for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[l3[j][a / 3] + a % 3]; }
+                            for (int q0 = 0; q0 < ND; q0 += 12) {
+                                double old[12];
 #pragma unroll
-                            for (int q = 0; q < 12; ++q) {
-                                const int a = q0 + q;
-                                ys[l3[j][a / 3] + a % 3] = old[q] + flip_sign(acc[j][a], sg[j], a);     // :280, :300
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[l3[j][a / 3] + a % 3]; }
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[l3[j][a / 3] + a % 3] = old[q] + acc[j][a]; }   // :300
                             }
                         }
                     }
             }
+            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
+        }
         __syncthreads();
     }
+    EBE_STAMP(4)                                   // accumulation done
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
         if (g[j] >= 0) {
             double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
             const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
-            out[0] = y0; out[1] = y1; out[2] = y2;
+            if ((PCG_EBE_ABL & 4) == 0 || y0 == 1.2345e-300) { out[0] = y0; out[1] = y1; out[2] = y2; }
             if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                const uint8_t *fp = flags + dst[j];
-                if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
-                if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
-                if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
+                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
+                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
+                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
             }
         }
+    EBE_STAMP(5)                                   // stores issued
     if constexpr (DOT) {
         __shared__ double lds[kWavesPerBlock];
         double v[1] = {dot};
@@ -585,6 +643,7 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
         if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // hex8 chunks on the matrix cores.  The reference computes Ke @ (Ck * U) for all elements of a type as ONE
@@ -736,7 +795,9 @@ __global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
 
 
 // nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id.  Slots are numbered node-major
-// (ebe.cpp): node k of the phase owns slots slot0 + [sh_ptr[k], sh_ptr[k+1]) - consecutive threads stream consecutive runs.
+// (ebe.cpp): node k of the phase owns slots slot0 + [sh_ptr[k], sh_ptr[k+1]).  One thread per (node, direction): the
+// three threads of a node and the threads of the next node read adjacent addresses (the launch streams the buffer front
+// to back), and a thread has all its addends in flight before it adds them - in slot order, so the sum is the same.
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
                                                        int slot0, const double *__restrict__ buf,
@@ -744,23 +805,23 @@ __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ s
                                                        const uint8_t *__restrict__ flags, double *__restrict__ partials,
                                                        long long dot_lo)
 {
-    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int k = t / 3, d = t - 3 * k;
     double dot = 0.0;
     if (k < count) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        const int q0 = sh_ptr[k], q1 = sh_ptr[k + 1];
-        const double *b = buf + 3 * (size_t)(slot0 + q0);
-        for (int q = q0; q < q1; ++q, b += 3) { s0 += ntload(b); s1 += ntload(b + 1); s2 += ntload(b + 2); }
-        const size_t d0 = 3 * (size_t)sh_node[k];
-        double *yp = y + d0;
-        yp[0] = s0; yp[1] = s1; yp[2] = s2;
-        if (DOT && (long long)d0 >= dot_lo) {
-            const uint8_t *fp = flags + d0;
-            const double *xp = x + d0;
-            if ((fp[0] & 3) == 3) dot += xp[0] * s0;
-            if ((fp[1] & 3) == 3) dot += xp[1] * s1;
-            if ((fp[2] & 3) == 3) dot += xp[2] * s2;
-        }
+        const int q0 = sh_ptr[k], cnt = sh_ptr[k + 1] - q0;
+        const double *b = buf + 3 * (size_t)(slot0 + q0) + d;
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = q < cnt ? ntload(b + 3 * q) : 0.0;
+        double s = v[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            if (q < cnt) s += v[q];
+        for (int q = 8; q < cnt; ++q) s += ntload(b + 3 * q);      // more than 8 chunks at one node: irregular meshes only
+        const size_t dof = 3 * (size_t)sh_node[k] + d;
+        y[dof] = s;
+        if (DOT && (long long)dof >= dot_lo && (flags[dof] & 3) == 3) dot += x[dof] * s;
     }
     if constexpr (DOT) {
         __shared__ double lds[kWavesPerBlock];
@@ -1065,7 +1126,12 @@ class HipBackend : public Backend {
     // per-launch tables of the hex8 class for k_ebe_hex (hex_mode_ > 0)
     HexTab hex_tab_[2] = {};
     std::vector<void *> hex_allocs_;
-    int hex_mode_ = 0, hex_ept_ = 2, hex_npt_ = 3;
+    std::vector<int> hex_nodes_host_[2];                 // to fold the ownership / free masks into the slot table (upload_masks)
+    std::vector<unsigned short> hex_tslot_host_[2];
+    // Defaults from the same-box A/B at 10 M dof (profiles/r02_ebe_lab_*.log, tools/ebe_lab.py): 256-element chunks, 5 blocks per
+    // CU (96 VGPRs), ds_add_f64 accumulation: 0.166 ms per apply vs 0.174 for k_ebe_chunk (0.176 vs 0.190 with the fused p.Ap).
+    // PCG_EBE_HEX=0 selects k_ebe_chunk for the hex8 class too; PCG_EBE_ACC=0 the read-add-write accumulation.
+    int hex_mode_ = 2, hex_ept_ = 2, hex_npt_ = 3, hex_acc_ = 1;
     int n_chunks_total_[2] = {0, 0};
     int sh_count_[2] = {0, 0};
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr};
@@ -1142,6 +1208,7 @@ public:
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_EBE_HEX")) hex_mode_ = atoi(e);
+        if (const char *e = getenv("PCG_EBE_ACC")) hex_acc_ = atoi(e);
     }
     ~HipBackend() override
     {
@@ -1266,7 +1333,7 @@ public:
             if (hex_mode_ > 0 && C.cls[0].n_chunks > 0 && !ebe_mfma_) build_hex_tables(C);
             for (int ph = 0; ph < 2; ++ph) {
                 sh_count_[ph] = (int)C.sh_node[ph].size();
-                np += (C.sh_node[ph].size() + kBlock - 1) / kBlock;
+                np += (3 * C.sh_node[ph].size() + kBlock - 1) / kBlock;
                 sh_slot0_[ph] = ph ? (int)C.sh_ptr[0].back() : 0;
                 if (sh_count_[ph]) { up(d_sh_node_[ph], C.sh_node[ph]); up(d_sh_ptr_[ph], C.sh_ptr[ph]); }
             }
@@ -1287,16 +1354,20 @@ public:
             return d;
         };
         for (int ph = 0; ph < 2; ++ph) {
-            const size_t n = K.list[ph].size();
-            if (!n) continue;
-            std::vector<int> hdr(4 * n), nodes(n * MAXN, -1), dst(n * MAXN, 0);
-            std::vector<unsigned short> tslot(n * MAXN, 0), lid(n * 8 * CE);
-            std::vector<double> ck(n * CE);
-            std::vector<unsigned> sgn(n * CE);
-            for (size_t b = 0; b < n; ++b) {
+            const size_t n_real = K.list[ph].size();
+            if (!n_real) continue;
+            const size_t n = n_real;
+            std::vector<int> hdr(4 * n, 0), nodes(n * MAXN, -1), dst(n * MAXN, 0);
+            std::vector<unsigned short> tslot(n * MAXN, 0), lid(n * 8 * CE, 0);
+            std::vector<double> ck(n * CE, 0.0);
+            std::vector<unsigned> sgn(n * CE, 0xff000000u);
+            for (size_t b = 0; b < n_real; ++b) {
                 const int32_t *h = &C.hdr[(size_t)K.list[ph][b] * 8];
                 const int32_t off = h[0], nn = h[1], kci = h[4];
-                hdr[4 * b] = nn; hdr[4 * b + 1] = h[2]; hdr[4 * b + 2] = h[3]; hdr[4 * b + 3] = 0;
+                hdr[4 * b] = nn; hdr[4 * b + 1] = h[2]; hdr[4 * b + 2] = h[3];
+                int any_sign = 0;
+                for (int e = 0; e < CE; ++e) any_sign |= (K.sgn[(size_t)kci * CE + e] & 0x00ffffffu) != 0;
+                hdr[4 * b + 3] = any_sign;
                 for (int k = 0; k < nn; ++k) {
                     nodes[b * MAXN + k] = C.nodes[off + k]; dst[b * MAXN + k] = C.dst[off + k]; tslot[b * MAXN + k] = C.tslot[off + k];
                 }
@@ -1306,17 +1377,25 @@ public:
             }
             hex_tab_[ph] = HexTab{(const int4 *)up(hdr), (const int *)up(nodes), (const int *)up(dst), (const unsigned short *)up(tslot),
                                   (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn)};
+            hex_nodes_host_[ph] = nodes;
+            hex_tslot_host_[ph] = tslot;
         }
+    }
+    template <int EPT, int NPT, int LB, int ACCM>
+    void launch_hex_a(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, true, false, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
+                               d_ch_buf_, d_flags_, part, dot_lo, (long long *)nullptr);
+        else
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, false, false, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
+                               d_ch_buf_, d_flags_, part, dot_lo, (long long *)nullptr);
     }
     template <int EPT, int NPT, int LB>
     void launch_hex(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
-        if (dot)
-            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, true>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_,
-                               d_flags_, part, dot_lo);
-        else
-            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, false>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_,
-                               d_flags_, part, dot_lo);
+        if (hex_acc_ == 1) launch_hex_a<EPT, NPT, LB, 1>(ph, count, ke, x, y, dot, part, dot_lo);
+        else launch_hex_a<EPT, NPT, LB, 0>(ph, count, ke, x, y, dot, part, dot_lo);
     }
     void ebe_launch_range(const EbeRange &r, const double *x, double *y)
     {
@@ -1397,7 +1476,7 @@ public:
                     if (fuse) cnt_ebe_ += np;
                 }
             if (sh_count_[ph]) {
-                const int grid = (sh_count_[ph] + kBlock - 1) / kBlock;
+                const int grid = (3 * sh_count_[ph] + kBlock - 1) / kBlock;
                 double *part = d_part_ebe_ + cnt_ebe_;
                 if (fuse)
                     hipLaunchKernelGGL((k_ebe_shared<true>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
@@ -1415,7 +1494,23 @@ public:
         return fuse;
     }
     bool ebe_can_split() const override { return ebe_ranges_[0].empty() && ebe_ranges_[1].empty(); }
-    void upload_masks(const uint8_t *f, int64_t n) override { h2d(d_flags_, f, (size_t)n); }
+    void upload_masks(const uint8_t *f, int64_t n) override
+    {
+        h2d(d_flags_, f, (size_t)n);
+        for (int ph = 0; ph < 2; ++ph) {                     // k_ebe_hex reads the dot weights from its slot table
+            if (!hex_tab_[ph].tslot) continue;
+            std::vector<unsigned short> t(hex_tslot_host_[ph]);
+            for (size_t k = 0; k < t.size(); ++k) {
+                const int g = hex_nodes_host_[ph][k];
+                if (g < 0) continue;
+                unsigned m = 0;
+                for (int d = 0; d < 3; ++d)
+                    if ((f[3 * (size_t)g + d] & 3) == 3) m |= 1u << d;
+                t[k] = (unsigned short)((t[k] & 0x3ff) | (m << 12));
+            }
+            h2d((void *)hex_tab_[ph].tslot, t.data(), sizeof(unsigned short) * t.size());
+        }
+    }
     void upload_halo(const HaloHost &h) override
     {
         for (void *p : {(void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_}) if (p) (void)hipFree(p);
@@ -1639,6 +1734,40 @@ public:
         double s = 0;
         for (int k = 0; k < ev_used_; ++k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0_[k], ev1_[k])); s += ms; }
         *ms_sum = s; *count = ev_applies_;
+    }
+    // development: mean cycles between the phase stamps of k_ebe_hex over all blocks of the interior-phase hex8 launch
+    int ebe_phase_cycles(const double *x, double *y, double *out /* 2 waves x 6 */) override
+    {
+        const int ph = hex_tab_[1].hdr ? 1 : 0;
+        if (!hex_tab_[ph].hdr) return -1;
+        const int n = chc_[0].count[ph];
+        long long *d = (long long *)alloc(sizeof(long long) * 16 * (size_t)n);
+        HIP_CHECK(hipMemsetAsync(d, 0, sizeof(long long) * 16 * (size_t)n, st_));
+        for (int rep = 0; rep < 2; ++rep) {
+            if (hex_ept_ == 2 && hex_acc_ == 1)
+                hipLaunchKernelGGL((k_ebe_hex<2, 3, 3, false, true, 1>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
+                                   d_flags_, d_part_ebe_, 0ll, d);
+            else if (hex_ept_ == 2)
+                hipLaunchKernelGGL((k_ebe_hex<2, 3, 3, false, true, 0>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
+                                   d_flags_, d_part_ebe_, 0ll, d);
+            else if (hex_acc_ == 1)
+                hipLaunchKernelGGL((k_ebe_hex<1, 2, 4, false, true, 1>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
+                                   d_flags_, d_part_ebe_, 0ll, d);
+            else
+                hipLaunchKernelGGL((k_ebe_hex<1, 2, 4, false, true, 0>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
+                                   d_flags_, d_part_ebe_, 0ll, d);
+        }
+        HIP_CHECK(hipGetLastError());
+        std::vector<long long> h((size_t)16 * n);
+        d2h(h.data(), d, sizeof(long long) * h.size());
+        release(d);
+        for (int k = 0; k < 12; ++k) out[k] = 0.0;
+        for (int b = 0; b < n; ++b)
+            for (int w = 0; w < 2; ++w)
+                for (int k = 1; k < 6; ++k) out[w * 6 + k] += (double)(h[((size_t)b * 2 + w) * 8 + k] - h[((size_t)b * 2 + w) * 8 + k - 1]);
+        for (int k = 0; k < 12; ++k) out[k] /= n;
+        out[0] = n; out[6] = n;
+        return 0;
     }
     int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) override
     {
