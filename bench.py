@@ -95,7 +95,21 @@ def launch_ranks(args):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         log("launching", args.gpus, "ranks:", " ".join(cmd[1:8]), "...")
-        return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        limit = float(os.environ.get("PCG_BENCH_RANKS_TIMEOUT_S", "1500"))     # a hung collective must not eat the caller's whole budget
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            log(f"ranks did not finish within {limit:.0f} s - terminating the launch (process group {p.pid})")
+            import signal
+            os.killpg(p.pid, signal.SIGTERM)
+            try:
+                out, _ = p.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                out, _ = p.communicate()
+            return subprocess.CompletedProcess(cmd, 124, out, None)
+        return subprocess.CompletedProcess(cmd, p.returncode, out, None)
     r = run({})
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if (r.returncode != 0 or not line) and args.comm == "native" and os.environ.get("PCG_BENCH_NO_RETRY") != "1":

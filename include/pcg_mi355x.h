@@ -116,6 +116,21 @@ typedef struct {
 int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks);
 void *pcg_stream(pcg_engine *e);
 
+/* ---- partition set-up on the device ------------------------------------------------
+ * The whole-model index passes of src/solver/partition_mesh.py as HIP kernels (csrc/part_setup.hip); integer work, exact.
+ * pcg_part_interface       identify_PotentialNeighbours :657-741 + config_Neighbours :745-830: which global nodes are
+ *                          touched by elements of MORE THAN ONE part, and by which parts.  elem_ptr / flat_nodes = the
+ *                          model's NodeGlbOffset / NodeGlbFlat as a CSR over elements (i64 offsets, i32 node ids),
+ *                          ele_part = MeshPart_<N>.npy (run_metis.py:88-92).  Writes up to `cap` pairs (node, part) in
+ *                          arbitrary order with duplicates (sort + unique on the host: the interface is a small subset);
+ *                          *n_pairs = pairs found - call again with that capacity if it exceeds `cap`.
+ * pcg_part_local_numbering config_ElemVectors :252-268: the part's ascending unique node ids (np.unique) and the local
+ *                          index of every element node (getIndices :58-67), by mark + exclusive scan + gather. */
+int pcg_part_interface(int32_t device, int64_t n_glob_nodes, int64_t n_elem, const int64_t *elem_ptr, const int32_t *flat_nodes,
+                       const int32_t *ele_part, int64_t cap, int64_t *pairs /* 2*cap */, int64_t *n_pairs);
+int pcg_part_local_numbering(int32_t device, int64_t n_glob_nodes, int64_t n_flat, const int32_t *flat_nodes,
+                             int32_t *unique_nodes /* n_flat */, int32_t *local_of_flat /* n_flat */, int64_t *n_unique);
+
 /* ---- native communicator: RCCL over xGMI, issued by the engine --------------------------------
  * Replaces the reference's mpi4py calls on the hot path without any callback into the host language:
  *   Isend / Recv / Waitall per neighbour (pcg_solver.py:318-328) -> one ncclGroupStart..ncclSend/ncclRecv..ncclGroupEnd

@@ -627,6 +627,35 @@ int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks)
 
 void *pcg_stream(pcg_engine *e) { return e ? e->be->stream() : nullptr; }
 
+// ---- partition set-up on the device -------------------------------------------------------------------
+int pcg_part_interface(int32_t device, int64_t n_glob_nodes, int64_t n_elem, const int64_t *elem_ptr, const int32_t *flat_nodes,
+                       const int32_t *ele_part, int64_t cap, int64_t *pairs, int64_t *n_pairs)
+{
+    return guarded("pcg_part_interface", [&]() -> int {
+        if (!elem_ptr || !flat_nodes || !ele_part || !n_pairs || n_elem < 0 || n_glob_nodes <= 0 || cap < 0 || (cap > 0 && !pairs))
+            return set_error("pcg_part_interface: bad argument");
+        for (int64_t e = 0; e < n_elem; ++e)
+            if (elem_ptr[e + 1] < elem_ptr[e]) return set_error("pcg_part_interface: elem_ptr must be non-decreasing");
+        for (int64_t k = elem_ptr[0]; k < elem_ptr[n_elem]; ++k)
+            if (flat_nodes[k] < 0 || flat_nodes[k] >= n_glob_nodes) return set_error("pcg_part_interface: node id out of range");
+        *n_pairs = part_interface(device, n_glob_nodes, n_elem, elem_ptr, flat_nodes, ele_part, cap, pairs);
+        return 0;
+    });
+}
+
+int pcg_part_local_numbering(int32_t device, int64_t n_glob_nodes, int64_t n_flat, const int32_t *flat_nodes, int32_t *unique_nodes,
+                             int32_t *local_of_flat, int64_t *n_unique)
+{
+    return guarded("pcg_part_local_numbering", [&]() -> int {
+        if (!flat_nodes || !unique_nodes || !local_of_flat || !n_unique || n_flat <= 0 || n_glob_nodes <= 0)
+            return set_error("pcg_part_local_numbering: bad argument");
+        for (int64_t k = 0; k < n_flat; ++k)
+            if (flat_nodes[k] < 0 || flat_nodes[k] >= n_glob_nodes) return set_error("pcg_part_local_numbering: node id out of range");
+        *n_unique = part_local_numbering(device, n_glob_nodes, n_flat, flat_nodes, unique_nodes, local_of_flat);
+        return 0;
+    });
+}
+
 // ---- native RCCL communicator ----------------------------------------------------------------------
 int pcg_rccl_unique_id(void *out)
 {

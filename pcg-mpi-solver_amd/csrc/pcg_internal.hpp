@@ -244,6 +244,14 @@ public:
 std::unique_ptr<Comm> make_rccl_comm(int device, int rank, int nranks, const void *unique_ids /* 2 x 128 B */);
 int rccl_unique_ids(void *out /* 2 x 128 B */);
 
+// ---- partition set-up on the device (part_setup.hip; the CPU test double has none) ---------------------------------
+// -> number of (node, part) pairs found (pairs[2i], pairs[2i+1]; only the first `cap` are written)
+int64_t part_interface(int device, int64_t n_glob_nodes, int64_t n_elem, const int64_t *elem_ptr, const int32_t *flat_nodes,
+                       const int32_t *ele_part, int64_t cap, int64_t *pairs);
+// -> number of distinct nodes; unique_nodes ascending, local_of_flat[i] = index of flat_nodes[i] in it
+int64_t part_local_numbering(int device, int64_t n_glob_nodes, int64_t n_flat, const int32_t *flat_nodes, int32_t *unique_nodes,
+                             int32_t *local_of_flat);
+
 std::unique_ptr<Backend> make_backend(int device);   // defined by exactly one back end per library
 int backend_device_count();
 const char *backend_static_name();

@@ -74,6 +74,8 @@ _SIGS = {
     "pcg_set_halo": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "pcg_set_comm": (C.c_int, [_P, C.POINTER(CommHooks)]),
     "pcg_stream": (_P, [_P]),
+    "pcg_part_interface": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    "pcg_part_local_numbering": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(C.c_int64)]),
     "pcg_rccl_unique_id": (C.c_int, [_P]),
     "pcg_comm_create_rccl": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "pcg_comm_destroy": (None, [_P]),

@@ -16,10 +16,11 @@ The reference walks Python lists element by element (its own TODOs: "Perform the
 :237,:272,:282); here every step is a whole-array operation (ragged gathers through offset arithmetic,
 sorted-unique + searchsorted), so a 10 M-dof model partitions in seconds, and a rank of a multi-GPU job can
 build ONLY its own part (`only=[rank]`): the other parts enter through one scatter / gather pass over the flat
-element -> node list that finds the interface nodes.  Not built: interface (cohesive) elements (ElemTypeId -2 / -1, :603-653 - no
+element -> node list that finds the interface nodes.  With `device=<gpu index>` the two whole-model passes - that
+interface scatter / mark / emit, and the part's local numbering (np.unique + searchsorted of its element nodes) - run
+as HIP kernels (csrc/part_setup.hip via pcg_part_interface / pcg_part_local_numbering): same keys, same values.  Not built: interface (cohesive) elements (ElemTypeId -2 / -1, :603-653 - no
 such model exists in the reference repository) and the non-local stress neighbourhoods (:1006-1282,
 ExportNonLocalStress = 0 in examples/run_basic_script.bash), both outside the PCG hot path.
-Host-side set-up only.
 """
 from __future__ import annotations
 
@@ -65,8 +66,44 @@ def geometric_partition(model, n_parts, axis=None):
     return part
 
 
-def partition_model(model, ele_part, only=None, glob_data=None):
-    """RefMeshPart dicts (REF_KEY_LIST + 'GlobData') for the part ids in `only` (default: every part)."""
+def _gpu_interface(device, n_glob_nodes, elem_ptr, flat_nodes, ele_part, n_total):
+    """(if_node, if_part): sorted unique (node, part) pairs of the nodes touched by more than one part - device pass."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    ptr = np.ascontiguousarray(elem_ptr, np.int64)
+    flat = np.ascontiguousarray(flat_nodes, np.int32)
+    ep = np.ascontiguousarray(ele_part, np.int32)
+    cap = max(1024, len(flat) // 8)
+    while True:
+        pairs = np.empty((cap, 2), np.int64)
+        n = C.c_int64()
+        _lib.check(L.pcg_part_interface(int(device), int(n_glob_nodes), len(ep), ptr.ctypes.data, flat.ctypes.data, ep.ctypes.data,
+                                        cap, pairs.ctypes.data, C.byref(n)), "pcg_part_interface")
+        if n.value <= cap:
+            break
+        cap = int(n.value)
+    pairs = pairs[:n.value]
+    key = np.unique(pairs[:, 0] * n_total + pairs[:, 1])
+    return key // n_total, key % n_total
+
+
+def _gpu_local_numbering(device, n_glob_nodes, flat_nodes):
+    """(ascending unique node ids, local index of every entry) of a part's flat element -> node list - device pass."""
+    import ctypes as C
+    from . import _lib
+    flat = np.ascontiguousarray(flat_nodes, np.int32)
+    uniq = np.empty(len(flat), np.int32)
+    loc = np.empty(len(flat), np.int32)
+    n = C.c_int64()
+    _lib.check(_lib.lib().pcg_part_local_numbering(int(device), int(n_glob_nodes), len(flat), flat.ctypes.data, uniq.ctypes.data,
+                                                   loc.ctypes.data, C.byref(n)), "pcg_part_local_numbering")
+    return uniq[:n.value].astype(np.int64), loc.astype(np.int64)
+
+
+def partition_model(model, ele_part, only=None, glob_data=None, device=None):
+    """RefMeshPart dicts (REF_KEY_LIST + 'GlobData') for the part ids in `only` (default: every part).
+    device: GPU index - the whole-model index passes run as HIP kernels (None: whole-array NumPy)."""
     ele_part = np.asarray(ele_part).astype(np.int64)
     E = int(model["GlobNElem"])
     if ele_part.shape != (E,):
@@ -117,6 +154,9 @@ def partition_model(model, ele_part, only=None, glob_data=None):
         n_per = node_off[:, 1] - node_off[:, 0] + 1
         contiguous = E and node_off[0, 0] == 0 and np.all(node_off[1:, 0] == node_off[:-1, 1] + 1) and node_off[-1, 1] + 1 == len(node_flat)
         flat_nodes = node_flat if contiguous else _ragged_take(node_flat, node_off, np.arange(E))[0]
+    if n_total > 1 and device is not None:
+        if_node, if_part = _gpu_interface(device, n_dof_glob // 3 + 1, np.concatenate([[0], np.cumsum(n_per)]), flat_nodes, ele_part, n_total)
+    elif n_total > 1:
         part_of_flat = np.repeat(ele_part.astype(np.int32), n_per)
         rec = np.full(n_dof_glob // 3 + 1, -1, np.int32)
         rec[flat_nodes] = part_of_flat
@@ -147,10 +187,18 @@ def partition_model(model, ele_part, only=None, glob_data=None):
         cum_sign, ns_e = _ragged_take(sign_flat, sign_off, eids)
         if not np.array_equal(nd_e, ns_e) or not np.array_equal(nd_e, 3 * nn_e):
             raise ValueError("inconsistent node / dof / sign ranges")
-        nodes = np.unique(cum_node)                                                        # :252
-        dofs = np.unique(cum_dof)                                                          # :256
-        loc_node = np.searchsorted(nodes, cum_node)                                        # getIndices (:58-67) on sorted unique
-        loc_dof = np.searchsorted(dofs, cum_dof)
+        if device is not None:
+            # the dof list is the node list times three (dof = 3 * node + dir, :688-690,:826): checked, then derived
+            if not np.array_equal(cum_dof.reshape(-1, 3), 3 * cum_node[:, None] + np.arange(3)[None, :]):
+                raise ValueError("device partition set-up needs node-blocked dof ids (dof = 3 * node + dir)")
+            nodes, loc_node = _gpu_local_numbering(device, n_dof_glob // 3 + 1, cum_node)   # :252, getIndices :58-67
+            dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()                     # :256
+            loc_dof = (3 * loc_node[:, None] + np.arange(3)[None, :]).ravel()
+        else:
+            nodes = np.unique(cum_node)                                                    # :252
+            dofs = np.unique(cum_dof)                                                      # :256
+            loc_node = np.searchsorted(nodes, cum_node)                                    # getIndices (:58-67) on sorted unique
+            loc_dof = np.searchsorted(dofs, cum_dof)
         e_first_n = np.cumsum(nn_e) - nn_e
         e_first_d = np.cumsum(nd_e) - nd_e
         n_node, n_dof = len(nodes), len(dofs)

@@ -136,7 +136,7 @@ def main(argv=None):
             ele_part = mdf_mod.read_mesh_part(args.mdf, n_parts)
         except FileNotFoundError:
             ele_part = geometric_partition(model, n_parts)            # deterministic: every rank computes the same vector
-        part = partition_model(model, ele_part, only=[rank])[0]
+        part = partition_model(model, ele_part, only=[rank], device=dev)[0]   # index passes on the GPU (csrc/part_setup.hip)
         gd.update(part["GlobData"])                                   # readModelData :107-108
         part["GlobData"] = gd
         del model

@@ -286,5 +286,13 @@ const char *backend_static_name() { return "hostops-test"; }
 // the test double has no native communicator: the CPU suite drives the callback seam (pcg_set_comm) with gloo
 std::unique_ptr<Comm> make_rccl_comm(int, int, int, const void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
 int rccl_unique_ids(void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
+int64_t part_interface(int, int64_t, int64_t, const int64_t *, const int32_t *, const int32_t *, int64_t, int64_t *)
+{
+    throw std::runtime_error("the CPU test double has no device-side partition set-up");
+}
+int64_t part_local_numbering(int, int64_t, int64_t, const int32_t *, int32_t *, int32_t *)
+{
+    throw std::runtime_error("the CPU test double has no device-side partition set-up");
+}
 
 }  // namespace pcg

@@ -295,3 +295,38 @@ def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
     assert float(td["CalcTime"]) > 0
     if ranks > 1:
         assert 0 < float(td["CommWaitTime"]) < float(td["TotalTime"])         # a7: time blocked in communication (GPU side)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(pc.CASES))
+def test_partition_on_device_reproduces_reference_export(gpu_lib, name):
+    """SURVEY 8(f)-3 on the GPU: interface discovery (scatter / mark / emit) and the local numbering (mark / scan / gather)
+    as HIP kernels (csrc/part_setup.hip) - every exported key of every part identical (values, shapes, dtypes) to what the
+    unmodified partition_mesh.py wrote for the same model and the same element -> part vector."""
+    g = golden(name)
+    model, ele_part = pc.build_model(name)
+    flat_ref = {k: g[k] for k in g.files}
+    n_parts = int(g["n_parts"])
+    parts = partition.partition_model(model, ele_part, device=0)
+    assert len(parts) == n_parts
+    for k, p in enumerate(parts):
+        assert_same_part(flat_ref, p, f"p{k}")
+    k = n_parts - 1                                   # a rank that builds only its own part
+    assert_same_part(flat_ref, partition.partition_model(model, ele_part, only=[k], device=0)[0], f"p{k}")
+
+
+@pytest.mark.gpu
+def test_partition_device_kernels_at_size(gpu_lib):
+    """The device passes on a 1 M-dof brick split 2x2x2 (tile boundaries of the scan, multi-block launches, a few thousand
+    interface pairs per part) against the whole-array host path."""
+    from pcg_mi355x.brick import Brick, block_partition
+    b = Brick(70, seed=0)
+    model = mdf.model_from_brick(b)
+    ele_part = block_partition(b, 2, 2, 2).astype(np.int64)
+    for k in (0, 5):
+        host = partition.partition_model(model, ele_part, only=[k])[0]
+        dev = partition.partition_model(model, ele_part, only=[k], device=0)[0]
+        fh, fd = pc.flatten_part(host, "p"), pc.flatten_part(dev, "p")
+        assert fh.keys() == fd.keys()
+        for key, v in fh.items():
+            assert fd[key].dtype == v.dtype and np.array_equal(fd[key], v), key

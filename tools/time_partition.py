@@ -19,6 +19,11 @@ t0 = time.time(); parts = partition.partition_model(model, ep); t_all = time.tim
 t0 = time.time(); one = partition.partition_model(model, ep, only=[n_parts - 1]); t_one = time.time() - t0
 print(f"N={N} dof={b.n_dof} elements={b.n_elem} parts={n_parts}: model {t_model:.2f}s, partition_model all parts {t_all:.2f}s, "
       f"one part (only=[rank]) {t_one:.2f}s", flush=True)
+if "--device" in sys.argv:                     # the index passes as HIP kernels (csrc/part_setup.hip); first call pays library load
+    partition.partition_model(model, ep, only=[0], device=0)
+    t0 = time.time(); dev = partition.partition_model(model, ep, only=[n_parts - 1], device=0); t_dev = time.time() - t0
+    same = all(np.array_equal(one[0][k], dev[0][k]) for k in ("DofVector", "NodeIdVector", "DofWeightVector", "Flat_ElemLocDof"))
+    print(f"one part with the index passes on the GPU: {t_dev:.2f}s (identical: {same})", flush=True)
 if "--ref" in sys.argv:
     import ref_shim
     work = tempfile.mkdtemp()
