@@ -206,9 +206,6 @@ int pcg_set_profiling(pcg_engine *e, int32_t on);
 /* ---- measurement / unit-test entry points --------------------------------------------------- */
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
-/* Development aid: mean shader cycles between the phase boundaries of the hex8 element kernel (k_ebe_hex), for the first and
- * the last wave of a workgroup: out12 = 2 x [blocks, loads + tile, barrier, contraction, LDS accumulation, stores]. */
-int pcg_ebe_phase_cycles(pcg_engine *e, double *out12);
 /* HBM stream microbenchmark on the engine's device and stream (16 B per lane, non-temporal, grid-stride - the access
  * shape of the solver's kernels): mode 0 reads `bytes`, mode 1 copies `bytes` (read + write = 2 * bytes of traffic).
  * The practical bandwidth ceiling of the box a number was measured on, reported beside the 8 TB/s spec (bench.py). */

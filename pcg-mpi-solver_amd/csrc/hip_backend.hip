@@ -487,28 +487,21 @@ __device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
     return __longlong_as_double(__double_as_longlong(v) ^ (long long)m);
 }
 
-// TIM (development, pcg_ebe_phase_cycles): thread 0 and thread 192 of every block stamp s_memtime at the phase boundaries.
-#define EBE_STAMP(k)                                                                             \
-    if constexpr (TIM) {                                                                         \
-        if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 3))                                 \
-            stamps[((size_t)blockIdx.x * 2 + (wave == 3)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); \
-    }
 // ACCM: how a lane adds its 24 outputs into the LDS y tile.  0: read - add - write in two batches of 12 (the signs are
 // applied beforehand, outside the serial part, and the wave whose turn it is runs at raised priority: its few VALU adds
 // must not queue behind the other workgroups' FMA streams while three waves wait at the barrier).  1: ds_add_f64 - the
 // LDS unit adds in place, the serial part of a wave is 24 * EPT LDS instructions and no VALU work at all.  The order of
 // additions per node is the same in both modes (wave after wave, sub-colour after sub-colour): bit-reproducible.
-template <int EPT, int NPT, int LB, bool DOT, bool TIM = false, int ACCM = 0>
+template <int EPT, int NPT, int LB, bool DOT, int ACCM>
 __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
                                                                double *__restrict__ y, double *__restrict__ buf,
                                                                const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                               long long dot_lo, long long *__restrict__ stamps = nullptr)
+                                                               long long dot_lo)
 {
     constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
     const int b = blockIdx.x, wave = threadIdx.x >> 6;
-    EBE_STAMP(0)
     const int4 h = T.hdr[b];
     // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
     unsigned sg[EPT];
@@ -541,9 +534,7 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
             xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
             ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
         }
-    EBE_STAMP(1)                                   // own loads landed, tile written
     __syncthreads();
-    EBE_STAMP(2)
     const double *K = ke_col + (size_t)h.z * ND * ND;
     double acc[EPT][ND];
 #pragma unroll
@@ -583,7 +574,6 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
     };
     if (h.w) contract(std::true_type());
     else contract(std::false_type());
-    EBE_STAMP(3)                                   // contraction done
     // ---- LDS-staged partial sums, wave after wave (slot order = sub-colour order) ----------------------------------
     if constexpr ((PCG_EBE_ABL & 2) != 0) {           // keep the values alive without the serial LDS part
         double t = 0.0;
@@ -621,7 +611,6 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
         }
         __syncthreads();
     }
-    EBE_STAMP(4)                                   // accumulation done
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
@@ -635,7 +624,6 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
                 if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
             }
         }
-    EBE_STAMP(5)                                   // stores issued
     if constexpr (DOT) {
         __shared__ double lds[kWavesPerBlock];
         double v[1] = {dot};
@@ -644,6 +632,129 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// hex8 chunks of 512 elements in TWO sequential passes of 256 (k_ebe_hexs).  The geometry of the 512-element chunk (an
+// 8x8x8 cell: 729 tile nodes, 386 of them shared with other chunks = 0.75 boundary slots per element, against 1.0 for
+// the 8x8x4 cells of the 256-element chunks) with the register footprint of one element per thread (96 VGPRs): the two
+// halves of the cell are contracted and accumulated one after the other into the SAME LDS y tile, so the plane between
+// them never leaves the workgroup and the tile is staged / written out once.  Why bytes matter here: at 10 M dof an apply
+// moves ~0.65 GB with 256-element chunks (0.49 GB with 512), of which a third is the boundary-slot round trip; the
+// element kernel + shared-node sums run within 1.4x of what that traffic costs at the stream rate.
+// Slot of thread t in pass p: p * 256 + t, i.e. slot order = (pass, wave) order = sub-colour order: same sums as k_ebe_hex.
+// ------------------------------------------------------------------------------------------------
+template <int LB, bool DOT, int ACCM>
+__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                                double *__restrict__ y, double *__restrict__ buf,
+                                                                const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                                long long dot_lo)
+{
+    constexpr int SEQ = 2, NPT = 3, CE = kChunkThreads * SEQ, MAXN = kChunkThreads * NPT, ND = 24;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int4 h = T.hdr[b];
+    unsigned sg;
+    double c;
+    int l3[8];
+    auto load_elem = [&](int ps) {
+        const size_t slot = (size_t)b * CE + ps * kChunkThreads + threadIdx.x;
+        sg = ntload(T.sgn + slot);
+        c = ntload(T.ck + slot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + ps * kChunkThreads + threadIdx.x);
+    };
+    load_elem(0);
+    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+        g[j] = ntload(T.nodes + n);
+        dst[j] = ntload(T.dst + n);
+        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
+        sl3[j] = 3 * (ts & 0x3ff);
+        wmask[j] = ts >> 12;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            const double *xp = x + 3 * (size_t)g[j];
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    __syncthreads();
+    const double *K = ke_col + (size_t)h.z * ND * ND;
+#pragma unroll
+    for (int ps = 0; ps < SEQ; ++ps) {
+        double acc[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[a] = 0.0;
+        auto contract = [&](auto with_signs) {
+            constexpr bool SIG = decltype(with_signs)::value;
+#pragma unroll
+            for (int bb = 0; bb < ND; ++bb) {
+                const double xv = xs[l3[bb / 3] + bb % 3];                                               // :277 gather
+                const double u = c * (SIG ? flip_sign(xv, sg, bb) : xv);                                 // :278-279 sign, Ck
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = fma(K[bb * ND + a], u, acc[a]);                    // :279 Ke @ (.)
+            }
+            if constexpr (SIG) {
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = flip_sign(acc[a], sg, a);                          // :280
+            }
+        };
+        if (h.w) contract(std::true_type());
+        else contract(std::false_type());
+        const unsigned my_colour = sg >> 24;
+        const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
+        if (ps + 1 < SEQ) load_elem(ps + 1);                 // the other half's slots arrive under this accumulation
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (wave == w) {
+                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
+                for (int s = 0; s < h.y; ++s)
+                    if ((int)my_colour == s) {
+                        if constexpr (ACCM == 1) {
+#pragma unroll
+                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
+                                __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+#pragma unroll
+                            for (int q0 = 0; q0 < ND; q0 += 12) {
+                                double old[12];
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[a0[a / 3] + a % 3]; }
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[a0[a / 3] + a % 3] = old[q] + acc[a]; }
+                            }
+                        }
+                    }
+                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
+                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
+                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // hex8 chunks on the matrix cores.  The reference computes Ke @ (Ck * U) for all elements of a type as ONE
@@ -1128,10 +1239,14 @@ class HipBackend : public Backend {
     std::vector<void *> hex_allocs_;
     std::vector<int> hex_nodes_host_[2];                 // to fold the ownership / free masks into the slot table (upload_masks)
     std::vector<unsigned short> hex_tslot_host_[2];
-    // Defaults from the same-box A/B at 10 M dof (profiles/r02_ebe_lab_*.log, tools/ebe_lab.py): 256-element chunks, 5 blocks per
-    // CU (96 VGPRs), ds_add_f64 accumulation: 0.166 ms per apply vs 0.174 for k_ebe_chunk (0.176 vs 0.190 with the fused p.Ap).
-    // PCG_EBE_HEX=0 selects k_ebe_chunk for the hex8 class too; PCG_EBE_ACC=0 the read-add-write accumulation.
-    int hex_mode_ = 2, hex_ept_ = 2, hex_npt_ = 3, hex_acc_ = 1;
+    // Same-box A/B at 10 M dof (tools/ebe_lab.py, profiles/r02_ebe_lab_*.log), one apply with the fused p.Ap:
+    //   k_ebe_chunk, 512-element chunks (round 1)                      0.195 ms
+    //   k_ebe_hex,   256-element chunks, 5 blocks per CU, ds_add_f64   0.180 ms
+    //   k_ebe_hexs,  512-element chunks in two passes, ds_add_f64      0.158 ms   <- default for large meshes
+    // (512 elements per thread pair at once, 6 blocks per CU, read-add-write accumulation, several chunks per block with the
+    // next one prefetched: all measured, all slower - DESIGN.md section 4b.)  PCG_EBE_HEX=0 selects k_ebe_chunk for the hex8
+    // class too; PCG_EBE_ACC=0 the read-add-write accumulation.
+    int hex_mode_ = 1, hex_ept_ = 2, hex_npt_ = 3, hex_acc_ = 1;
     int n_chunks_total_[2] = {0, 0};
     int sh_count_[2] = {0, 0};
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr};
@@ -1385,11 +1500,20 @@ public:
     void launch_hex_a(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
-            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, true, false, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
-                               d_ch_buf_, d_flags_, part, dot_lo, (long long *)nullptr);
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, true, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
+                               d_ch_buf_, d_flags_, part, dot_lo);
         else
-            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, false, false, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
-                               d_ch_buf_, d_flags_, part, dot_lo, (long long *)nullptr);
+            hipLaunchKernelGGL((k_ebe_hex<EPT, NPT, LB, false, ACCM>), dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y,
+                               d_ch_buf_, d_flags_, part, dot_lo);
+    }
+    template <int LB>
+    void launch_hexs(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        };
+        if (hex_acc_ == 1) { if (dot) go(k_ebe_hexs<LB, true, 1>); else go(k_ebe_hexs<LB, false, 1>); }
+        else { if (dot) go(k_ebe_hexs<LB, true, 0>); else go(k_ebe_hexs<LB, false, 0>); }
     }
     template <int EPT, int NPT, int LB>
     void launch_hex(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
@@ -1433,18 +1557,9 @@ public:
         switch (D.nnp) {
         case 8:
             if (D.full && hex_mode_ > 0 && hex_tab_[ph].hdr) {     // hex8 class through the per-launch tables
-                // hex_mode_: 1 = the register budget of k_ebe_chunk (3 / 4 blocks per CU), 2 = one block more, 3 = two more
-                const int lb = (hex_ept_ == 2 ? 3 : 4) + (hex_mode_ - 1);
-                if (hex_ept_ == 2 && hex_npt_ == 3) {
-                    if (lb == 3) launch_hex<2, 3, 3>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
-                    else launch_hex<2, 3, 4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
-                } else if (hex_ept_ == 1 && hex_npt_ == 2) {
-                    if (lb == 4) launch_hex<1, 2, 4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
-                    else if (lb == 5) launch_hex<1, 2, 5>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
-                    else launch_hex<1, 2, 6>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);
-                } else {
-                    throw std::runtime_error("k_ebe_hex: unexpected chunk shape");
-                }
+                if (hex_ept_ == 2 && hex_npt_ == 3) launch_hexs<4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);          // 512-element chunks, two passes
+                else if (hex_ept_ == 1 && hex_npt_ == 2) launch_hex<1, 2, 5>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);   // 256-element chunks
+                else throw std::runtime_error("k_ebe_hex: unexpected chunk shape");
                 break;
             }
             if (D.full && ebe_mfma_) {                          // hex8 class on the matrix cores
@@ -1734,40 +1849,6 @@ public:
         double s = 0;
         for (int k = 0; k < ev_used_; ++k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0_[k], ev1_[k])); s += ms; }
         *ms_sum = s; *count = ev_applies_;
-    }
-    // development: mean cycles between the phase stamps of k_ebe_hex over all blocks of the interior-phase hex8 launch
-    int ebe_phase_cycles(const double *x, double *y, double *out /* 2 waves x 6 */) override
-    {
-        const int ph = hex_tab_[1].hdr ? 1 : 0;
-        if (!hex_tab_[ph].hdr) return -1;
-        const int n = chc_[0].count[ph];
-        long long *d = (long long *)alloc(sizeof(long long) * 16 * (size_t)n);
-        HIP_CHECK(hipMemsetAsync(d, 0, sizeof(long long) * 16 * (size_t)n, st_));
-        for (int rep = 0; rep < 2; ++rep) {
-            if (hex_ept_ == 2 && hex_acc_ == 1)
-                hipLaunchKernelGGL((k_ebe_hex<2, 3, 3, false, true, 1>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
-                                   d_flags_, d_part_ebe_, 0ll, d);
-            else if (hex_ept_ == 2)
-                hipLaunchKernelGGL((k_ebe_hex<2, 3, 3, false, true, 0>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
-                                   d_flags_, d_part_ebe_, 0ll, d);
-            else if (hex_acc_ == 1)
-                hipLaunchKernelGGL((k_ebe_hex<1, 2, 4, false, true, 1>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
-                                   d_flags_, d_part_ebe_, 0ll, d);
-            else
-                hipLaunchKernelGGL((k_ebe_hex<1, 2, 4, false, true, 0>), dim3(n), dim3(kChunkThreads), 0, st_, hex_tab_[ph], chc_[0].ke, x, y, d_ch_buf_,
-                                   d_flags_, d_part_ebe_, 0ll, d);
-        }
-        HIP_CHECK(hipGetLastError());
-        std::vector<long long> h((size_t)16 * n);
-        d2h(h.data(), d, sizeof(long long) * h.size());
-        release(d);
-        for (int k = 0; k < 12; ++k) out[k] = 0.0;
-        for (int b = 0; b < n; ++b)
-            for (int w = 0; w < 2; ++w)
-                for (int k = 1; k < 6; ++k) out[w * 6 + k] += (double)(h[((size_t)b * 2 + w) * 8 + k] - h[((size_t)b * 2 + w) * 8 + k - 1]);
-        for (int k = 0; k < 12; ++k) out[k] /= n;
-        out[0] = n; out[6] = n;
-        return 0;
     }
     int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) override
     {

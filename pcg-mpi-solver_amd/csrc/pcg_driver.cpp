@@ -922,17 +922,6 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
     });
 }
 
-int pcg_ebe_phase_cycles(pcg_engine *e, double *out12)
-{
-    return guarded("pcg_ebe_phase_cycles", [&]() -> int {
-        if (!e || !out12 || e->kind != 1) return set_error("pcg_ebe_phase_cycles: needs a matrix-free engine");
-        double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->zero(dx, sizeof(double) * e->n);
-        if (e->be->ebe_phase_cycles(dx, dy, out12) != 0) return set_error("pcg_ebe_phase_cycles: the hex8 kernel with per-launch tables is not active");
-        return 0;
-    });
-}
-
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each)
 {
     return guarded("pcg_bench_hbm", [&]() -> int {

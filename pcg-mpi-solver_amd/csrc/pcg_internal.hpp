@@ -210,8 +210,6 @@ public:
     virtual void set_profiling(bool on) = 0;
     virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
     virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;
-    // development: mean cycles per phase of the hex8 element kernel (12 doubles: two waves x [n, load, barrier, contraction, accumulate, store])
-    virtual int ebe_phase_cycles(const double *x, double *y, double *out) = 0;
     // stream microbenchmark over `bytes` of device memory: mode 0 read-only, 1 copy (read + write); ms per repetition
     virtual int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) = 0;
 };

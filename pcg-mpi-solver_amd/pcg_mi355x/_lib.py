@@ -95,7 +95,6 @@ _SIGS = {
     "pcg_solve": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(Result)]),
     "pcg_set_profiling": (C.c_int, [_P, C.c_int32]),
     "pcg_bench_spmv": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
-    "pcg_ebe_phase_cycles": (C.c_int, [_P, _P]),
     "pcg_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "pcg_operator_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "pcg_operator_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -84,9 +84,11 @@ class Operator:
             arr, keep = _pack_groups(ebe_groups)
             perm = None if node_perm is None else np.ascontiguousarray(node_perm, np.int64)
             xyz = None if node_coords is None else _f64(np.asarray(node_coords).reshape(self.n_nodes, 3))
-            # elements per thread of the hex8 kernel: 1 = 256-element chunks (k_ebe_hex: 96 VGPRs, 5 workgroups per CU) - the
-            # faster shape in the same-box A/B at 10 M dof (profiles/r02_ebe_lab_*.log); PCG_EBE_EPT=2 gives 512-element chunks
-            ept = os.environ.get("PCG_EBE_EPT", "1")
+            # hex8 chunk size: 512 elements (an 8x8x8 cell, contracted in two passes of 256: k_ebe_hexs) unless that leaves fewer
+            # chunks than a few per CU - then 256 (k_ebe_hex).  Measured: profiles/r02_ebe_lab_*.log; PCG_EBE_EPT overrides.
+            n_elem = sum(int(np.asarray(g["ElemList_Ck"]).shape[0]) for g in ebe_groups)
+            # (1 M dof / 328 k elements: 0.034 ms per apply with 717 chunks of 512 vs 0.040 with 1433 of 256; 59 k elements: 256 wins)
+            ept = os.environ.get("PCG_EBE_EPT", "1" if n_elem < 256 * 512 else "2")
             check(L.pcg_create_ebe(device, self.n_nodes, len(ebe_groups), arr, perm.ctypes.data if perm is not None else None,
                                    int(n_boundary_nodes), xyz.ctypes.data if xyz is not None else None,
                                    (0 if ebe_chunked else 1) | (2 if ept == "1" else 0), C.byref(h)), "pcg_create_ebe")

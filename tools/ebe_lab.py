@@ -20,9 +20,9 @@ from pcg_mi355x.brick import Brick, make_parts
 from pcg_mi355x.operator import from_refmeshpart
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 150
-DEFAULT = ["chunk_ept2:PCG_EBE_HEX=0,PCG_EBE_EPT=2", "chunk_ept1:PCG_EBE_HEX=0,PCG_EBE_EPT=1",
-           "hex_ept2_lb3:PCG_EBE_HEX=1,PCG_EBE_EPT=2", "hex_ept2_lb4:PCG_EBE_HEX=2,PCG_EBE_EPT=2",
-           "hex_ept1_lb4:PCG_EBE_HEX=1,PCG_EBE_EPT=1", "hex_ept1_lb5:PCG_EBE_HEX=2,PCG_EBE_EPT=1", "hex_ept1_lb6:PCG_EBE_HEX=3,PCG_EBE_EPT=1"]
+DEFAULT = ["chunk_512:PCG_EBE_HEX=0,PCG_EBE_EPT=2", "chunk_256:PCG_EBE_HEX=0,PCG_EBE_EPT=1",
+           "hexs_512_two_pass_atomic:PCG_EBE_HEX=1,PCG_EBE_EPT=2,PCG_EBE_ACC=1", "hexs_512_two_pass_rmw:PCG_EBE_HEX=1,PCG_EBE_EPT=2,PCG_EBE_ACC=0",
+           "hex_256_atomic:PCG_EBE_HEX=1,PCG_EBE_EPT=1,PCG_EBE_ACC=1", "hex_256_rmw:PCG_EBE_HEX=1,PCG_EBE_EPT=1,PCG_EBE_ACC=0"]
 configs = [a for a in sys.argv[1:] if ":" in a] or DEFAULT
 KNOBS = ("PCG_EBE_HEX", "PCG_EBE_EPT", "PCG_EBE_MFMA", "PCG_BENCH_SPMV_DOT", "PCG_EBE_PERSIST", "PCG_EBE_ACC")
 
@@ -52,12 +52,6 @@ for cfg in configs:
             res["chunks"] = op.operator_info()["n_chunks"]
         ms = op.bench_spmv(20, 200)
         res["dot" + dot] = {"median_ms": float(np.median(ms)), "min_ms": float(ms.min())}
-        if dot == "0" and os.environ.get("PCG_EBE_HEX", "0") != "0":
-            ph = np.zeros(12)
-            if op._L.pcg_ebe_phase_cycles(op._h, ph.ctypes.data) == 0:
-                names = ["blocks", "loads+tile", "barrier", "contraction", "accumulate", "stores"]
-                res["phase_cycles_wave0"] = dict(zip(names, [round(float(v)) for v in ph[:6]]))
-                res["phase_cycles_wave3"] = dict(zip(names, [round(float(v)) for v in ph[6:]]))
         op.close()
     out[name] = res
     print(name, json.dumps(res), file=sys.stderr, flush=True)
