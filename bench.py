@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ranks", type=int, default=0, help="processes of the multi-core CPU baseline (0 = min(cores, 64))")
     ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
+    ap.add_argument("--pmc-traffic", action="store_true",
+                    help="N = 1: measure the HBM traffic of the SpMV launch on THIS box with two extra rocprofv3 --pmc passes of a short "
+                         "run of this script (FETCH_SIZE, WRITE_SIZE; +1-2 min) instead of quoting profiles/pmc_traffic.json")
     return ap.parse_args(argv)
 
 
@@ -185,6 +188,28 @@ def cpu_baseline(part, N, ranks=0, workload="brick"):
         log(f"multi-process CPU baseline failed: {ex!r}")
         out.update(value=single["value"], cores=1, sample=single["sample"], multi_core_error=repr(ex))
     return out
+
+
+def pmc_traffic_live(args):
+    """HBM bytes per k_spmv<1,true> launch on this box: rocprofv3 --kernel-trace --pmc <counter> passes (one counter per pass, as
+    MI355X_MICROARCH.md prescribes) of a short assembled-operator run of this script; FETCH_SIZE x2 (gfx950: 128-B requests are
+    tallied at 64 B for wide streaming reads - calibrated on the vector kernels in profiles/pmc_traffic.json), WRITE_SIZE as is."""
+    import glob
+    import sqlite3
+    import tempfile
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pcg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "20", "--warmup", "3", "--operator", "sell", "--no-cpu-baseline", "--no-finish",
+               "--nodes-per-side", str(args.nodes_per_side), "--rows-per-lane", str(args.rows_per_lane)]
+        subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        db = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
+        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_spmv<1, true>%' and counter_name = ?",
+                          (ctr,)).fetchall()
+        vals[ctr] = (float(rows[0][0]), int(rows[0][1]))
+    return {"bytes": 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"][0],
+            "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1]}
 
 
 def box_identity(dev):
@@ -460,6 +485,16 @@ def main():
                                                    "(gfx950-corrected), collected on another box in another session - not a measurement of this run")
         except OSError:
             pass
+        if args.pmc_traffic and world == 1:
+            try:
+                live = pmc_traffic_live(args)
+                out["roofline"]["traffic"] = live["bytes"]
+                out["roofline"]["traffic_note"] = ("measured on THIS box by two rocprofv3 --kernel-trace --pmc passes of a 20-step run of this command "
+                                                   f"(FETCH_SIZE {live['FETCH_SIZE_KB_raw']:.0f} KB x2 gfx950 correction + WRITE_SIZE {live['WRITE_SIZE_KB_raw']:.0f} KB, "
+                                                   f"mean of {live['dispatches']} launches)")
+                out["roofline"]["traffic_over_bytes"] = live["bytes"] / sell_bytes
+            except Exception as ex:      # noqa: BLE001
+                log(f"live PMC traffic measurement failed: {ex!r}")
     if world > 1:
         out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]]}
         if head["comm"]:
