@@ -436,9 +436,16 @@ def main():
                 stream = {"read_GBps": e["op"].bench_hbm(2 << 30, "read"), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
         e["op"].close()
 
-    if rank != 0:
+    def shutdown():
+        part.pop("_pcg_mi355x_operator", None)
         if world > 1:
-            dist.barrier(); dist.destroy_process_group()
+            dist.barrier()
+            if hasattr(comm, "close"):
+                comm.close()                 # ncclCommDestroy while the HIP runtime is still up, not at interpreter exit
+            dist.destroy_process_group()
+
+    if rank != 0:
+        shutdown()
         return
 
     head = m if m is not None else e
@@ -503,8 +510,7 @@ def main():
         log("timing the CPU baseline (oracle port: 1 core, then R processes x 1 thread) ...")
         out["cpu_baseline"] = cpu_baseline(part, N, args.cpu_ranks, args.workload)
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+    shutdown()
 
 
 if __name__ == "__main__":

@@ -138,7 +138,8 @@ int pcg_part_local_numbering(int32_t device, int64_t n_glob_nodes, int64_t n_fla
  *       (interface rows -> pack -> exchange || interior rows -> wait -> add in neighbour order);
  *   MPI_SUM -> Comm.allreduce (:622-628) -> ncclAllReduce(ncclDouble, ncclSum) in place on the device status block.
  * One process per GPU, one part per process, part id == rank (pcg_solver.py:91,:320); neighbour ids passed to
- * pcg_set_halo() are peer ranks.  A communicator may serve several engines of the process, one solve at a time.
+ * pcg_set_halo() are peer ranks.  A communicator may serve several engines of the process, one solve at a time; it must
+ * outlive every engine it is attached to (detach with pcg_set_comm_native(e, NULL) or destroy the engines first).
  * Bootstrap: rank 0 calls pcg_rccl_unique_id(), the bytes reach the other ranks by any means the launcher has
  * (MPI_Bcast in the reference's mpiexec world, torch.distributed / a file under torchrun), every rank then calls
  * pcg_comm_create_rccl() (collective).  When a native communicator is attached it takes precedence over

@@ -166,8 +166,13 @@ def main(argv=None):
         print(f">file read time:     {rec['dT_FileRead']:.1f} sec\n>calculation time:   {rec['dT_Calc']:.1f} sec\n"
               f">communication time: {rec['dT_CommWait']:.1f} sec\n>total runtime:      {total:.1f} sec\n"
               f">flag {flag[1:]}, iterations {it[1:]}, relres {relres[1:]}")
+    op = part.pop("_pcg_mi355x_operator", None)
+    if op is not None:
+        op.close()
     if world > 1:
         dist.barrier()
+        if hasattr(comm, "close"):
+            comm.close()                     # ncclCommDestroy while the HIP runtime is still up
         dist.destroy_process_group()
 
 

@@ -89,3 +89,35 @@ def test_c_abi_from_plain_c_on_gpu(tmp_path):
     r = subprocess.run([exe, "48"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "hip-gfx950" in r.stdout and "flag 0" in r.stdout
+
+
+def test_device_entry_points_fail_loudly_without_gpu(product_lib):
+    """The round-2 entry points (native communicator, device-side partition set-up) have no CPU path either: without a
+    device they return an error code and a message, they do not fall back or crash."""
+    import numpy as np
+    lib = ctypes.CDLL(product_lib)
+    if lib.pcg_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    lib.pcg_last_error.restype = ctypes.c_char_p
+    ptr = np.array([0, 2, 4], np.int64); flat = np.array([0, 1, 1, 2], np.int32); part = np.array([0, 1], np.int32)
+    pairs = np.zeros((8, 2), np.int64); n = ctypes.c_int64()
+    lib.pcg_part_interface.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p,
+                                                                                                                  ctypes.POINTER(ctypes.c_int64)]
+    rc = lib.pcg_part_interface(0, 3, 2, ptr.ctypes.data, flat.ctypes.data, part.ctypes.data, 8, pairs.ctypes.data, ctypes.byref(n))
+    assert rc != 0 and b"no HIP device" in lib.pcg_last_error()
+    bad = np.array([0, 7, 1, 2], np.int32)                       # node id out of range: rejected before any device work
+    rc = lib.pcg_part_interface(0, 3, 2, ptr.ctypes.data, bad.ctypes.data, part.ctypes.data, 8, pairs.ctypes.data, ctypes.byref(n))
+    assert rc != 0 and b"out of range" in lib.pcg_last_error()
+    uid = ctypes.create_string_buffer(256)
+    comm = ctypes.c_void_p()
+    lib.pcg_comm_create_rccl.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    rc = lib.pcg_comm_create_rccl(0, 0, 1, uid, ctypes.byref(comm))
+    assert rc != 0 and lib.pcg_last_error()
+
+
+def test_test_double_has_no_native_communicator(hostops):
+    """tests/hostops is a CPU double of the KERNELS only; the native communicator and the device partition passes exist
+    only in the product library."""
+    uid = ctypes.create_string_buffer(256)
+    assert hostops.lib().pcg_rccl_unique_id(uid) != 0
+    assert b"no RCCL communicator" in hostops.lib().pcg_last_error()
