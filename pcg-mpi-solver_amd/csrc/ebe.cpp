@@ -216,6 +216,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         K.nnp = c == 4 ? 8 : 8 * (c + 1);
         K.full = c == 0;
         K.ept = c == 0 ? ept : 1;
+        K.ce = c == 0 ? kChunkThreads * ept : 64;
         K.words = 3 * K.nnp / 32 + 1;
         K.max_nodes = (c == 0 && ept == 1) ? 512 : kChunkMaxNodes;      // 8x8x4 hex cells -> 405 nodes: a 2-nodes-per-thread tile
     }
@@ -229,6 +230,15 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             ke_index[g] = (int32_t)(K.ke_col.size() / ((size_t)ndp * ndp));
             for (int b = 0; b < ndp; ++b)
                 for (int a = 0; a < ndp; ++a) K.ke_col.push_back(a < nd && b < nd ? gs[g].ke[(size_t)a * nd + b] : 0.0);
+            if (c != 0) {                                   // row-split layout: wave w owns rows [w*ndp/4, (w+1)*ndp/4)
+                const int rpw = ndp / 4;
+                for (int w = 0; w < 4; ++w)
+                    for (int b = 0; b < ndp; ++b)
+                        for (int a = 0; a < rpw; ++a) {
+                            const int ar = w * rpw + a;
+                            K.ke_rows.push_back(ar < nd && b < nd ? gs[g].ke[(size_t)ar * nd + b] : 0.0);
+                        }
+            }
             any = true;
         }
     if (!any) return;
@@ -280,7 +290,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         if (o.elems.empty()) return;
         const auto &in = gs[g];
         auto &K = C.cls[cls_of[g]];
-        const int nno = in.nd / 3, CE = kChunkThreads * K.ept, W = K.words;
+        const int nno = in.nd / 3, CE = K.ce, W = K.words;
         const int32_t cid = (int32_t)C.n_chunks++;
         const int32_t kci = (int32_t)K.n_chunks++;
         const int nn = (int)o.nodes.size();
@@ -342,7 +352,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             const auto &in = gs[g];
             const auto &L = per_group[g];
             const int nno = in.nd / 3;
-            const size_t chunk_elems = (size_t)kChunkThreads * C.cls[cls_of[g]].ept;
+            const size_t chunk_elems = (size_t)C.cls[cls_of[g]].ce;
             Open o;
             std::vector<std::pair<uint64_t, int32_t>> keyed;
             std::vector<int> sc;

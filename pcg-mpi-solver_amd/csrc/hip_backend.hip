@@ -756,6 +756,124 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Pattern types other than the full hex8 class (hanging-node octree patterns with up to 32 nodes, and patterns with fewer
+// than 8): k_ebe_rows.  A chunk is 64 elements - ONE per lane - and the four waves of the workgroup each contract a
+// quarter of the output rows (whole local nodes: NDP/4 = 6 / 12 / 18 / 24 rows) of the same 64 elements:
+//   * a lane carries NDP/4 accumulators instead of NDP (12 instead of 48 for the 13-node transition cells): 5-8 waves
+//     per SIMD instead of 2, and a workgroup's critical path is a quarter of the element's contraction;
+//   * four times as many workgroups for the same elements.  On the two-level octree mesh of bench.py (4 608 transition
+//     cells among 1.1 M hex8 cells) the round-1 kernel ran 18 workgroups for 47.6 us - more than the 33 us the 1.1 M
+//     hex8 cells took - because each of them streamed a 48 x 48 Ke through one wave per SIMD with nothing to hide the
+//     scalar-load waits behind;
+//   * Ke is laid out per wave (ke_rows: wave, column, row-in-wave), so a wave's slice of a column is one contiguous
+//     scalar load; the wave index is read with readfirstlane so the loads stay scalar.
+// Gather, signs, Ck, LDS accumulation (wave after wave, sub-colour after sub-colour, ds_add_f64) and the exclusive /
+// shared write-out are those of k_ebe_hex; every wave gathers all NDP inputs (the tile is in LDS, the redundancy is 4 LDS
+// reads instead of 1 per input).
+// ------------------------------------------------------------------------------------------------
+template <int NNP, bool DOT>
+__global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
+    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
+    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const double *__restrict__ ke_rows, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
+    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
+{
+    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
+    constexpr int CE = 64, NDP = 3 * NNP, RPW = NDP / 4, NPW = NNP / 4, W = NDP / 32 + 1;
+    static_assert(RPW % 3 == 0, "a wave owns whole local nodes");
+    __shared__ double xs[3 * kChunkMaxNodes];
+    __shared__ double ys[3 * kChunkMaxNodes];
+    const int chunk = chunk_list[blockIdx.x];
+    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
+    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
+    const int kci = h2.x, nd = h2.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // element `lane` of the chunk (every wave loads it: same cache lines)
+    unsigned sg[W];
+    int l3[NNP], lown[NPW];
+#pragma unroll
+    for (int w = 0; w < W; ++w) sg[w] = ntload(sgn + ((size_t)kci * W + w) * CE + lane);
+    const double c = ntload(ck + (size_t)kci * CE + lane);
+#pragma unroll
+    for (int k = 0; k < NNP; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) lown[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + wave * NPW + k) * CE + lane);
+    int dst[NPT], sl3[NPT];
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        int g = -1;
+        dst[j] = 0;
+        sl3[j] = 0;
+        if (n < h.y) {
+            g = ntload(nodes + h.x + n); dst[j] = ntload(dstl + h.x + n);
+            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
+        }
+        if (g >= 0) {
+            const double *xp = x + 3 * (size_t)g;
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    }
+    __syncthreads();
+    const double *K = ke_rows + ((size_t)h.w * 4 + wave) * NDP * RPW;       // this wave's rows: [column b][row a]
+    double acc[RPW];
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) acc[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NDP; ++b) {
+        if (b < nd) {                                        // nd is block-uniform: scalar compare, loops stay unrolled
+            const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);                   // :277-279
+#pragma unroll
+            for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                       // :279 Ke @ (.)
+        }
+    }
+    const int row0 = wave * RPW;                             // global row of acc[0]
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) {                          // :280 (dynamic bit position: the wave index is not a constant)
+        const int r = row0 + a;
+        acc[a] = flip_sign(acc[a], sg[W == 1 ? 0 : (r >> 5)], r & 31);
+    }
+    const int my_colour = (int)(sg[W - 1] >> 24);
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave == w)
+            for (int s = 0; s < h.z; ++s)
+                if (my_colour == s) {
+#pragma unroll
+                    for (int a = 0; a < RPW; ++a)
+                        if (row0 + a < nd)                   // padded rows alias local node 0: never add them
+                            __hip_atomic_fetch_add(&ys[lown[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        if (n < h.y) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                const uint8_t *fp = flags + dst[j];
+                if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
+                if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
+                if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // hex8 chunks on the matrix cores.  The reference computes Ke @ (Ck * U) for all elements of a type as ONE
 // dgemm (pcg_solver.py:279): Y(24 x Ne) = Ke(24 x 24) . U(24 x Ne).  That is what v_mfma_f64_16x16x4_f64 is
@@ -1211,6 +1329,13 @@ class HipBackend : public Backend {
     int dev_ = 0;
     int n_cu_ = 256;
     hipStream_t st_ = nullptr;
+    // PCG_EBE_STREAMS=1: the element launches of the non-hex8 classes run on a second stream beside the hex8 launch of the same
+    // phase (disjoint exclusive nodes, disjoint boundary slots; fork / join with events).  Measured on the two-level octree
+    // mesh (1.2 M dof): a stand-alone apply 0.065 -> 0.059 ms, but the PCG iteration 0.097 -> 0.100 ms - the two cross-stream
+    // waits per apply cost the look-ahead loop more than the overlap returns - so it is off by default.  ls_ = launch stream.
+    hipStream_t st2_ = nullptr, ls_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool ebe_two_streams_ = false;
     // matrix
     int bs_ = 3;
     int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
@@ -1231,7 +1356,7 @@ class HipBackend : public Backend {
         int *list[2] = {nullptr, nullptr};
         int count[2] = {0, 0};
         unsigned short *lid = nullptr;
-        double *ck = nullptr, *ke = nullptr;
+        double *ck = nullptr, *ke = nullptr, *ke_rows = nullptr;
         unsigned *sgn = nullptr;
     } chc_[kChunkClasses];
     // per-launch tables of the hex8 class for k_ebe_hex (hex_mode_ > 0)
@@ -1314,6 +1439,11 @@ public:
             throw std::runtime_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
         n_cu_ = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        ls_ = st_;
+        if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_two_streams_ = atoi(e) != 0;
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
@@ -1333,7 +1463,7 @@ public:
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
-            for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke})
+            for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke, (void *)D.ke_rows})
                 if (p) (void)hipFree(p);
         for (void *p : {(void *)d_ch_hdr_, (void *)d_ch_nodes_, (void *)d_ch_tslot_, (void *)d_ch_dst_, (void *)d_ch_buf_, (void *)d_part_ebe_, (void *)d_sh_node_[0],
                         (void *)d_sh_node_[1], (void *)d_sh_ptr_[0], (void *)d_sh_ptr_[1]})
@@ -1348,6 +1478,9 @@ public:
             (void)hipHostFree(h_mirror_);
             for (auto e : ev_slot_) (void)hipEventDestroy(e);
         }
+        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        if (ev_join_) (void)hipEventDestroy(ev_join_);
+        if (st2_) (void)hipStreamDestroy(st2_);
         if (st_) (void)hipStreamDestroy(st_);
     }
     const char *name() const override { return "hip-gfx950"; }
@@ -1438,6 +1571,7 @@ public:
                 D.nnp = K.nnp; D.ept = K.ept; D.full = K.full;
                 if (K.n_chunks == 0) continue;
                 up(D.lid, K.lid); up(D.ck, K.ck); up(D.sgn, K.sgn); up(D.ke, K.ke_col);
+                if (!K.ke_rows.empty()) up(D.ke_rows, K.ke_rows);
                 for (int ph = 0; ph < 2; ++ph) {
                     D.count[ph] = (int)K.list[ph].size();
                     n_chunks_total_[ph] += D.count[ph];
@@ -1510,7 +1644,7 @@ public:
     void launch_hexs(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, st_, hex_tab_[ph], ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+            hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, hex_tab_[ph], ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         };
         if (hex_acc_ == 1) { if (dot) go(k_ebe_hexs<LB, true, 1>); else go(k_ebe_hexs<LB, false, 1>); }
         else { if (dot) go(k_ebe_hexs<LB, true, 0>); else go(k_ebe_hexs<LB, false, 0>); }
@@ -1535,20 +1669,30 @@ public:
     void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_,
                                d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_,
+            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_,
                                d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+    }
+    template <int NNP>
+    void launch_rows(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_ebe_rows<NNP, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        else
+            hipLaunchKernelGGL((k_ebe_rows<NNP, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     template <int EPT>
     void launch_mfma(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (dot)
-            hipLaunchKernelGGL((k_ebe_mfma<EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+            hipLaunchKernelGGL((k_ebe_mfma<EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
                                d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         else
-            hipLaunchKernelGGL((k_ebe_mfma<EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, st_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
+            hipLaunchKernelGGL((k_ebe_mfma<EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
                                d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
     // -> number of dot partials the launch writes
@@ -1567,13 +1711,13 @@ public:
                 else launch_mfma<1>(D, ph, x, y, dot, part, dot_lo);
                 break;
             }
-            if (!D.full) launch_chunks<8, 1, false>(D, ph, x, y, dot, part, dot_lo);
+            if (!D.full) launch_rows<8>(D, ph, x, y, dot, part, dot_lo);             // fewer than 8 nodes, padded
             else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo);
             else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo);
             break;
-        case 16: launch_chunks<16, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
-        case 24: launch_chunks<24, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
-        default: launch_chunks<32, 1, false>(D, ph, x, y, dot, part, dot_lo); break;
+        case 16: launch_rows<16>(D, ph, x, y, dot, part, dot_lo); break;
+        case 24: launch_rows<24>(D, ph, x, y, dot, part, dot_lo); break;
+        default: launch_rows<32>(D, ph, x, y, dot, part, dot_lo); break;
         }
         return D.count[ph];
     }
@@ -1585,11 +1729,25 @@ public:
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         if (zero_first && ch_needs_zero_) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
-            for (const auto &D : chc_)                           // one launch per node-count class
-                if (D.count[ph]) {
-                    const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
-                    if (fuse) cnt_ebe_ += np;
-                }
+            int others = 0;
+            for (int c = 1; c < kChunkClasses; ++c) others += chc_[c].count[ph] > 0;
+            const bool fork = ebe_two_streams_ && chc_[0].count[ph] > 0 && others > 0;
+            if (fork) {                                          // the other classes beside the hex8 launch
+                HIP_CHECK(hipEventRecord(ev_fork_, st_));
+                HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
+            }
+            for (int c = 0; c < kChunkClasses; ++c) {            // one launch per node-count class
+                const auto &D = chc_[c];
+                if (!D.count[ph]) continue;
+                ls_ = (fork && c > 0) ? st2_ : st_;
+                const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
+                if (fuse) cnt_ebe_ += np;
+            }
+            ls_ = st_;
+            if (fork) {
+                HIP_CHECK(hipEventRecord(ev_join_, st2_));
+                HIP_CHECK(hipStreamWaitEvent(st_, ev_join_, 0));
+            }
             if (sh_count_[ph]) {
                 const int grid = (3 * sh_count_[ph] + kBlock - 1) / kBlock;
                 double *part = d_part_ebe_ + cnt_ebe_;

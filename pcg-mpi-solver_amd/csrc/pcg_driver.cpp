@@ -540,7 +540,7 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
             b += 34.0 * (double)Ch.nodes.size();             // per tile node: id 4 + dst 4 + slot 2, x tile in 24
             b += 24.0 * (double)Ch.nodes.size();             //                y (exclusive) or boundary slot out 24
             for (const auto &K : Ch.cls)                     // per element slot: local node ids, Ck, sign words
-                b += (double)K.n_chunks * kChunkThreads * K.ept * (2.0 * K.nnp + 8.0 + 4.0 * K.words);
+                b += (double)K.n_chunks * K.ce * (2.0 * K.nnp + 8.0 + 4.0 * K.words);
             b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
             for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size();   // ... y out 24 + node id + run pointer
             b += 32.0 * (double)Ch.n_chunks;                 // chunk headers

@@ -69,14 +69,17 @@ constexpr int kChunkClasses = 5;                   // 0: exactly 8 nodes (hex8, 
 struct EbeClassHost {
     int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
     bool full = false;                 // every element of the class has exactly nnp nodes (no padding guards needed)
-    int32_t ept = 1;                   // elements per thread: a chunk holds 256*ept elements (2 only for nnp == 8)
+    int32_t ept = 1;                   // hex8 class: elements per thread, a chunk holds 256*ept elements
+    int32_t ce = kChunkThreads;        // element slots per chunk: 256*ept for the hex8 class, 64 for the others (one element per
+                                       // LANE; the four waves of the workgroup contract a quarter of the output rows each)
     int32_t words = 1;                 // sign words per element = NDP/32 + 1; bits 24..31 of the last word = sub-colour
     int32_t max_nodes = kChunkMaxNodes; // tile nodes a chunk of this class may have (512 for the 256-element hex8 chunks)
     int64_t n_chunks = 0;
-    std::vector<uint16_t> lid;         // (n_chunks, nnp, 256*ept) local node index of element-node l (0 for padding)
-    std::vector<double> ck;            // (n_chunks, 256*ept)   (0 for padding slots)
-    std::vector<uint32_t> sgn;         // (n_chunks, words, 256*ept); sub-colour 255 = padding slot
+    std::vector<uint16_t> lid;         // (n_chunks, nnp, ce) local node index of element-node l (0 for padding)
+    std::vector<double> ck;            // (n_chunks, ce)   (0 for padding slots)
+    std::vector<uint32_t> sgn;         // (n_chunks, words, ce); sub-colour 255 = padding slot
     std::vector<double> ke_col;        // (groups of the class, NDP b, NDP a) column-major, zero padded
+    std::vector<double> ke_rows;       // 64-slot classes: (groups, 4 waves, NDP b, NDP/4 a): the rows of one wave contiguous per column
     std::vector<int32_t> list[2];      // per phase: global chunk ids of this class (one launch each)
 };
 struct EbeChunkedHost {

@@ -56,7 +56,7 @@ public:
             for (int32_t cid : K.list[ph]) {
                 const int32_t *h = &C.hdr[(size_t)cid * 8];
                 const int32_t off = h[0], nn = h[1], nsub = h[2], kci = h[4], nd = h[5];
-                const int CE = kChunkThreads * K.ept, W = K.words, ndp = 3 * K.nnp;
+                const int CE = K.ce, W = K.words, ndp = 3 * K.nnp;
                 const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
                 acc.assign((size_t)nd * CE, 0.0);
                 for (int n = 0; n < nn; ++n)
