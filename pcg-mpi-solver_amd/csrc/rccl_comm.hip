@@ -144,6 +144,9 @@ class RcclComm : public Comm {
     hipEvent_t ev_packed_[kFence] = {}, ev_done_[kFence] = {};
     int fence_ = 0, open_fence_ = -1;
     bool timing_ = false;
+    // PCG_RCCL_ALLOW_SELF=1 (tests): a part may list ITSELF as a neighbour, so that a one-GPU box drives the real
+    // ncclSend / ncclRecv group, the comm stream and the fences on librccl (RCCL matches a send to self with the recv of the group)
+    bool allow_self_ = std::getenv("PCG_RCCL_ALLOW_SELF") != nullptr;
     EventRing t_halo_, t_red_;
     CommStats st_;
 
@@ -198,7 +201,7 @@ public:
             const int64_t off = h.send_ptr[j], cnt = h.send_ptr[j + 1] - off;
             if (cnt <= 0) continue;
             const int peer = h.peer_ids[j];
-            if (peer < 0 || peer >= size_ || peer == rank_) {
+            if (peer < 0 || peer >= size_ || (peer == rank_ && !allow_self_)) {
                 (void)A.GroupEnd();
                 throw std::runtime_error("rccl comm: neighbour part id is not a peer rank (one part per rank, pcg_solver.py:91)");
             }

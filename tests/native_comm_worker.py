@@ -104,8 +104,33 @@ def main():
         o = run_rank(P, probe[P["DofVector"]], comm, kind, device, timing)
         np.savez(os.path.join(outdir, f"{case}_{kind}_rank{rank}.npz"), **o)
         comm.close()
+    elif mode == "selfloop":
+        # ONE rank on real librccl whose part lists ITSELF as its only neighbour (PCG_RCCL_ALLOW_SELF=1): the interface
+        # exchange then delivers the part's own partial sums back to it, so y = A_local x with the interface dofs doubled.
+        case, kind, outdir = sys.argv[2:5]
+        parts, probe = build(case)
+        P = parts[0]
+        assert len(P["NbrMPIdVector"]) == 1
+        P["NbrMPIdVector"] = [0]
+        P["Id"] = 0
+        comm = RcclComm.from_file(0, 1, 0, os.path.join(outdir, "id_self_" + kind))
+        from pcg_mi355x.operator import from_refmeshpart
+        x = probe[P["DofVector"]]
+        op = from_refmeshpart(P, comm=comm, kind=kind)
+        y = op.apply(x)
+        d = op.diag()
+        st = comm.stats()
+        op.close()
+        Q = {k: v for k, v in P.items()}
+        Q["NbrMPIdVector"], Q["OvrlpLocalDofVecList"], Q["OvrlpLocalNodeIdVecList"] = [], [], []
+        lop = from_refmeshpart(Q, kind=kind)                      # the same part without any exchange
+        y0, d0 = lop.apply(x), lop.diag()
+        lop.close()
+        np.savez(os.path.join(outdir, f"selfloop_{kind}.npz"), y=y, y0=y0, d=d, d0=d0, ovl=np.asarray(P["OvrlpLocalDofVecList"][0]),
+                 n_halo=st["n_halo"])
+        comm.close()
     else:
-        raise SystemExit("mode must be threads or proc")
+        raise SystemExit("mode must be threads, proc or selfloop")
 
 
 if __name__ == "__main__":

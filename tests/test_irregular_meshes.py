@@ -60,6 +60,7 @@ SPECS = [
     ([(8, 200), (4, 150), (9, 60)], False),    # mixed pattern sizes: chunked + generic paths together
     ([(8, 240), (6, 90)], True),               # hub node shared by ~110 elements
     ([(4, 500)], False),                       # only non-hex patterns
+    ([(20, 120), (5, 40), (30, 90), (7, 30), (13, 70)], False),   # node-blocked patterns of every node-count class: <= 24, <= 32, < 8, <= 16
 ]
 
 

@@ -75,6 +75,24 @@ def test_real_rccl_world_size_1(gpu_lib, tmp_path):
         assert 0 < float(outs[0]["t_comm"]) < float(outs[0]["t_total"])
 
 
+def test_real_rccl_send_recv_group_on_one_gpu(gpu_lib, tmp_path):
+    """The exchange itself on real librccl: one rank whose part lists ITSELF as its neighbour (PCG_RCCL_ALLOW_SELF=1), so
+    ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the communication stream and both fence events run on RCCL, not
+    on the stand-in.  What comes back is the part's own partial sums: y = A_local x with the interface dofs doubled."""
+    env = _env(False)
+    env["PCG_RCCL_ALLOW_SELF"] = "1"
+    for kind in ("sell", "ebe"):
+        r = subprocess.run([sys.executable, WORKER, "selfloop", "n9_p2", kind, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        o = np.load(os.path.join(tmp_path, f"selfloop_{kind}.npz"))
+        ovl = o["ovl"]
+        assert len(ovl) > 100 and int(o["n_halo"]) >= 2              # one exchange for A x, one for diag(A)
+        for got, loc in ((o["y"], o["y0"]), (o["d"], o["d0"])):
+            want = loc.copy()
+            want[ovl] += loc[ovl]
+            assert relerr(got, want) < 1e-13                        # (the exchange-free operator numbers its rows differently)
+
+
 @pytest.mark.parametrize("cases", ["n9_p2,n9_p8", "n9_p2_flag4,n9_p2_maxiter", "oct_p3,oct_p2_z,n13_t3_p4_ud"])
 def test_parts_as_threads_on_one_gpu(gpu_lib, tmp_path, cases):
     r = subprocess.run([sys.executable, WORKER, "threads", cases, "sell,ebe", str(tmp_path)], env=_env(True),
