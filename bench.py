@@ -397,8 +397,8 @@ def main():
         n_loc, nnz_loc = op.n, op.nnz
         sell_bytes, sell_flops = op.operator_cost()
         if rank == 0:                                # what THIS box's HBM delivers to a plain stream kernel on the engine's stream
-            stream = {"read_GBps": op.bench_hbm(2 << 30, "read"), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
-                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 2 GiB (read) / 1 + 1 GiB (copy)"}
+            stream = {"read_GBps": op.bench_hbm(8 << 30, "read", 10), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
+                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy)"}
         if rank == 0:
             if brick.nnz is None:
                 brick.nnz = op.nnz if world == 1 else None
@@ -433,7 +433,7 @@ def main():
         if m is None:
             n_loc = e["op"].n
             if rank == 0:
-                stream = {"read_GBps": e["op"].bench_hbm(2 << 30, "read"), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
+                stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
         e["op"].close()
 
     def shutdown():

@@ -1307,9 +1307,11 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const double2 *__restric
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
     int64_t t = t0;
-    for (; t + 3 * ts < n2; t += 4 * ts) {
+    for (; t + 7 * ts < n2; t += 8 * ts) {                 // eight 16-B loads in flight per lane
         const double2 v0 = ntload(a + t), v1 = ntload(a + t + ts), v2 = ntload(a + t + 2 * ts), v3 = ntload(a + t + 3 * ts);
-        s0 += v0.x + v0.y; s1 += v1.x + v1.y; s2 += v2.x + v2.y; s3 += v3.x + v3.y;
+        const double2 v4 = ntload(a + t + 4 * ts), v5 = ntload(a + t + 5 * ts), v6 = ntload(a + t + 6 * ts), v7 = ntload(a + t + 7 * ts);
+        s0 += (v0.x + v0.y) + (v4.x + v4.y); s1 += (v1.x + v1.y) + (v5.x + v5.y);
+        s2 += (v2.x + v2.y) + (v6.x + v6.y); s3 += (v3.x + v3.y) + (v7.x + v7.y);
     }
     for (; t < n2; t += ts) { const double2 v = ntload(a + t); s0 += v.x + v.y; }
     const double s = (s0 + s1) + (s2 + s3);
@@ -2014,7 +2016,8 @@ public:
         double2 *a = (double2 *)alloc((size_t)n2 * 16), *b = mode == 1 ? (double2 *)alloc((size_t)n2 * 16) : nullptr;
         double *out = (double *)alloc(8);
         HIP_CHECK(hipMemsetAsync(a, 0x3c, (size_t)n2 * 16, st_));          // finite non-zero doubles
-        const int grid = n_cu_ * 8;
+        int grid = n_cu_ * (mode == 1 ? 4 : 32);       // measured best of {4, 8, 16, 32} blocks per CU for each mode
+        if (const char *e = getenv("PCG_STREAM_BLOCKS_PER_CU")) grid = n_cu_ * std::max(1, atoi(e));
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         for (int k = -3; k < reps; ++k) {
