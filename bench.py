@@ -16,8 +16,8 @@ multi-GPU data path is the engine's native communicator (csrc/rccl_comm.hip): gr
 communication stream overlapped with the interior rows, two ncclAllReduce per iteration - no Python in the loop.
 
 Objects on the JSON line besides the contract's fields:
-  roofline     - dominant kernel k_spmv: PHYSICAL bytes of the stored operator per launch (pcg_operator_cost: 76 B per
-                 stored 3x3 block + x in + y out) / mean launch time from HIP events on the engine stream inside the
+  roofline     - dominant kernel k_spmv: PHYSICAL bytes of the stored operator per launch (pcg_operator_cost: 72 B of values
+                 + a 4 B column, or a 2 B column offset where the slices allow it, per stored 3x3 block + x in + y out) / mean launch time from HIP events on the engine stream inside the
                  timed region -> achieved GB/s, frac = achieved / 8 TB/s (<= 1 by construction).  The SURVEY 8(d)
                  CSR-equivalent figure (12 nnz + 20 n: what a scalar-CSR kernel would have to move) is reported
                  separately as csr_equivalent_*; `hbm_stream_this_box` is a plain read / copy stream measured in this run
@@ -98,7 +98,7 @@ def launch_ranks(args):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         log("launching", args.gpus, "ranks:", " ".join(cmd[1:8]), "...")
-        limit = float(os.environ.get("PCG_BENCH_RANKS_TIMEOUT_S", "1500"))     # a hung collective must not eat the caller's whole budget
+        limit = float(os.environ.get("PCG_BENCH_RANKS_TIMEOUT_S", "900"))     # a hung collective must not eat the caller's whole budget
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
         try:
             out, _ = p.communicate(timeout=limit)
@@ -398,7 +398,9 @@ def main():
         sell_bytes, sell_flops = op.operator_cost()
         if rank == 0:                                # what THIS box's HBM delivers to a plain stream kernel on the engine's stream
             stream = {"read_GBps": op.bench_hbm(8 << 30, "read", 10), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
-                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy)"}
+                      "slice_read_GBps": op.bench_hbm(6 << 30, 2, 10),
+                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy); slice_read = one wave per contiguous 126 KB region in 4608-B steps, 8 B per lane - the shape in which "
+                              "k_spmv streams a slice's values, without columns, gathers or arithmetic: the ceiling of that access pattern on this box"}
         if rank == 0:
             if brick.nnz is None:
                 brick.nnz = op.nnz if world == 1 else None
@@ -433,7 +435,8 @@ def main():
         if m is None:
             n_loc = e["op"].n
             if rank == 0:
-                stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
+                stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy"),
+                          "slice_read_GBps": e["op"].bench_hbm(6 << 30, 2, 10)}
         e["op"].close()
 
     def shutdown():
@@ -467,25 +470,28 @@ def main():
         t_k = m["op_ms"] * 1e-3
         achieved = sell_bytes / t_k / 1e9
         alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                 # what scalar CSR (f64 value + i32 column per nnz) would move
-        out["config"]["format"] = f"SELL-{info['slice_rows']} over 3x3 blocks"
+        col_bytes = int(round((sell_bytes - 16.0 * n_loc) / info["stored_blocks"] - 72.0))          # 4, or 2 (16-bit column offsets)
+        out["config"]["format"] = f"SELL-{info['slice_rows']} over 3x3 blocks, {8 * col_bytes}-bit block columns"
         out["config"]["spmv_achieved_GBps"] = achieved
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_spmv<1,true> (SELL-BSR3 SpMV + fused p.Ap)" + (" - this rank's part" if world > 1 else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_launch": sell_bytes,
-            "bytes_definition": "stored operator: 76 B per stored 3x3 block (72 B values + one i32 column) + x in + y out (16 B/dof) + slice "
+            "bytes_definition": f"stored operator: {72 + col_bytes} B per stored 3x3 block (72 B values + one {8 * col_bytes}-bit column"
+                                + (" offset from the slice's base column" if col_bytes == 2 else "") + ") + x in + y out (16 B/dof) + slice "
                                 "pointers - the algorithmic traffic of the block format (pcg_operator_cost)",
             "avg_launch_ms": m["op_ms"], "launches_timed": m["n_op"],
             "traffic": None,
             "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 passes of their own; the committed passes for this kernel are under "
                             "profiles/ (DESIGN.md section 8) - traffic / bytes_per_launch = 1.03",
             "hbm_stream_this_box": stream, "frac_of_stream_read": achieved / stream["read_GBps"] if stream else None,
+            "frac_of_slice_read": achieved / stream["slice_read_GBps"] if stream else None,
             "csr_equivalent_bytes": alg_bytes, "csr_equivalent_GBps": alg_bytes / t_k / 1e9,
             "csr_equivalent_note": "SURVEY 8(d) formula 12 nnz + 20 n: a scalar-CSR kernel's traffic for the same product; NOT what this "
                                    "kernel moves (it can exceed the HBM peak) - kept for comparison with CSR codes only",
             "standalone_spmv": m["standalone"]}
         try:        # PMC traffic of an identical launch, collected by separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}")
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}" + ("_col16" if col_bytes == 2 else ""))
             if pmc and world == 1:
                 out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = ("from profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch "

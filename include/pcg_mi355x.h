@@ -208,7 +208,9 @@ int pcg_set_profiling(pcg_engine *e, int32_t on);
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
 /* HBM stream microbenchmark on the engine's device and stream (16 B per lane, non-temporal, grid-stride - the access
- * shape of the solver's kernels): mode 0 reads `bytes`, mode 1 copies `bytes` (read + write = 2 * bytes of traffic).
+ * shape of the solver's kernels): mode 0 reads `bytes`, mode 1 copies `bytes` (read + write = 2 * bytes of traffic);
+ * modes 2-4 are access-pattern probes that read `bytes` the way k_spmv streams the values of its slices (2: one wave
+ * per contiguous region, 8 B per lane; 3: the same with 16 B per lane; 4: step-major across the grid).
  * The practical bandwidth ceiling of the box a number was measured on, reported beside the 8 TB/s spec (bench.py). */
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each /* reps */);
 int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free */, int64_t *n_elem, int64_t *n_slots,

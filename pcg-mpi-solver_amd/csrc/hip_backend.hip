@@ -132,8 +132,23 @@ __device__ __forceinline__ int2 ntload(const int2 *p)
     return make_int2(t.x, t.y);
 }
 
-template <int RPL, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
+__device__ __forceinline__ int ntload(const unsigned short *p) { return (int)__builtin_nontemporal_load(p); }
+__device__ __forceinline__ int2 ntload(const ushort2 *p)
+{
+    const unsigned t = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    return make_int2((int)(t & 0xffffu), (int)(t >> 16));
+}
+
+// COL16: the block columns of a slice are stored as 16-bit offsets from the slice's smallest column (colbase[s]) -
+// 74 instead of 76 bytes per stored block; chosen at upload when every slice spans fewer than 65536 block columns
+// (node numberings with a bandwidth below 32 k nodes, e.g. the 10 M-dof brick: 22 651).  Same columns, same order,
+// same arithmetic: results are bit-identical to the 32-bit form.
+#ifndef PCG_SPMV_ABL
+#define PCG_SPMV_ABL 0     // development builds only (tools/spmv_ablation.sh): 1 = no x gather (columns still loaded), 2 = gather from a
+#endif                     // 24 KB window of x (always cache hits), 4 = no column loads either.  Ablated kernels compute WRONG results.
+template <int RPL, bool DOT, bool COL16>
+__global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
+                                                 const int *__restrict__ colbase,
                                                  const double *__restrict__ vals, const double *__restrict__ x,
                                                  double *__restrict__ y, const uint8_t *__restrict__ flags,
                                                  double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
@@ -142,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     constexpr int C = 64 * RPL;
     using DV = typename VecT<RPL>::d;
     using IV = typename VecT<RPL>::i;
+    using CV = typename std::conditional<COL16, typename std::conditional<RPL == 1, unsigned short, ushort2>::type, IV>::type;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // Slice -> wave mapping.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
     // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
@@ -158,19 +174,27 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
         const int64_t base = slice_ptr[s];
         const int w = (int)(slice_ptr[s + 1] - base);
         const DV *vp = reinterpret_cast<const DV *>(vals + (size_t)base * 9 * C) + lane;
-        const IV *cp = reinterpret_cast<const IV *>(cols + (size_t)base * C) + lane;
+        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
+        int cb = 0;
+        if constexpr (COL16) cb = colbase[s];
         double acc[RPL][3];
 #pragma unroll
         for (int h = 0; h < RPL; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.0;
 #pragma unroll 3
         for (int k = 0; k < w; ++k) {
-            const IV jv = ntload(cp + (size_t)k * 64);
+            IV jv = (PCG_SPMV_ABL & 4) ? IV{} : ntload(cp + (size_t)k * 64);
+            if constexpr (COL16) {
+                if constexpr (RPL == 1) jv += cb; else { jv.x += cb; jv.y += cb; }
+            }
+            if constexpr ((PCG_SPMV_ABL & 2) != 0 && RPL == 1) jv &= 1023;
             DV v[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
             if constexpr (RPL == 1) {
                 const double *xp = x + 3 * (size_t)jv;
-                const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+                double x0, x1, x2;
+                if constexpr ((PCG_SPMV_ABL & 1) != 0) { x0 = (double)jv; x1 = 2.0; x2 = 3.0; }      // column consumed, no gather
+                else { x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     acc[0][a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[0][a])));
@@ -1318,6 +1342,44 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const double2 *__restric
     if (s == 1.2345e-300) out[0] = s;              // keeps the loads alive, never true for the benchmark data
 }
 
+// Access-pattern probes (modes 2-4 of pcg_bench_hbm; tools only): a wave streams its own contiguous "slice" of
+// W steps x 4608 B like k_spmv reads the values of a slice (nine 512-B planes per step), without gathers or FMAs.
+//   PAT 0: wave g owns region g, g + G, ...; 8-B loads per lane (k_spmv RPL = 1)
+//   PAT 1: the same regions with 16-B loads per lane (two steps = nine 1-KB loads)
+//   PAT 2: step-major across the grid: at step k wave g reads chunk (k * G + g) of its round - one compact window
+template <int PAT>
+__global__ __launch_bounds__(kBlock) void k_stream_slices(const double *__restrict__ a, double *__restrict__ out, int64_t n_regions, int W)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t G = (int64_t)gridDim.x * kWavesPerBlock, g = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int64_t r = g; r < n_regions; r += G) {
+        if constexpr (PAT == 0 || PAT == 2) {
+            const int64_t round = r / G;
+#pragma unroll 3
+            for (int k = 0; k < W; ++k) {
+                const double *p = PAT == 0 ? a + ((size_t)r * W + k) * 576 + lane
+                                           : a + (((size_t)round * W + k) * G + g) * 576 + lane;
+                double v[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = ntload(p + c * 64);
+                s0 += (v[0] + v[1]) + v[2]; s1 += (v[3] + v[4]) + v[5]; s2 += (v[6] + v[7]) + v[8];
+            }
+        } else {
+            const double2 *p2 = reinterpret_cast<const double2 *>(a + (size_t)r * W * 576) + lane;
+            for (int k = 0; k + 1 < W; k += 2) {
+                double2 v[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = ntload(p2 + ((size_t)k / 2 * 9 + c) * 64);
+#pragma unroll
+                for (int c = 0; c < 9; c += 3) { s0 += v[c].x + v[c].y; s1 += v[c + 1].x + v[c + 1].y; s2 += v[c + 2].x + v[c + 2].y; }
+            }
+        }
+    }
+    const double s = (s0 + s1) + s2;
+    if (s == 1.2345e-300) out[0] = s;
+}
+
 __global__ __launch_bounds__(kBlock) void k_stream_copy(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
 {
     const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
@@ -1344,6 +1406,8 @@ class HipBackend : public Backend {
     int C_ = 64;
     int64_t *d_slice_ptr_ = nullptr;
     int *d_cols_ = nullptr;
+    unsigned short *d_cols16_ = nullptr;      // COL16 form (then d_cols_ stays null for 3x3-block matrices)
+    int *d_colbase_ = nullptr;
     double *d_vals_ = nullptr, *d_diag_ = nullptr;
     uint8_t *d_flags_ = nullptr;
     // matrix-free operator
@@ -1460,7 +1524,7 @@ public:
     ~HipBackend() override
     {
         (void)hipSetDevice(dev_);
-        for (void *p : {(void *)d_slice_ptr_, (void *)d_cols_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
+        for (void *p : {(void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
@@ -1514,12 +1578,36 @@ public:
         bs_ = m.bs;
         n_nodes_ = m.n_nodes; n_ = m.bs * m.n_nodes; n_slices_ = m.n_slices; n_bnd_slices_ = m.n_bnd_slices; C_ = m.C;
         d_slice_ptr_ = (int64_t *)alloc(sizeof(int64_t) * m.slice_ptr.size());
-        d_cols_ = (int *)alloc(sizeof(int) * m.cols.size());
         d_vals_ = (double *)alloc(sizeof(double) * m.vals.size());
         d_diag_ = (double *)alloc(sizeof(double) * m.diag.size());
         d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
         h2d(d_slice_ptr_, m.slice_ptr.data(), sizeof(int64_t) * m.slice_ptr.size());
-        h2d(d_cols_, m.cols.data(), sizeof(int) * m.cols.size());
+        // 16-bit column offsets when every slice's columns span < 65536 (k_spmv COL16); PCG_SPMV_COL16=0 keeps 32 bits
+        bool col16 = m.bs == 3 && m.n_slices > 0;
+        if (const char *e = getenv("PCG_SPMV_COL16")) col16 = col16 && atoi(e) != 0;
+        std::vector<int> cbase;
+        if (col16) {
+            cbase.assign((size_t)m.n_slices, 0);
+            for (int64_t sl = 0; sl < m.n_slices && col16; ++sl) {
+                const int64_t a = m.slice_ptr[sl] * m.C, b = m.slice_ptr[sl + 1] * m.C;
+                int lo = INT32_MAX, hi = 0;
+                for (int64_t k = a; k < b; ++k) { lo = std::min(lo, m.cols[k]); hi = std::max(hi, m.cols[k]); }
+                if (b > a) { cbase[sl] = lo; if (hi - lo > 65535) col16 = false; }
+            }
+        }
+        if (col16) {
+            std::vector<unsigned short> c16(m.cols.size());
+            for (int64_t sl = 0; sl < m.n_slices; ++sl)
+                for (int64_t k = m.slice_ptr[sl] * m.C, b = m.slice_ptr[sl + 1] * m.C; k < b; ++k)
+                    c16[k] = (unsigned short)(m.cols[k] - cbase[sl]);
+            d_cols16_ = (unsigned short *)alloc(sizeof(unsigned short) * std::max<size_t>(1, c16.size()));
+            d_colbase_ = (int *)alloc(sizeof(int) * cbase.size());
+            h2d(d_cols16_, c16.data(), sizeof(unsigned short) * c16.size());
+            h2d(d_colbase_, cbase.data(), sizeof(int) * cbase.size());
+        } else {
+            d_cols_ = (int *)alloc(sizeof(int) * m.cols.size());
+            h2d(d_cols_, m.cols.data(), sizeof(int) * m.cols.size());
+        }
         h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
         h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
@@ -1815,13 +1903,20 @@ public:
                                    d_flags_, d_part_spmv_, lo, hi, n_nodes_);
             return;
         }
-        if (dot)
-            hipLaunchKernelGGL((k_spmv<RPL, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
-                               d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
-        else
-            hipLaunchKernelGGL((k_spmv<RPL, false>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, d_cols_, d_vals_, x, y,
-                               d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
+        if (d_cols16_) launch_spmv_c<RPL, true>(x, y, lo, hi, dot, grid, d_cols16_);
+        else launch_spmv_c<RPL, false>(x, y, lo, hi, dot, grid, d_cols_);
     }
+    template <int RPL, bool COL16>
+    void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
+    {
+        if (dot)
+            hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
+        else
+            hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
+    }
+    int col_index_bytes() const override { return d_cols16_ ? 2 : 4; }
     void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
     {
         if (hi <= lo) { if (with_dot) cnt_spmv_ = 0; return; }
@@ -2016,13 +2111,19 @@ public:
         double2 *a = (double2 *)alloc((size_t)n2 * 16), *b = mode == 1 ? (double2 *)alloc((size_t)n2 * 16) : nullptr;
         double *out = (double *)alloc(8);
         HIP_CHECK(hipMemsetAsync(a, 0x3c, (size_t)n2 * 16, st_));          // finite non-zero doubles
-        int grid = n_cu_ * (mode == 1 ? 4 : 32);       // measured best of {4, 8, 16, 32} blocks per CU for each mode
+        int grid = n_cu_ * (mode == 0 ? 32 : 4);       // measured best of {4, 8, 16, 32} blocks per CU for modes 0 and 1
         if (const char *e = getenv("PCG_STREAM_BLOCKS_PER_CU")) grid = n_cu_ * std::max(1, atoi(e));
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         for (int k = -3; k < reps; ++k) {
             HIP_CHECK(hipEventRecord(e0, st_));
+            const int W = 28;                                              // steps per region (even; a 27-wide slice + 1)
+            const int64_t n_regions = (int64_t)(bytes / ((size_t)W * 4608));
             if (mode == 1) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(kBlock), 0, st_, a, b, n2);
+            else if (mode == 2) hipLaunchKernelGGL((k_stream_slices<0>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out, n_regions, W);
+            else if (mode == 3) hipLaunchKernelGGL((k_stream_slices<1>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out, n_regions, W);
+            else if (mode == 4) hipLaunchKernelGGL((k_stream_slices<2>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out,
+                                                   n_regions / ((int64_t)grid * kWavesPerBlock) * ((int64_t)grid * kWavesPerBlock), W);
             else hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(kBlock), 0, st_, a, out, n2);
             HIP_CHECK(hipEventRecord(e1, st_));
             HIP_CHECK(hipEventSynchronize(e1));

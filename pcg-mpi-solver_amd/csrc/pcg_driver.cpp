@@ -436,10 +436,12 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         e->C = m.C;
         e->nnzb = m.nnzb;
         e->stored_blocks = m.slice_ptr.back() * m.C;
-        // 72 B of values + one 4 B column per stored 3x3 block, x read and y written once, the slice pointers
-        e->op_bytes = 76.0 * (double)e->stored_blocks + 16.0 * (double)e->n + 8.0 * (double)(m.n_slices + 1);
         e->op_flops = 18.0 * (double)m.nnzb;
         e->be->upload_matrix(m);
+        // 72 B of values + one column (4 B, or a 2 B offset + 4 B per slice) per stored 3x3 block, x read and y written
+        // once, the slice pointers
+        const int cb = e->be->col_index_bytes();
+        e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
         e->be->set_status_block(e->d_st);
@@ -925,7 +927,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each)
 {
     return guarded("pcg_bench_hbm", [&]() -> int {
-        if (!e || bytes < 16 || reps < 1 || !ms_each || (mode != 0 && mode != 1)) return set_error("pcg_bench_hbm: bad argument");
+        if (!e || bytes < 16 || reps < 1 || !ms_each || mode < 0 || mode > 4) return set_error("pcg_bench_hbm: bad argument");
         return e->be->bench_hbm((size_t)bytes, mode, reps, ms_each);
     });
 }

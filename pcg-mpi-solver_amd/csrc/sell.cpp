@@ -50,7 +50,7 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
                         if (cols[r0 + k] == r)
                             for (int a = 0; a < 3; ++a) out.diag[(size_t)r * 3 + a] = b[a * 3 + a];
                     } else {
-                        out.cols[ci] = live ? (int32_t)r : 0;      // padding: value 0, harmless valid column
+                        out.cols[ci] = (int32_t)(live ? r : n_nodes - 1);      // padding: value 0, a valid column NEAR the slice (16-bit column offsets)
                     }
                 }
             }

@@ -273,8 +273,9 @@ class Operator:
     def bench_hbm(self, nbytes=2 << 30, mode="read", reps=20):
         """GB/s of a device stream over `nbytes`: mode "read" (read-only) or "copy" (traffic = 2 * nbytes)."""
         ms = np.zeros(reps, np.float32)
-        check(self._L.pcg_bench_hbm(self._h, int(nbytes), 1 if mode == "copy" else 0, reps, ms.ctypes.data), "pcg_bench_hbm")
-        return (2 if mode == "copy" else 1) * nbytes / (float(np.median(ms)) * 1e-3) / 1e9
+        m = {"read": 0, "copy": 1}.get(mode, mode)          # 2..4: access-pattern probes (hip_backend.hip k_stream_slices)
+        check(self._L.pcg_bench_hbm(self._h, int(nbytes), int(m), reps, ms.ctypes.data), "pcg_bench_hbm")
+        return (2 if m == 1 else 1) * nbytes / (float(np.median(ms)) * 1e-3) / 1e9
 
     def operator_info(self):
         k, a, b, c, d = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()

@@ -89,6 +89,50 @@ def test_scalar_csr_format_kernel_and_solve(gpu_lib):
     o.close()
 
 
+@pytest.mark.parametrize("rpl", [1, 2])
+def test_16_bit_block_columns_change_nothing(gpu_lib, monkeypatch, rpl):
+    """k_spmv COL16 (16-bit column offsets from the slice's base column, chosen at upload when every slice allows it)
+    against the 32-bit form: same columns, same order -> bit-identical A x, fused p.Ap and solve; 2 bytes less per
+    stored block in pcg_operator_cost.  A matrix whose first row reaches beyond 65535 block columns keeps 32 bits."""
+    import scipy.sparse as sp
+    from pcg_mi355x.operator import Operator, from_refmeshpart
+    b = Brick(21, n_types=2)
+    outs = []
+    for c16 in ("1", "0"):
+        monkeypatch.setenv("PCG_SPMV_COL16", c16)
+        P = make_parts(b)[0]
+        op = from_refmeshpart(P, rows_per_lane=rpl)
+        x = np.random.default_rng(11).standard_normal(b.n_dof)
+        y = op.apply(x)
+        fext, udi = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        xs, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), 1e-9, 5000, P["GlobData"]["GlobNDofEff"], history=True)
+        outs.append((y, xs, res.iter, np.asarray(hist), op.operator_cost()[0], op.matrix_info()["stored_blocks"]))
+        op.close()
+    (y16, x16, it16, h16, b16, nb), (y32, x32, it32, h32, b32, _) = outs
+    assert np.array_equal(y16, y32) and np.array_equal(x16, x32) and it16 == it32 and np.array_equal(h16, h32)
+    assert relerr(y16, pcg_oracle.matvec_local(make_parts(b)[0], np.random.default_rng(11).standard_normal(b.n_dof))) < 1e-13
+    assert 1.99 * nb < b32 - b16 <= 2.0 * nb
+    # an arrow matrix: node 0 coupled to the last of 70 001 nodes -> slice 0 spans > 65535 columns -> 32-bit columns kept
+    monkeypatch.setenv("PCG_SPMV_COL16", "1")
+    n = 70001
+    T = sp.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(n, n)).tolil()
+    T[0, n - 1] = T[n - 1, 0] = -0.5
+    A = sp.kron(T.tocsr(), sp.eye(3) * 1.0 + 0.1 * np.ones((3, 3))).tocsr()
+    o = Operator.from_csr(A.indptr, A.indices, A.data, block=3)
+    xa = np.random.default_rng(12).standard_normal(3 * n)
+    assert relerr(o.apply(xa), A @ xa) < 1e-14
+    assert abs(o.operator_cost()[0] - (76.0 * o.matrix_info()["stored_blocks"] + 16.0 * 3 * n)) < 8.0 * (n / 64 + 2)
+    o.close()
+    # the same matrix without the arrow: > 65535 nodes, a ragged last slice (its unused lanes must not widen the span) -> 16 bits
+    T[0, n - 1] = T[n - 1, 0] = 0.0
+    A = sp.kron(T.tocsr(), sp.eye(3) * 1.0 + 0.1 * np.ones((3, 3))).tocsr()
+    A.eliminate_zeros()
+    o = Operator.from_csr(A.indptr, A.indices, A.data, block=3)
+    assert relerr(o.apply(xa), A @ xa) < 1e-14
+    assert abs(o.operator_cost()[0] - (74.0 * o.matrix_info()["stored_blocks"] + 16.0 * 3 * n)) < 12.0 * (n / 64 + 2)
+    o.close()
+
+
 def test_vector_kernels_vs_numpy(gpu_lib):
     from pcg_mi355x.operator import from_refmeshpart
     from pcg_mi355x._lib import check
