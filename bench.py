@@ -205,7 +205,7 @@ def pmc_traffic_live(args):
                "--nodes-per-side", str(args.nodes_per_side), "--rows-per-lane", str(args.rows_per_lane)]
         subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
         db = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
-        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_spmv<1, true>%' and counter_name = ?",
+        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_spmv<1, true%' and counter_name = ?",
                           (ctr,)).fetchall()
         vals[ctr] = (float(rows[0][0]), int(rows[0][1]))
     return {"bytes": 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"][0],

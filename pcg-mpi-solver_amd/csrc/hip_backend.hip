@@ -125,6 +125,12 @@ __device__ __forceinline__ double2 ntload(const double2 *p)
     v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(p));
     return make_double2(t.x, t.y);
 }
+__device__ __forceinline__ void ntstore(double2 *p, double2 v)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(p));
+}
 __device__ __forceinline__ int2 ntload(const int2 *p)
 {
     typedef int v2 __attribute__((ext_vector_type(2)));
@@ -163,11 +169,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
     // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
     const int64_t S = slice_hi - slice_lo;
-    const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
-    const int64_t lb = xcd_aware ? (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t blocks_per_xcd = xcd_aware ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
-    const int64_t c_lo = xcd_aware ? slice_lo + (S * xcd) / 8 : slice_lo;
-    const int64_t c_hi = xcd_aware ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
+    const bool xa = (xcd_aware & 1) != 0;                    // bit 1 of the argument: non-temporal y stores
+    const int xcd = xa ? (blockIdx.x & 7) : 0;
+    const int64_t lb = xa ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t blocks_per_xcd = xa ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
+    const int64_t c_lo = xa ? slice_lo + (S * xcd) / 8 : slice_lo;
+    const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
     const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
     double dot = 0.0;
     for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
@@ -214,7 +221,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
             const int64_t row = s * C + (int64_t)lane * RPL + h;
             if (row < n_nodes) {
                 double *yp = y + 3 * row;
-                yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2];
+                if (xcd_aware & 2) {
+                    __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
+                    __builtin_nontemporal_store(acc[h][2], yp + 2);
+                } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
                 if constexpr (DOT) {
                     const uint8_t *fp = flags + 3 * row;
                     const double *xp = x + 3 * row;
@@ -1166,7 +1176,7 @@ __global__ void k_scalar_alpha(double *st, double *mirror)
 // enqueues this kernel (look-ahead), and divides the same two doubles later for its own Flag-4 test (:476-478).
 __global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, const double *__restrict__ pi,
                                                      const double *__restrict__ r, const double *__restrict__ minv,
-                                                     const double *__restrict__ st, double rho_prev, int first, int64_t n)
+                                                     const double *__restrict__ st, double rho_prev, int first, int nt, int64_t n)
 {
     const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
     const int64_t n2 = n >> 1;
@@ -1175,10 +1185,10 @@ __global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, co
     const double2 *pi2 = reinterpret_cast<const double2 *>(pi);
     const double2 *r2 = reinterpret_cast<const double2 *>(r), *m2 = reinterpret_cast<const double2 *>(minv);
     for (int64_t t = t0; t < n2; t += ts) {
-        const double2 rr = r2[t], mm = m2[t];
+        const double2 rr = (nt & 4) ? ntload(r2 + t) : r2[t], mm = (nt & 4) ? ntload(m2 + t) : m2[t];
         double2 z = make_double2(mm.x * rr.x, mm.y * rr.y);        // :447
-        if (!first) { const double2 pp = pi2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
-        po2[t] = z;
+        if (!first) { const double2 pp = (nt & 4) ? ntload(pi2 + t) : pi2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
+        if (nt & 1) ntstore(po2 + t, z); else po2[t] = z;
     }
     if ((n & 1) && t0 == 0) {
         const int64_t i = n - 1;
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_update(double *st, double *mir
                                                          double *__restrict__ rn, const double *__restrict__ xo,
                                                          double *__restrict__ xn,
                                                          const double *__restrict__ minv, const uint8_t *__restrict__ flags,
-                                                         double *__restrict__ partials, int64_t n)
+                                                         double *__restrict__ partials, int nt, int64_t n)
 {
     __shared__ double lds[5 * kWavesPerBlock];
     Up u = {0, 0, 0, 0, 0};
@@ -1240,13 +1250,15 @@ __global__ __launch_bounds__(kBlock) void k_fused_update(double *st, double *mir
         double2 *rn2 = reinterpret_cast<double2 *>(rn), *xn2 = reinterpret_cast<double2 *>(xn);
         const uchar2 *f2 = reinterpret_cast<const uchar2 *>(flags);
         for (int64_t t = t0; t < n2; t += ts) {
-            const double2 pp = p2[t], qq = q2[t], xx = x2[t], mm = m2[t];
-            double2 rr = r2[t], xo2;
+            const bool ntl = (nt & 4) != 0;
+            const double2 pp = ntl ? ntload(p2 + t) : p2[t], qq = ntl ? ntload(q2 + t) : q2[t], xx = ntl ? ntload(x2 + t) : x2[t],
+                          mm = ntl ? ntload(m2 + t) : m2[t];
+            double2 rr = ntl ? ntload(r2 + t) : r2[t], xo2;
             const uchar2 ff = f2[t];
             update_one(alpha, pp.x, qq.x, rr.x, xx.x, xo2.x, mm.x, ff.x, u);
             update_one(alpha, pp.y, qq.y, rr.y, xx.y, xo2.y, mm.y, ff.y, u);
-            rn2[t] = rr;
-            xn2[t] = xo2;
+            if (nt & 1) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
+            else { rn2[t] = rr; xn2[t] = xo2; }
         }
         if ((n & 1) && t0 == 0) {
             const int64_t i = n - 1;
@@ -1386,6 +1398,40 @@ __global__ __launch_bounds__(kBlock) void k_stream_copy(const double2 *__restric
     for (int64_t t = t0; t < n2; t += ts) b[t] = ntload(a + t);
 }
 
+__global__ __launch_bounds__(kBlock) void k_stream_copy_nt(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = t0; t < n2; t += ts) {
+        const double2 v = ntload(a + t);
+        v2 w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(b + t));
+    }
+}
+// store-flavour probes: MODE 0 = sc1, 1 = sc0 sc1, 2 = nt sc0 sc1 (development, PCG_BENCH_SPMV_CTX)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_stream_copy_sc(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = t0; t < n2; t += ts) {
+        const double2 v = ntload(a + t);
+        v4f w;
+        __builtin_memcpy(&w, &v, 16);
+        double2 *p = b + t;
+        if constexpr (MODE == 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+        else if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(w) : "memory");
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_stream_read_plain(const double2 *__restrict__ a, double *__restrict__ out, int64_t n2)
+{
+    double s = 0;
+    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = t0; t < n2; t += ts) { const double2 v = a[t]; s += v.x + v.y; }
+    if (s == 1.2345e-300) out[0] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------------
@@ -1485,6 +1531,15 @@ class HipBackend : public Backend {
     int spmv_blocks_per_cu_ = 4;
     int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
     bool bench_dot_ = false;
+    // Non-temporal accesses in the vector kernels (PCG_VEC_NT, bit mask; A/B: tools/vec_nt_ab.py re-reads it per solve).
+    // bit 0: the vectors the iteration rewrites (p in k_update_p; r', x' in k_fused_update) are stored non-temporally.  Plain
+    //        stores leave the rewritten lines dirty in the memory-side cache; they are then written out underneath the next
+    //        operator's read stream: a stand-alone SpMV whose x was just rewritten by a plain-store kernel runs 2.5-6 % slower,
+    //        with `nt` stores 0.5-1 % (sc1 / sc0 sc1 do not help; profiles/r02_spmv_launch_context.txt).  In the loop at
+    //        10 M dof: assembled 780 -> 842 it/s (SpMV 1.120 -> 1.033 ms), matrix-free 3070 -> 3110 it/s, same process.
+    // bit 2: the vector kernels' streaming loads are non-temporal too: 845 / 3184 it/s.
+    // bit 1: non-temporal y stores in k_spmv: no effect, off.  Results are bit-identical in every combination.
+    int vec_nt_ = 5;
     // PCG_EBE_MFMA=1: hex8 chunks on the matrix cores (k_ebe_mfma) instead of the v_fma kernel (k_ebe_chunk).  Off by
     // default: measured 0.25 ms vs 0.20 ms per apply at 10 M dof - neither kernel is bound by its arithmetic
     // (profiles/r01_pmc_ebe_mfma.md).
@@ -1517,6 +1572,7 @@ public:
         if (const char *e = getenv("PCG_SPMV_BLOCKS_PER_CU")) spmv_blocks_per_cu_ = std::max(1, atoi(e));
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
+        reload_tuning();
         if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_EBE_HEX")) hex_mode_ = atoi(e);
         if (const char *e = getenv("PCG_EBE_ACC")) hex_acc_ = atoi(e);
@@ -1911,10 +1967,10 @@ public:
     {
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
         else
             hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
     }
     int col_index_bytes() const override { return d_cols16_ ? 2 : 4; }
     void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
@@ -2001,6 +2057,11 @@ public:
         return true;
     }
     void set_status_slot(int slot) override { cur_slot_ = slot; }
+    void reload_tuning() override
+    {
+        vec_nt_ = 5;
+        if (const char *e = getenv("PCG_VEC_NT")) vec_nt_ = atoi(e);          // bit 0: p / r' / x' stores, bit 1: SpMV y stores, bit 2: vector loads
+    }
     void publish_status(bool copy_block) override
     {
         if (copy_block) {
@@ -2023,7 +2084,7 @@ public:
     void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
                   bool first) override
     {
-        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, n_);
+        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, vec_nt_, n_);
         HIP_CHECK(hipGetLastError());
     }
     void fused_update(double *st, const double *p, const double *q, const double *r, double *rn, const double *xo, double *xn,
@@ -2032,10 +2093,10 @@ public:
         cnt_vec_ = vec_grid(n_);
         if (with_alpha)
             hipLaunchKernelGGL((k_fused_update<true>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, mirror_of(st), p, q, r, rn, xo, xn, minv,
-                               d_flags_, d_part_, n_);
+                               d_flags_, d_part_, vec_nt_, n_);
         else
             hipLaunchKernelGGL((k_fused_update<false>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, (double *)nullptr, p, q, r, rn, xo, xn,
-                               minv, d_flags_, d_part_, n_);
+                               minv, d_flags_, d_part_, vec_nt_, n_);
         HIP_CHECK(hipGetLastError());
     }
     void reduce_update(double *red5) override
@@ -2152,17 +2213,92 @@ public:
         }
         const int grid = spmv_grid(n_slices_);
         const bool dot = bench_dot_;
-        for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y, 0, n_slices_, dot, grid); }
-        hipEvent_t a, b;
-        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-        for (int k = 0; k < reps; ++k) {
-            HIP_CHECK(hipEventRecord(a, st_));
-            if (C_ == 64) launch_spmv<1>(x, y, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y, 0, n_slices_, dot, grid);
-            HIP_CHECK(hipEventRecord(b, st_));
-            HIP_CHECK(hipEventSynchronize(b));
-            HIP_CHECK(hipEventElapsedTime(&ms_each[k], a, b));
+        // PCG_BENCH_SPMV_CTX (development, tools/spmv_state.py): what a launch finds when it is NOT repeated back to back -
+        // bit 0: x rewritten by a copy kernel right before the launch (as k_update_p does in the loop); bit 1: 1 GiB of
+        // unrelated data streamed through the caches before the launch; bit 2: no host wait between launches.
+        int ctx = 0;
+        if (const char *e = getenv("PCG_BENCH_SPMV_CTX")) ctx = atoi(e);
+        if (ctx == 8) {            // placement probe: the same x in differently placed buffers (stderr)
+            const size_t nb = sizeof(double) * (size_t)n_;
+            char *slab = (char *)alloc(nb * 2 + (64u << 20));
+            std::vector<std::pair<const char *, double *>> cand;
+            cand.push_back({"x as given", const_cast<double *>(x)});
+            for (int k = 0; k < 4; ++k) cand.push_back({"fresh hipMalloc", (double *)alloc(nb)});
+            cand.push_back({"slab + 0", (double *)slab});
+            cand.push_back({"slab + 4 KiB", (double *)(slab + 4096)});
+            cand.push_back({"slab + 64 KiB", (double *)(slab + 65536)});
+            cand.push_back({"slab + 1 MiB", (double *)(slab + (1u << 20))});
+            cand.push_back({"slab + 2 MiB rounded up", (double *)(((uintptr_t)slab + (2u << 20) - 1) / (2u << 20) * (2u << 20))});
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+            for (auto &c : cand) {
+                if (c.second != x) HIP_CHECK(hipMemcpyAsync(c.second, x, nb, hipMemcpyDeviceToDevice, st_));
+                std::vector<float> t;
+                for (int k = -3; k < 30; ++k) {
+                    HIP_CHECK(hipEventRecord(a, st_));
+                    if (C_ == 64) launch_spmv<1>(c.second, y, 0, n_slices_, dot, grid); else launch_spmv<2>(c.second, y, 0, n_slices_, dot, grid);
+                    HIP_CHECK(hipEventRecord(b, st_));
+                    HIP_CHECK(hipEventSynchronize(b));
+                    float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+                    if (k >= 0) t.push_back(ms);
+                }
+                std::sort(t.begin(), t.end());
+                fprintf(stderr, "placement %-26s x=%p (mod 2 MiB = %7zu)  y=%p vals=%p  median %.4f ms\n", c.first, (void *)c.second,
+                        (size_t)((uintptr_t)c.second % (2u << 20)), (void *)y, (void *)d_vals_, t[t.size() / 2]);
+            }
+            // and y placed in the slab
+            {
+                double *y2 = (double *)(((uintptr_t)slab + nb + (4u << 20)) / (2u << 20) * (2u << 20));
+                std::vector<float> t;
+                for (int k = -3; k < 30; ++k) {
+                    HIP_CHECK(hipEventRecord(a, st_));
+                    if (C_ == 64) launch_spmv<1>(x, y2, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y2, 0, n_slices_, dot, grid);
+                    HIP_CHECK(hipEventRecord(b, st_));
+                    HIP_CHECK(hipEventSynchronize(b));
+                    float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+                    if (k >= 0) t.push_back(ms);
+                }
+                std::sort(t.begin(), t.end());
+                fprintf(stderr, "placement y in slab (2 MiB aligned) y=%p median %.4f ms\n", (void *)y2, t[t.size() / 2]);
+            }
+            HIP_CHECK(hipEventDestroy(a)); HIP_CHECK(hipEventDestroy(b));
+            for (size_t k = 1; k <= 4; ++k) release(cand[k].second);
+            release(slab);
+            ctx = 0;
         }
-        HIP_CHECK(hipEventDestroy(a)); HIP_CHECK(hipEventDestroy(b));
+        double *x2 = (ctx & 1) ? (double *)alloc(sizeof(double) * (size_t)n_) : nullptr;
+        const int64_t fl2 = (int64_t)(1 << 30) / 16;
+        double2 *fl = (ctx & 2) ? (double2 *)alloc((size_t)fl2 * 16) : nullptr;
+        if (fl) HIP_CHECK(hipMemsetAsync(fl, 0x3c, (size_t)fl2 * 16, st_));
+        auto pre = [&]() {
+            const double2 *xa = reinterpret_cast<const double2 *>(x);
+            double2 *xb = reinterpret_cast<double2 *>(x2);
+            if (x2 && (ctx & 64)) hipLaunchKernelGGL((k_stream_copy_sc<0>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
+            else if (x2 && (ctx & 128)) hipLaunchKernelGGL((k_stream_copy_sc<1>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
+            else if (x2 && (ctx & 256)) hipLaunchKernelGGL((k_stream_copy_sc<2>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
+            else if (x2 && (ctx & 16)) hipLaunchKernelGGL(k_stream_copy_nt, dim3(n_cu_ * 4), dim3(kBlock), 0, st_, reinterpret_cast<const double2 *>(x),
+                                                     reinterpret_cast<double2 *>(x2), n_ / 2);
+            else if (x2) hipLaunchKernelGGL(k_stream_copy, dim3(n_cu_ * 4), dim3(kBlock), 0, st_, reinterpret_cast<const double2 *>(x),
+                                            reinterpret_cast<double2 *>(x2), n_ / 2);
+            if (fl && (ctx & 32)) hipLaunchKernelGGL(k_stream_read_plain, dim3(n_cu_ * 32), dim3(kBlock), 0, st_, (const double2 *)fl, y, fl2);
+            else if (fl) hipLaunchKernelGGL(k_stream_read, dim3(n_cu_ * 32), dim3(kBlock), 0, st_, (const double2 *)fl, y, fl2);
+        };
+        const double *xs = x2 ? x2 : x;
+        for (int k = 0; k < warmup; ++k) { pre(); if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid); }
+        std::vector<hipEvent_t> ev((size_t)2 * reps);
+        for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
+        for (int k = 0; k < reps; ++k) {
+            pre();
+            HIP_CHECK(hipEventRecord(ev[2 * k], st_));
+            if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid);
+            HIP_CHECK(hipEventRecord(ev[2 * k + 1], st_));
+            if (!(ctx & 4)) HIP_CHECK(hipEventSynchronize(ev[2 * k + 1]));
+        }
+        HIP_CHECK(hipStreamSynchronize(st_));
+        for (int k = 0; k < reps; ++k) HIP_CHECK(hipEventElapsedTime(&ms_each[k], ev[2 * k], ev[2 * k + 1]));
+        for (auto &e : ev) HIP_CHECK(hipEventDestroy(e));
+        if (x2) release(x2);
+        if (fl) release(fl);
         return 0;
     }
 };

@@ -794,6 +794,7 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         const double t0 = now_s();
         ensure_solver_buffers(e);
         Backend &be = *e->be;
+        be.reload_tuning();
         auto &s = e->s;
         s = pcg_engine::Solve();
         s.active = true;

@@ -158,6 +158,7 @@ public:
     // false when some pattern type runs outside the chunked form (its colour launches ADD into y, chunk stores assign):
     // the two phases may then not be interleaved with the interface exchange (pcg_driver.cpp apply())
     virtual bool ebe_can_split() const = 0;
+    virtual void reload_tuning() {}                        // re-read the environment switches a solve may be A/B-tested with
     virtual int col_index_bytes() const { return 4; }      // bytes per stored block column after upload_matrix (2: 16-bit offsets)
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;

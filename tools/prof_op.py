@@ -4,6 +4,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
 import numpy as np
+if os.environ.get("PROF_IMPORT_TORCH"):     # does a process that also runs torch's HIP context time the same kernel differently?
+    import torch
+    torch.cuda.init()
+    _t = torch.zeros(1 << 20, device="cuda")
+    print("torch", torch.__version__, "context up")
 if os.environ.get("PCG_LIB"):               # A/B against another build of the engine (development only)
     from pcg_mi355x import _lib
     _lib.use_library(os.environ["PCG_LIB"])
