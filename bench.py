@@ -474,7 +474,7 @@ def main():
         out["config"]["format"] = f"SELL-{info['slice_rows']} over 3x3 blocks, {8 * col_bytes}-bit block columns"
         out["config"]["spmv_achieved_GBps"] = achieved
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_spmv<1,true> (SELL-BSR3 SpMV + fused p.Ap)" + (" - this rank's part" if world > 1 else ""),
+            "bound": "hbm", "kernel": f"k_spmv<{info['slice_rows'] // 64}, true, {'true' if col_bytes == 2 else 'false'}> (SELL-BSR3 SpMV + fused p.Ap)" + (" - this rank's part" if world > 1 else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_launch": sell_bytes,
             "bytes_definition": f"stored operator: {72 + col_bytes} B per stored 3x3 block (72 B values + one {8 * col_bytes}-bit column"
