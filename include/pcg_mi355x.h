@@ -203,6 +203,40 @@ int pcg_solve(pcg_engine *e, const double *b, const double *x0, const double *in
               int64_t max_iter, int64_t glob_n_eff, double *x_out, double *hist, int64_t hist_cap,
               pcg_result *res);
 int pcg_set_profiling(pcg_engine *e, int32_t on);
+int pcg_engine_device(const pcg_engine *e);      /* the device id the engine was created on */
+
+/* ---- device group: ONE process drives several GPUs (SURVEY 8b pcg_group_*) ------------------------------------------
+ * The reference runs one MPI rank per part (mpiexec -np N, pcg_solver.py:91); the product's default launch is the same,
+ * one process per GPU.  A group is the alternative for a host program that cannot be launched N times (a notebook, an
+ * embedding application): member k of the group is part k on device dev_ids[k], and every pcg_group_* call below is the
+ * per-engine call of the same name made for ALL members at once - the library runs one persistent host thread per
+ * member (bound to the member's device), because the calls are collective: the interface exchange and the all-reduces
+ * of one member complete only when its neighbours have issued theirs.  Communication is the native communicator above
+ * (one pcg_comm per member, RCCL over xGMI, unique id generated in-process), so a group solve is the same engine code
+ * path as N processes; results are bit-identical to the N-process run.
+ *   usage: pcg_group_create -> per member: pcg_create*(dev_ids[k], ..), pcg_set_masks, pcg_set_halo (peer id == member
+ *   index), pcg_group_attach -> pcg_group_update_bc / _build_jacobi / _solve ... -> pcg_destroy(engines) -> pcg_group_destroy.
+ * Array arguments hold one pointer per member (host vectors of THAT member's local length); where a per-member pointer
+ * may be NULL for the single-engine call it may be NULL here, and a NULL array means "NULL for every member".
+ * On failure the return value is < 0 and pcg_last_error() names the failing member(s).  A member that fails inside a
+ * collective cannot be recovered from any more than a crashed rank can (its peers wait); create/attach errors are. */
+typedef struct pcg_group pcg_group;
+int pcg_group_create(int32_t n_dev, const int32_t *dev_ids, pcg_group **out);
+void pcg_group_destroy(pcg_group *g);            /* after the engines attached to it have been destroyed or detached */
+int pcg_group_size(const pcg_group *g);
+int pcg_group_device(const pcg_group *g, int32_t member);
+pcg_comm *pcg_group_comm(pcg_group *g, int32_t member);       /* borrowed: owned by the group */
+int pcg_group_attach(pcg_group *g, int32_t member, pcg_engine *e /* created on dev_ids[member]; NULL detaches */);
+int pcg_group_apply(pcg_group *g, const double *const *x, double *const *y);
+int pcg_group_diag(pcg_group *g, double *const *d);
+int pcg_group_build_jacobi(pcg_group *g, double *const *inv_diag_out);
+int pcg_group_update_bc(pcg_group *g, const double *const *ref_load, const double *const *ud, double delta,
+                        double *const *fext_out, double *const *udi_out);
+int pcg_group_dot_w(pcg_group *g, const double *const *a, const double *const *b, double *out /* the global sum */);
+int pcg_group_solve(pcg_group *g, const double *const *b, const double *const *x0, const double *const *inv_diag,
+                    double tol, int64_t max_iter, int64_t glob_n_eff, double *const *x_out, double *const *hist,
+                    int64_t hist_cap, pcg_result *res /* n_dev results, may be NULL */);
+int pcg_group_set_timing(pcg_group *g, int32_t on);           /* pcg_comm_set_timing on every member */
 
 /* ---- measurement / unit-test entry points --------------------------------------------------- */
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */

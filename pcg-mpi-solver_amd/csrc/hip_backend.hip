@@ -1612,6 +1612,8 @@ public:
         if (st_) (void)hipStreamDestroy(st_);
     }
     const char *name() const override { return "hip-gfx950"; }
+    int device() const override { return dev_; }
+    void bind_thread() override { HIP_CHECK(hipSetDevice(dev_)); }
     void *stream() override { return (void *)st_; }
     void *alloc(size_t bytes) override
     {

@@ -405,6 +405,20 @@ int guarded(const char *where, F f)
     }
 }
 
+// Entry points that take an engine: the engine's device becomes the calling thread's current device first, so one
+// process may hold engines on several GPUs (pcg_group_* runs one host thread per member).
+template <class F>
+int guarded(const char *where, pcg_engine *e, F f)
+{
+    try {
+        if (!e || !e->be) return set_error(std::string(where) + ": null engine");
+        e->be->bind_thread();
+        return f();
+    } catch (const std::exception &ex) {
+        return set_error(std::string(where) + ": " + ex.what());
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -570,7 +584,7 @@ void pcg_destroy(pcg_engine *e) { delete e; }
 
 int pcg_set_masks(pcg_engine *e, const uint8_t *flags)
 {
-    return guarded("pcg_set_masks", [&]() -> int {
+    return guarded("pcg_set_masks", e, [&]() -> int {
         if (!e || !flags) return set_error("pcg_set_masks: null");
         e->be->upload_masks(flags, e->n);
         e->has_masks = true;
@@ -580,7 +594,7 @@ int pcg_set_masks(pcg_engine *e, const uint8_t *flags)
 
 int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const int64_t *send_ptr, const int32_t *send_idx)
 {
-    return guarded("pcg_set_halo", [&]() -> int {
+    return guarded("pcg_set_halo", e, [&]() -> int {
         if (!e || n_peers < 0) return set_error("pcg_set_halo: bad argument");
         HaloHost &h = e->halo;
         h = HaloHost();
@@ -714,7 +728,7 @@ int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out)
 
 int pcg_apply(pcg_engine *e, const double *x, double *y)
 {
-    return guarded("pcg_apply", [&]() -> int {
+    return guarded("pcg_apply", e, [&]() -> int {
         double *dx = e->scratch(0), *dy = e->scratch(1);
         e->be->h2d(dx, x, sizeof(double) * e->n);
         e->apply(dx, dy, false);
@@ -725,7 +739,7 @@ int pcg_apply(pcg_engine *e, const double *x, double *y)
 
 int pcg_diag(pcg_engine *e, double *d)
 {
-    return guarded("pcg_diag", [&]() -> int {
+    return guarded("pcg_diag", e, [&]() -> int {
         double *dd = e->scratch(0);
         e->be->copy_diag(dd);                   // :282-287 element diagonals, assembled
         e->halo_sum(dd);                        // :303-334
@@ -736,7 +750,7 @@ int pcg_diag(pcg_engine *e, double *d)
 
 int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out)
 {
-    return guarded("pcg_build_jacobi", [&]() -> int {
+    return guarded("pcg_build_jacobi", e, [&]() -> int {
         double *dd = e->scratch(0);
         e->be->copy_diag(dd);
         e->halo_sum(dd);
@@ -749,7 +763,7 @@ int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out)
 
 int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, double delta, double *fext_out, double *udi_out)
 {
-    return guarded("pcg_update_bc", [&]() -> int {
+    return guarded("pcg_update_bc", e, [&]() -> int {
         double *dud = e->scratch(0), *dudi = e->scratch(1), *dfdi = e->scratch(2), *df = e->scratch(3);
         e->be->h2d(dud, ud, sizeof(double) * e->n);
         e->be->h2d(df, ref_load, sizeof(double) * e->n);
@@ -764,7 +778,7 @@ int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, doubl
 
 int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out)
 {
-    return guarded("pcg_dot_w", [&]() -> int {
+    return guarded("pcg_dot_w", e, [&]() -> int {
         double *da = e->scratch(0), *db = e->scratch(1);
         e->be->h2d(da, a, sizeof(double) * e->n);
         e->be->h2d(db, b, sizeof(double) * e->n);
@@ -779,16 +793,19 @@ int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out)
 
 int pcg_set_profiling(pcg_engine *e, int32_t on)
 {
-    if (!e) return set_error("null");
-    e->profiling = on != 0;
-    e->be->set_profiling(on != 0);
-    return 0;
+    return guarded("pcg_set_profiling", e, [&]() -> int {
+        e->profiling = on != 0;
+        e->be->set_profiling(on != 0);
+        return 0;
+    });
 }
+
+int pcg_engine_device(const pcg_engine *e) { return e && e->be ? e->be->device() : -1; }
 
 int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const double *inv_diag, double tol,
                     int64_t max_iter, int64_t glob_n_eff)
 {
-    return guarded("pcg_solve_begin", [&]() -> int {
+    return guarded("pcg_solve_begin", e, [&]() -> int {
         if (!e || !b) return set_error("pcg_solve_begin: null");
         if (max_iter < 1) return set_error("pcg_solve_begin: max_iter must be >= 1");
         const double t0 = now_s();
@@ -849,7 +866,7 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
 
 int pcg_solve_run(pcg_engine *e, int64_t n_iters, double *hist, int64_t hist_cap, pcg_result *res)
 {
-    return guarded("pcg_solve_run", [&]() -> int {
+    return guarded("pcg_solve_run", e, [&]() -> int {
         if (!e || !e->s.active) return set_error("pcg_solve_run: no solve in progress");
         const double t0 = now_s();
         auto &s = e->s;
@@ -869,7 +886,7 @@ int pcg_solve_run(pcg_engine *e, int64_t n_iters, double *hist, int64_t hist_cap
 
 int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res)
 {
-    return guarded("pcg_solve_end", [&]() -> int {
+    return guarded("pcg_solve_end", e, [&]() -> int {
         if (!e || !e->s.active) return set_error("pcg_solve_end: no solve in progress");
         const double t0 = now_s();
         auto &s = e->s;
@@ -915,7 +932,7 @@ int pcg_solve(pcg_engine *e, const double *b, const double *x0, const double *in
 
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
 {
-    return guarded("pcg_bench_spmv", [&]() -> int {
+    return guarded("pcg_bench_spmv", e, [&]() -> int {
         double *dx = e->scratch(0), *dy = e->scratch(1);
         std::vector<double> hx((size_t)e->n);
         uint64_t sd = 0x9E3779B97F4A7C15ull;                 // random (not zero-filled) operand: DVFS-honest
@@ -927,7 +944,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
 
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each)
 {
-    return guarded("pcg_bench_hbm", [&]() -> int {
+    return guarded("pcg_bench_hbm", e, [&]() -> int {
         if (!e || bytes < 16 || reps < 1 || !ms_each || mode < 0 || mode > 4) return set_error("pcg_bench_hbm: bad argument");
         return e->be->bench_hbm((size_t)bytes, mode, reps, ms_each);
     });
@@ -965,7 +982,7 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
 // ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first)
 {
-    return guarded("pcg_k_update_p", [&]() -> int {
+    return guarded("pcg_k_update_p", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
         double *dpo = e->scratch(3);
@@ -982,7 +999,7 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
 int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r, const double *x_old,
                        double *x_new, const double *inv_diag, double *sums5)
 {
-    return guarded("pcg_k_fused_update", [&]() -> int {
+    return guarded("pcg_k_fused_update", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         ensure_solver_buffers(e);
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
@@ -1004,7 +1021,7 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
 
 int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, const double *inv_diag, double *sums3)
 {
-    return guarded("pcg_k_residual", [&]() -> int {
+    return guarded("pcg_k_residual", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *db = e->scratch(0), *da = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         e->be->h2d(db, b, bytes); e->be->h2d(da, ax, bytes); e->be->h2d(dm, inv_diag, bytes);
@@ -1019,7 +1036,7 @@ int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, 
 
 int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
 {
-    return guarded("pcg_k_spmv_local", [&]() -> int {
+    return guarded("pcg_k_spmv_local", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dx = e->scratch(0), *dy = e->scratch(1);
         e->be->h2d(dx, x, bytes);

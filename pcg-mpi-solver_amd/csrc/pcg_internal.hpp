@@ -138,6 +138,10 @@ class Backend {
 public:
     virtual ~Backend() {}
     virtual const char *name() const = 0;
+    virtual int device() const { return 0; }
+    // make the back end's device the calling host thread's current device: every C-ABI entry point does this first, so
+    // one process may hold engines on several GPUs (pcg_group_*: one host thread per member) - a no-op once bound
+    virtual void bind_thread() {}
     virtual void *stream() = 0;
     virtual void *alloc(size_t bytes) = 0;
     virtual void release(void *p) = 0;

@@ -235,11 +235,13 @@ public:
     }
     void set_timing(bool on) override
     {
+        HIP_CHECK(hipSetDevice(dev_));               // the timing events belong to this communicator's device
         if (on) { t_halo_.init(); t_red_.init(); }
         timing_ = on;
     }
     CommStats stats() override
     {
+        HIP_CHECK(hipSetDevice(dev_));
         if (!t_halo_.a.empty()) { t_halo_.drain(); t_red_.drain(); }
         st_.halo_wait_ms = t_halo_.ms; st_.n_halo_timed = t_halo_.n;
         st_.allreduce_ms = t_red_.ms; st_.n_allreduce_timed = t_red_.n;

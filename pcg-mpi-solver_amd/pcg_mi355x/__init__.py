@@ -10,10 +10,11 @@ from . import _lib
 from ._lib import PcgError
 from .operator import Operator, from_refmeshpart, assemble_bsr3
 from . import io  # noqa: F401  (partition / result files; the CLI stages run / prepare / mdf are imported on demand)
+from .group import DeviceGroup, GroupSolver
 from .solver import (configure, get_operator, solve, PCG, update_bc, updateBC, update_preconditioner,
                      updatePreconditioner, calc_matvec_prod, calcMatVecProd, calc_mpfint, calcMPFint,
                      solve_system, SolveInfo)
 
-__all__ = ["PcgError", "Operator", "from_refmeshpart", "assemble_bsr3", "configure", "get_operator", "solve", "PCG",
+__all__ = ["PcgError", "Operator", "from_refmeshpart", "assemble_bsr3", "DeviceGroup", "GroupSolver", "configure", "get_operator", "solve", "PCG",
            "update_bc", "updateBC", "update_preconditioner", "updatePreconditioner", "calc_matvec_prod",
            "calcMatVecProd", "calc_mpfint", "calcMPFint", "solve_system", "SolveInfo"]

@@ -94,6 +94,20 @@ _SIGS = {
     "pcg_solve_end": (C.c_int, [_P, _P, C.POINTER(Result)]),
     "pcg_solve": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(Result)]),
     "pcg_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "pcg_engine_device": (C.c_int, [_P]),
+    "pcg_group_create": (C.c_int, [C.c_int32, _P, C.POINTER(_P)]),
+    "pcg_group_destroy": (None, [_P]),
+    "pcg_group_size": (C.c_int, [_P]),
+    "pcg_group_device": (C.c_int, [_P, C.c_int32]),
+    "pcg_group_comm": (_P, [_P, C.c_int32]),
+    "pcg_group_attach": (C.c_int, [_P, C.c_int32, _P]),
+    "pcg_group_apply": (C.c_int, [_P, _P, _P]),
+    "pcg_group_diag": (C.c_int, [_P, _P]),
+    "pcg_group_build_jacobi": (C.c_int, [_P, _P]),
+    "pcg_group_update_bc": (C.c_int, [_P, _P, _P, C.c_double, _P, _P]),
+    "pcg_group_dot_w": (C.c_int, [_P, _P, _P, C.POINTER(C.c_double)]),
+    "pcg_group_solve": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P]),
+    "pcg_group_set_timing": (C.c_int, [_P, C.c_int32]),
     "pcg_bench_spmv": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "pcg_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "pcg_operator_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

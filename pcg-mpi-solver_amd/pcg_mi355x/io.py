@@ -121,6 +121,18 @@ def write_result_vector(file_name, local_values, comm=None):
         dist.barrier(group=comm.group)
 
 
+def write_result_vector_parts(file_name, values_by_part):
+    """The same two files as write_result_vector() written by N ranks, from ONE process that holds every part (device
+    group, pcg_mi355x.group): segment k at part k's byte offset, one metadata row per part."""
+    data = [np.ascontiguousarray(v) for v in values_by_part]
+    meta = np.array([[d.nbytes, len(d), d.dtype] for d in data], dtype=object)
+    offsets = np.cumsum(np.hstack([[0], meta[:-1, 0]])).astype(np.int64)
+    np.save(file_name + "_metadat", np.array({"NfData": meta[:, 1], "DTypeData": meta[:, 2], "OffsetData": offsets}, dtype=object))
+    with open(file_name + ".mpidat", "wb") as f:
+        for d in data:
+            f.write(d.tobytes())
+
+
 def read_result_vector(file_name):
     """readMPIBinFile (file_operations.py:516-531): the concatenation of all ranks' segments."""
     metadat = np.load(file_name + "_metadat.npy", allow_pickle=True).item()
@@ -153,3 +165,24 @@ class ResultExporter:
             self.times.append(time_value)
             np.save(os.path.join(self.path, "Time_T"), self.times)
         self.count += 1                                                                             # :894
+
+
+class GroupResultExporter:
+    """ResultExporter for a device group: one process writes what the N ranks of the reference write (same files, same
+    per-part segments and metadata rows)."""
+
+    def __init__(self, parts, res_vec_path):
+        self.parts, self.path = parts, res_vec_path
+        os.makedirs(res_vec_path, exist_ok=True)
+        self.dof_masks = [np.asarray(P["DofWeightVector"]).astype(bool) for P in parts]             # :196
+        node_masks = [np.asarray(P["NodeWeightVector"]).astype(bool) for P in parts]                # :197
+        write_result_vector_parts(os.path.join(res_vec_path, "Dof"), [P["DofVector"][m] for P, m in zip(parts, self.dof_masks)])
+        write_result_vector_parts(os.path.join(res_vec_path, "NodeId"), [P["NodeIdVector"][m] for P, m in zip(parts, node_masks)])
+        self.count = 0
+        self.times = []
+
+    def export(self, time_value):
+        write_result_vector_parts(os.path.join(self.path, f"U_{self.count}"), [P["Un"][m] for P, m in zip(self.parts, self.dof_masks)])
+        self.times.append(time_value)
+        np.save(os.path.join(self.path, "Time_T"), self.times)
+        self.count += 1

@@ -10,6 +10,7 @@ replaces `mpiexec -np N python3 src/solver/pcg_solver.py <Run> <SpeedTestFlag>`.
     python -m pcg_mi355x.run --partition-prefix <PyDataPath_Part> --n-parts N \\
            --settings __pycache__/GlobSettings.zpkl --results <ScratchPath>/Results_Run1 [--operator ebe]
     python -m pcg_mi355x.run --mdf <Scratch>/ModelData/MDF/ ...     (no partition files: each rank partitions in memory)
+    python -m pcg_mi355x.run --group --n-parts N ...                (ONE process drives the N GPUs: device group)
 """
 from __future__ import annotations
 
@@ -22,7 +23,7 @@ import numpy as np
 from . import solver
 from .io import importz, read_partition, ResultExporter
 
-__all__ = ["init_glob_data", "apply_settings", "run_load_steps", "main"]
+__all__ = ["init_glob_data", "apply_settings", "run_load_steps", "run_load_steps_group", "main"]
 
 
 def init_glob_data():
@@ -80,6 +81,88 @@ def run_load_steps(part, res_vec_path=None, comm=None):
     return gd["TimeList_Flag"], gd["TimeList_RelRes"], gd["TimeList_Iter"]
 
 
+def run_load_steps_group(parts, res_vec_path=None, devices=None, operator="sell"):
+    """pcg_solver.py:996-1008 for ALL parts of the model in ONE process (device group, pcg_mi355x.group: member k = part k
+    on devices[k]); same per-step calls, same result files as N ranks.  -> (Flag, RelRes, Iter per step, GroupSolver)."""
+    from .group import GroupSolver
+    from .io import GroupResultExporter
+    parts = sorted(parts, key=lambda p: int(p["Id"]))
+    gd = parts[0]["GlobData"]
+    n_steps = int(gd.get("RefMaxTimeStepCount", len(gd["TimeStepDelta"])))
+    for P in parts:
+        g = P["GlobData"]
+        P["Un"] = np.zeros(P["NDOF"])                                                                  # :996
+        P["DofWeightVector_Eff"] = np.asarray(P["DofWeightVector"])[np.asarray(P["LocDofEff"], np.int64)]   # :997
+        for k in ("TimeList_Flag", "TimeList_RelRes", "TimeList_Iter"):                               # :162-165
+            g[k] = np.zeros(n_steps)
+        g["TimeStepCount"] = 0
+    dt = gd.get("dt", 1.0)
+    time_list = [i * dt for i in range(n_steps)]
+    key_frm = int(gd.get("ExportKeyFrm", 0) or 0)
+    frames = np.array(gd.get("ExportFrms", []), dtype=int)
+    frames = frames[0] - 1 if len(frames) > 0 else frames
+    gs = GroupSolver(parts, devices=devices, operator=operator, timing=True)   # the reference always keeps its calc / comm split
+    exporter = None
+    if gd.get("ExportFlag") and res_vec_path and "U" in str(gd.get("ExportVars", "U")):
+        exporter = GroupResultExporter(parts, res_vec_path)
+        exporter.export(time_list[0])
+    for step in range(1, n_steps):                                                                    # :1002
+        for P in parts:
+            P["GlobData"]["TimeStepCount"] = step
+        gs.updateBC()                                                                                 # :1004
+        gs.updatePreconditioner()                                                                     # :1005
+        gs.PCG()                                                                                      # :1006
+        if exporter is not None and ((key_frm > 0 and step % key_frm == 0) or (step in np.atleast_1d(frames))):
+            exporter.export(time_list[step])
+    return gd["TimeList_Flag"], gd["TimeList_RelRes"], gd["TimeList_Iter"], gs
+
+
+def _main_group(args, n_parts):
+    """--group: this ONE process drives n_parts GPUs (member k on device k modulo the visible devices)."""
+    from . import _lib
+    t0 = time.time()
+    gds = [init_glob_data() for _ in range(n_parts)]
+    if args.mdf is not None:
+        from . import mdf as mdf_mod
+        from .partition import partition_model, geometric_partition
+        model = mdf_mod.read_mdf(args.mdf)
+        try:
+            ele_part = mdf_mod.read_mesh_part(args.mdf, n_parts)
+        except FileNotFoundError:
+            ele_part = geometric_partition(model, n_parts)
+        parts = partition_model(model, ele_part, device=0)
+        for P, gd in zip(parts, gds):
+            gd.update(P["GlobData"])
+            P["GlobData"] = gd
+        del model
+    else:
+        parts = [read_partition(args.partition_prefix, n_parts, k, gds[k]) for k in range(n_parts)]
+    settings = importz(args.settings) if args.settings else {
+        "TimeHistoryParam": {"ExportFlag": True, "ExportFrmRate": 1, "ExportFrms": [], "PlotFlag": False,
+                             "TimeStepDelta": [0, 1], "ExportVars": "U"},
+        "SolverParam": {"Tol": args.tol, "MaxIter": args.max_iter}}
+    for gd in gds:
+        apply_settings(gd, settings, args.speed_test)
+        gd["MP_TimeRecData"]["dT_FileRead"] += time.time() - t0
+    if os.path.exists(args.results) and os.listdir(args.results):
+        from datetime import datetime
+        os.rename(args.results.rstrip(os.sep), args.results.rstrip(os.sep) + "_" + datetime.now().strftime("%d%m%Y_%H%M%S"))
+    have = max(1, _lib.lib().pcg_device_count())
+    t_start = time.time()
+    flag, relres, it, gs = run_load_steps_group(parts, os.path.join(args.results, "ResVecData") + os.sep,
+                                                [k % have for k in range(n_parts)], args.operator)
+    total = time.time() - t_start
+    gs.close()
+    os.makedirs(os.path.join(args.results, "PlotData"), exist_ok=True)
+    recs = [gd["MP_TimeRecData"] for gd in gds]                       # rank 0 reports the mean over ranks (file_operations.py:101-109)
+    calc, wait = float(np.mean([r["dT_Calc"] for r in recs])), float(np.mean([r["dT_CommWait"] for r in recs]))
+    np.savez_compressed(os.path.join(args.results, "PlotData", "TimeData"), Flag=flag, RelRes=relres, Iter=it,
+                        FileReadTime=recs[0]["dT_FileRead"], CalcTime=calc, CommWaitTime=wait, TotalTime=total)
+    print(f">file read time:     {recs[0]['dT_FileRead']:.1f} sec\n>calculation time:   {calc:.1f} sec\n"
+          f">communication time: {wait:.1f} sec\n>total runtime:      {total:.1f} sec\n"
+          f">flag {flag[1:]}, iterations {it[1:]}, relres {relres[1:]}")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--partition-prefix", default=None, help="PyDataPath_Part: files <prefix><N>_<id>.mpidat")
@@ -95,7 +178,15 @@ def main(argv=None):
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N > 1: native = RCCL calls issued by the engine (default); torch = torch.distributed callbacks")
     ap.add_argument("--speed-test", action="store_true")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process drives all --n-parts GPUs (device group, C ABI pcg_group_*) instead of one process per GPU")
     args = ap.parse_args(argv)
+    if args.group:
+        if (args.partition_prefix is None) == (args.mdf is None):
+            raise SystemExit("give exactly one of --partition-prefix / --mdf")
+        if not args.n_parts or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--group: one process, give --n-parts")
+        return _main_group(args, args.n_parts)
 
     import torch
     import torch.distributed as dist

@@ -25,7 +25,8 @@ def build_hostops():
     """Compile the CPU test double (tests/hostops) + the product's back-end-agnostic C++ sources."""
     import subprocess
     csrc = os.path.join(ROOT, "pcg-mpi-solver_amd", "csrc")
-    srcs = [HOSTOPS_SRC] + [os.path.join(csrc, f) for f in ("pcg_driver.cpp", "assemble.cpp", "sell.cpp", "ebe.cpp")]
+    srcs = [HOSTOPS_SRC, os.path.join(os.path.dirname(HOSTOPS_SRC), "local_comm.cpp")] + \
+           [os.path.join(csrc, f) for f in ("pcg_driver.cpp", "group.cpp", "assemble.cpp", "sell.cpp", "ebe.cpp")]
     deps = srcs + [os.path.join(csrc, "pcg_internal.hpp"), os.path.join(ROOT, "include", "pcg_mi355x.h")]
     if os.path.exists(HOSTOPS_LIB) and all(os.path.getmtime(HOSTOPS_LIB) >= os.path.getmtime(d) for d in deps):
         return HOSTOPS_LIB

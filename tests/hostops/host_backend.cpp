@@ -282,9 +282,8 @@ public:
 std::unique_ptr<Backend> make_backend(int) { return std::unique_ptr<Backend>(new HostBackend()); }
 int backend_device_count() { return 0; }
 const char *backend_static_name() { return "hostops-test"; }
-// the test double has no native communicator: the CPU suite drives the callback seam (pcg_set_comm) with gloo
-std::unique_ptr<Comm> make_rccl_comm(int, int, int, const void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
-int rccl_unique_ids(void *) { throw std::runtime_error("the CPU test double has no RCCL communicator"); }
+// make_rccl_comm / rccl_unique_ids of the test double: tests/hostops/local_comm.cpp (in-process mailboxes; there is no RCCL
+// on the CPU).  The gloo tests drive the callback seam (pcg_set_comm) instead.
 int64_t part_interface(int, int64_t, int64_t, const int64_t *, const int32_t *, const int32_t *, int64_t, int64_t *)
 {
     throw std::runtime_error("the CPU test double has no device-side partition set-up");

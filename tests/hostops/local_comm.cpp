@@ -1,0 +1,156 @@
+// TEST DOUBLE - in-process stand-in for the engine's native communicator (csrc/rccl_comm.hip) on the CPU test double.
+//
+// Compiled ONLY into tests/hostops/_build/libpcg_hostops.so.  It gives the `-m "not gpu"` suite what tests/fakenccl gives
+// the GPU suite: several parts in ONE process (one host thread per part) talking through pcg::Comm - the branch of
+// pcg_driver.cpp that the product takes with RCCL (comm->halo_begin / halo_end / allreduce, no callbacks) - and with it the
+// device-group API (csrc/group.cpp, pcg_group_*).  Semantics follow the reference's mpi4py calls:
+//   Isend / Recv / Waitall per neighbour (pcg_solver.py:318-328): one mailbox per (source, destination) pair, FIFO;
+//   MPI_SUM allreduce (:622-628): every rank deposits, all ranks add the deposits in rank order (same bits everywhere).
+// "Device" memory of the test double is host memory and its kernels run at enqueue time, so everything here is synchronous.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pcg_internal.hpp"
+
+namespace pcg {
+namespace {
+
+constexpr int kIdBytes = 256;
+constexpr auto kTimeout = std::chrono::seconds(120);      // a lost peer fails the test instead of hanging it
+
+struct World {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<std::vector<double>>> box;     // (src, dst) -> messages in flight
+    std::vector<std::vector<double>> dep;                                   // all-reduce deposits by rank
+    int arrived = 0, left = 0;
+    int64_t gen = 0;
+    int attached = 0;
+};
+
+std::mutex g_reg_m;
+std::map<std::string, std::shared_ptr<World>> g_reg;
+std::atomic<uint64_t> g_next_id{1};
+
+class LocalComm : public Comm {
+    std::shared_ptr<World> w_;
+    std::string key_;
+    int rank_, size_;
+    double *recv_ = nullptr;
+    const HaloHost *halo_ = nullptr;
+    CommStats st_;
+
+public:
+    LocalComm(int rank, int nranks, const void *ids) : rank_(rank), size_(nranks)
+    {
+        if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("local comm: bad rank / size");
+        key_.assign((const char *)ids, kIdBytes);
+        std::lock_guard<std::mutex> lk(g_reg_m);
+        auto &slot = g_reg[key_];
+        if (!slot) {
+            slot = std::make_shared<World>();
+            slot->n = nranks;
+            slot->dep.resize(nranks);
+        }
+        if (slot->n != nranks) throw std::runtime_error("local comm: ranks disagree on the world size");
+        slot->attached++;
+        w_ = slot;
+    }
+    ~LocalComm() override
+    {
+        std::lock_guard<std::mutex> lk(g_reg_m);
+        if (--w_->attached == 0) g_reg.erase(key_);
+    }
+    int rank() const override { return rank_; }
+    int size() const override { return size_; }
+
+    void halo_begin(double *send, double *recv, const HaloHost &h, void *) override        // :318-326
+    {
+        std::lock_guard<std::mutex> lk(w_->m);
+        for (int j = 0; j < h.n_peers; ++j) {
+            const int64_t off = h.send_ptr[j], cnt = h.send_ptr[j + 1] - off;
+            if (cnt <= 0) continue;
+            const int peer = h.peer_ids[j];
+            if (peer < 0 || peer >= size_ || peer == rank_)
+                throw std::runtime_error("local comm: neighbour part id is not a peer rank (one part per rank, pcg_solver.py:91)");
+            w_->box[{rank_, peer}].emplace_back(send + off, send + off + cnt);
+        }
+        w_->cv.notify_all();
+        recv_ = recv;
+        halo_ = &h;
+        st_.n_halo++;
+    }
+    void halo_end(void *) override                                                          // :328 Waitall
+    {
+        if (!halo_) throw std::runtime_error("local comm: halo_end without halo_begin");
+        const HaloHost &h = *halo_;
+        std::unique_lock<std::mutex> lk(w_->m);
+        for (int j = 0; j < h.n_peers; ++j) {
+            const int64_t off = h.send_ptr[j], cnt = h.send_ptr[j + 1] - off;
+            if (cnt <= 0) continue;
+            auto &q = w_->box[{h.peer_ids[j], rank_}];
+            if (!w_->cv.wait_for(lk, kTimeout, [&] { return !q.empty(); }))
+                throw std::runtime_error("local comm: no message from part " + std::to_string(h.peer_ids[j]));
+            if ((int64_t)q.front().size() != cnt) throw std::runtime_error("local comm: message length mismatch");
+            std::memcpy(recv_ + off, q.front().data(), sizeof(double) * (size_t)cnt);
+            q.pop_front();
+        }
+        halo_ = nullptr;
+    }
+    void allreduce(double *buf, int count, void *) override                                 // :622-628
+    {
+        st_.n_allreduce++;
+        std::unique_lock<std::mutex> lk(w_->m);
+        // a generation is open for deposits only after every rank has left the previous one
+        if (!w_->cv.wait_for(lk, kTimeout, [&] { return w_->left == 0; }))
+            throw std::runtime_error("local comm: the previous all-reduce never drained");
+        const int64_t my_gen = w_->gen;
+        w_->dep[rank_].assign(buf, buf + count);
+        if (++w_->arrived == size_) {
+            w_->arrived = 0;
+            w_->left = size_;
+            w_->gen++;
+            w_->cv.notify_all();
+        } else if (!w_->cv.wait_for(lk, kTimeout, [&] { return w_->gen != my_gen; })) {
+            throw std::runtime_error("local comm: a peer never reached the all-reduce");
+        }
+        for (int c = 0; c < count; ++c) {
+            double s = 0;
+            for (int r = 0; r < size_; ++r) {
+                if ((int)w_->dep[r].size() != count) throw std::runtime_error("local comm: all-reduce count mismatch");
+                s += w_->dep[r][c];
+            }
+            buf[c] = s;
+        }
+        if (--w_->left == 0) w_->cv.notify_all();
+    }
+    void set_timing(bool) override {}
+    CommStats stats() override { return st_; }
+};
+
+}  // namespace
+
+std::unique_ptr<Comm> make_rccl_comm(int, int rank, int nranks, const void *unique_ids)
+{
+    return std::unique_ptr<Comm>(new LocalComm(rank, nranks, unique_ids));
+}
+
+int rccl_unique_ids(void *out)
+{
+    std::memset(out, 0, kIdBytes);
+    const uint64_t id = g_next_id.fetch_add(1);
+    std::memcpy(out, "pcg-hostops-local-comm", 22);
+    std::memcpy((char *)out + 32, &id, sizeof(id));
+    return 0;
+}
+
+}  // namespace pcg

@@ -4,6 +4,8 @@ usage: python tests/native_comm_worker.py threads <case[,case..]> <kind[,kind..]
            every part of a golden case in THIS process, one thread per part, each thread with its own RcclComm
        python tests/native_comm_worker.py proc <case> <kind> <outdir> <rank> <world> <idfile> [device]
            this process is rank <rank> of <world> (one part per process, as in production)
+       python tests/native_comm_worker.py group <case[,case..]> <kind[,kind..]> <outdir>
+           every part of a case as a member of ONE device group (pcg_group_*: the library's own thread per member)
 The RCCL library is whatever csrc/rccl_comm.hip resolves: the real librccl (one rank per GPU), or - with
 PCG_RCCL_LIB=tests/fakenccl/_build/libfakenccl.so - the shared-GPU test double.  Results go to
 <outdir>/<case>_<kind>_rank<r>.npz in the layout of tests/dist_worker.py.
@@ -93,6 +95,37 @@ def main():
                     np.savez(os.path.join(outdir, f"{case}_{kind}_rank{r}.npz"), **o)
             for c in comms:
                 c.close()
+    elif mode == "group":
+        # ONE process, every part of the case as a member of a device group (pcg_group_*): the library's own threads
+        # drive the members; devices from PCG_TEST_GROUP_DEVICES (default: every member on device 0)
+        from pcg_mi355x.group import GroupSolver
+        import pcg_mi355x as pm
+        cases, kinds, outdir = sys.argv[2].split(","), sys.argv[3].split(","), sys.argv[4]
+        for case in cases:
+            for kind in kinds:
+                parts, probe = build(case)
+                world = len(parts)
+                devs = os.environ.get("PCG_TEST_GROUP_DEVICES")
+                devs = [int(d) for d in devs.split(",")] if devs else [0] * world
+                gs = GroupSolver(parts, devices=devs, operator=kind, timing=timing)
+                try:
+                    ys = gs.group.apply([probe[P["DofVector"]] for P in parts])
+                    ds = gs.group.diag()
+                    s0 = [c.stats() for c in gs.group.comms]
+                    gs.updateBC(); gs.updatePreconditioner()
+                    assert gs.PCG(history=True) is None
+                    s1 = [c.stats() for c in gs.group.comms]
+                    for r, P in enumerate(parts):
+                        info = P["_pcg_mi355x_info"]
+                        o = {"rank": r, "dofs": P["DofVector"], "y_probe": ys[r], "diag": ds[r], "Fext": P["Fext"], "Un": P["Un"],
+                             "history": info.history, "flag": info.flag, "iter": info.iter, "relres": info.relres, "status": info.status,
+                             "iters_done": info.iters_done, "iters_enqueued": info.iters_enqueued, "t_comm": info.t_comm_s,
+                             "t_total": info.t_total_s}
+                        for k in s1[r]:
+                            o["stat_" + k] = s1[r][k] - s0[r][k]
+                        np.savez(os.path.join(outdir, f"{case}_{kind}_rank{r}.npz"), **o)
+                finally:
+                    gs.close()
     elif mode == "proc":
         case, kind, outdir = sys.argv[2:5]
         rank, world, idfile = int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
@@ -130,7 +163,7 @@ def main():
                  n_halo=st["n_halo"])
         comm.close()
     else:
-        raise SystemExit("mode must be threads, proc or selfloop")
+        raise SystemExit("mode must be threads, group, proc or selfloop")
 
 
 if __name__ == "__main__":

@@ -115,9 +115,13 @@ def test_device_entry_points_fail_loudly_without_gpu(product_lib):
     assert rc != 0 and lib.pcg_last_error()
 
 
-def test_test_double_has_no_native_communicator(hostops):
-    """tests/hostops is a CPU double of the KERNELS only; the native communicator and the device partition passes exist
-    only in the product library."""
+def test_test_double_talks_through_process_memory_only(hostops):
+    """tests/hostops is a CPU double of the KERNELS; its stand-in for the native communicator (local_comm.cpp, in-process
+    mailboxes for the group tests) is not RCCL, and the device partition passes exist only in the product library."""
+    import numpy as np
     uid = ctypes.create_string_buffer(256)
-    assert hostops.lib().pcg_rccl_unique_id(uid) != 0
-    assert b"no RCCL communicator" in hostops.lib().pcg_last_error()
+    assert hostops.lib().pcg_rccl_unique_id(uid) == 0 and uid.raw.startswith(b"pcg-hostops-local-comm")
+    n = ctypes.c_int64()
+    rc = hostops.lib().pcg_part_local_numbering(0, 4, 2, np.zeros(2, np.int32).ctypes.data, np.zeros(2, np.int32).ctypes.data,
+                                                np.zeros(2, np.int32).ctypes.data, ctypes.byref(n))
+    assert rc != 0 and b"no device-side partition set-up" in hostops.lib().pcg_last_error()

@@ -252,7 +252,7 @@ def _oracle_load_steps(model, ele_part, deltas):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
-@pytest.mark.parametrize("name,ranks", [("part_brick_p1", 1), ("part_octree_p3", 3)])
+@pytest.mark.parametrize("name,ranks", [("part_brick_p1", 1), ("part_octree_p3", 3), ("part_octree_p3", -3)])
 def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
     """SURVEY 8(f)-4 on the HIP engine: MDF -> `python -m pcg_mi355x.run` with TWO load steps (warm start from the
     previous Un, :358,:378) -> U_<k>.mpidat / TimeData in the layout export_vtk.py reads, vs the oracle's loop.
@@ -274,13 +274,18 @@ def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
     results = str(tmp_path / "Results_Run1")
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "pcg-mpi-solver_amd"))
     cmd = [sys.executable]
-    if ranks > 1:
+    group = ranks < 0                          # -3: ONE process drives the three parts (--group, C ABI pcg_group_*)
+    ranks = abs(ranks)
+    if group:
+        if gpu_lib.lib().pcg_device_count() < ranks:
+            env.update(PCG_RCCL_LIB=conftest.build_fakenccl())
+    elif ranks > 1:
         if gpu_lib.lib().pcg_device_count() < ranks:
             env.update(PCG_RUN_SHARE_GPU="1", PCG_RCCL_LIB=conftest.build_fakenccl())
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
                 "--master-port", str(29700 + (kind == "ebe"))]
     cmd += ["-m", "pcg_mi355x.run", "--mdf", path, "--settings", str(tmp_path / "GlobSettings.zpkl"), "--results", results,
-            "--operator", kind]
+            "--operator", kind] + (["--group", "--n-parts", str(ranks)] if group else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     sols, its = _oracle_load_steps(model, ele_part, deltas)
@@ -294,6 +299,7 @@ def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
     assert list(np.load(os.path.join(results, "ResVecData", "Time_T.npy"))) == [0.0, 1.0, 2.0]
     assert float(td["CalcTime"]) > 0
     if ranks > 1:
+        assert np.load(os.path.join(results, "ResVecData", "U_1_metadat.npy"), allow_pickle=True).item()["NfData"].shape == (ranks,)
         assert 0 < float(td["CommWaitTime"]) < float(td["TotalTime"])         # a7: time blocked in communication (GPU side)
 
 
