@@ -16,6 +16,7 @@
  *   MPI_SUM                               :622-628        pcg_comm_create_rccl(): ncclAllReduce issued by the engine  | pcg_comm_hooks.allreduce
  *   Isend/Recv/Waitall interface sums     :318-334        pcg_comm_create_rccl(): grouped ncclSend/ncclRecv, comm stream | pcg_comm_hooks.halo_*
  *   np.dot(a, b*w)                        :381,415,462..  pcg_dot_w()
+ *   mpiexec -np N (one rank per part)     :91, :968-970   one process per GPU, or ONE process for all GPUs: pcg_group_*()
  *   element tables -> operator            (partition_mesh.py:443-491,576-581 data contract)
  *                                                          pcg_asm_*() + pcg_create()   assembled, SELL over 3x3 blocks
  *                                                          pcg_create_ebe()             matrix-free, as the reference
