@@ -74,12 +74,19 @@ void pcg_asm_destroy(pcg_asm *a);
 /* ---- engine ---------------------------------------------------------------------------------
  * n_boundary_nodes: nodes [0, n_boundary_nodes) are shared with another part (their rows are
  * computed first so the interface exchange overlaps the interior rows); 0 for a single part.
- * rows_per_lane: SELL slice = 64*rows_per_lane block rows (1 or 2; 0 = library default). */
+ * rows_per_lane: SELL slice = 64*rows_per_lane block rows (1 or 2; 0 = library default), optionally OR-ed with
+ *   PCG_FORMAT_DICTIONARY: store every stored block as a 2-byte index into a dictionary of the matrix's DISTINCT 3x3 blocks
+ *   (compared bit by bit: lossless, the SpMV is bit-identical to the plain format) instead of its 72 bytes of values - 4 to
+ *   6 bytes per block, the dictionary stays in LDS.  Pattern-based meshes (the reference's domain: a few element stiffness
+ *   patterns scaled by a few material factors, partition_mesh.py:443-491) assemble to a few hundred distinct blocks whatever
+ *   their size; a matrix with more than 65535 distinct blocks silently keeps the plain format (pcg_matrix_dictionary). */
+enum { PCG_FORMAT_DICTIONARY = 0x100 };
 int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols,
                const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
 /* The same engine from an already assembled scalar CSR matrix (i64 row pointer, i32 columns, f64 values).
  * block = 0/3: n = 3 * nodes rows (dof = 3*node + dir) grouped into 3x3 blocks internally (the fast format);
- * block = 1:   the scalar format is kept (any n; one f64 + one i32 per non-zero = the literal CSR traffic). */
+ * block = 1:   the scalar format is kept (any n; one f64 + one i32 per non-zero = the literal CSR traffic).
+ * block = 3 | PCG_FORMAT_DICTIONARY: 3x3 blocks with the value dictionary (see pcg_create). */
 int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val,
                    int64_t n_boundary_nodes, int32_t block, pcg_engine **out);
 /* Matrix-free variant: the operator stays in the reference's element-by-element form
@@ -254,6 +261,7 @@ int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free
  * structures) and compute (flops of the un-padded operator): the denominators of the roofline report (bench.py). */
 int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply);
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
+int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique /* distinct blocks of the value dictionary; 0 = plain values */);
 /* single fused kernels on host vectors, for per-kernel parity tests */
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first);
 int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r,

@@ -243,6 +243,85 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     }
 }
 
+// Dictionary variant (SellHost::bidx / dict, sell.cpp compress_blocks; PCG_FORMAT_DICTIONARY): a stored block is a column and a
+// 16-bit index into the table of the matrix's DISTINCT 3x3 blocks, 4-6 bytes instead of 74-76.  The same lanes multiply the
+// same values in the same order as k_spmv: results are bit-identical, only where the values come from differs.  LDSD: the
+// table (72 B per entry) is copied into LDS once per workgroup - the workgroups are persistent, each wave walks many
+// slices - and the lanes of a wave read their blocks from there (same index = one broadcast read; the kernel is bound by the
+// LDS read rate and the x gathers, not by HBM: 0.5 GB instead of 6.9 GB per launch at 10 M dof).  !LDSD: tables beyond the LDS
+// budget are read through L1/L2.
+template <bool DOT, bool COL16, bool LDSD, int BLK>
+__global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
+                                                      const int *__restrict__ colbase, const unsigned short *__restrict__ bidx,
+                                                      const double *__restrict__ dict, int n_unique,
+                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                      int64_t slice_lo, int64_t slice_hi, int64_t n_nodes)
+{
+    extern __shared__ double sdict[];
+    using CV = typename std::conditional<COL16, unsigned short, int>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int WPB = BLK / 64;                              // waves per workgroup: they share one copy of the table
+    if constexpr (LDSD) {
+        for (int i = threadIdx.x; i < 9 * n_unique; i += BLK) sdict[i] = dict[i];
+        __syncthreads();
+    }
+    const int64_t wstride = (int64_t)gridDim.x * WPB;
+    double dot = 0.0;
+    for (int64_t s = slice_lo + (int64_t)blockIdx.x * WPB + wid; s < slice_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
+        const unsigned short *ip = bidx + (size_t)base * 64 + lane;
+        int cb = 0;
+        if constexpr (COL16) cb = colbase[s];
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 3
+        for (int k = 0; k < w; ++k) {
+            int j = ntload(cp + (size_t)k * 64);
+            if constexpr (COL16) j += cb;
+            const int id = ntload(ip + (size_t)k * 64);
+            double v[9];
+            if constexpr (LDSD) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = sdict[9 * id + c];
+            } else {
+                const double *b = dict + 9 * (size_t)id;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = b[c];
+            }
+            const double *xp = x + 3 * (size_t)j;
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+        }
+        const int64_t row = s * 64 + lane;
+        if (row < n_nodes) {
+            double *yp = y + 3 * row;
+            yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+            if constexpr (DOT) {
+                const uint8_t *fp = flags + 3 * row;
+                const double *xr = x + 3 * row;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
+            }
+        }
+    }
+    if constexpr (DOT) {                                       // fixed order: lanes (shuffle tree), then the waves in turn
+        __shared__ double lds[WPB];
+        const double ws = wave_sum(dot);
+        if (lane == 0) lds[wid] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = lds[0];
+#pragma unroll
+            for (int q = 1; q < WPB; ++q) t += lds[q];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
 // Scalar-row variant (SellHost::bs == 1): one lane per matrix ROW, one f64 value + one i32 column per stored
 // entry - the literal CSR data volume (12 B per non-zero), in the same slice layout, so a wave's loads of a
 // slice column are one 512 B + one 256 B coalesced line.  Used by pcg_create_csr(block = 1): systems whose
@@ -1578,6 +1657,7 @@ public:
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_ALLOC_CONTIG")) alloc_contig_ = atoi(e);
+        if (const char *e = getenv("PCG_SPMV_DICT_BLOCK")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) dict_block_ = b; }
         reload_tuning();
         if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_EBE_HEX")) hex_mode_ = atoi(e);
@@ -1586,7 +1666,7 @@ public:
     ~HipBackend() override
     {
         (void)hipSetDevice(dev_);
-        for (void *p : {(void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
+        for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_})
             if (p) (void)hipFree(p);
@@ -1649,7 +1729,7 @@ public:
         bs_ = m.bs;
         n_nodes_ = m.n_nodes; n_ = m.bs * m.n_nodes; n_slices_ = m.n_slices; n_bnd_slices_ = m.n_bnd_slices; C_ = m.C;
         d_slice_ptr_ = (int64_t *)alloc(sizeof(int64_t) * m.slice_ptr.size());
-        d_vals_ = (double *)alloc(sizeof(double) * m.vals.size());
+        d_vals_ = m.bidx.empty() ? (double *)alloc(sizeof(double) * m.vals.size()) : nullptr;
         d_diag_ = (double *)alloc(sizeof(double) * m.diag.size());
         d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
         h2d(d_slice_ptr_, m.slice_ptr.data(), sizeof(int64_t) * m.slice_ptr.size());
@@ -1679,7 +1759,17 @@ public:
             d_cols_ = (int *)alloc(sizeof(int) * m.cols.size());
             h2d(d_cols_, m.cols.data(), sizeof(int) * m.cols.size());
         }
-        h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
+        if (!m.bidx.empty()) {                              // dictionary format: indices + table instead of the values
+            n_unique_ = (int)m.n_unique();
+            d_bidx_ = (unsigned short *)alloc(sizeof(unsigned short) * m.bidx.size());
+            d_dict_ = (double *)alloc(sizeof(double) * std::max<size_t>(9, m.dict.size()));
+            h2d(d_bidx_, m.bidx.data(), sizeof(unsigned short) * m.bidx.size());
+            h2d(d_dict_, m.dict.data(), sizeof(double) * m.dict.size());
+            dict_lds_ = (size_t)n_unique_ * 72 <= kDictLdsBytes;
+            if (const char *e = getenv("PCG_SPMV_DICT_LDS")) dict_lds_ = dict_lds_ && atoi(e) != 0;
+        } else {
+            h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
+        }
         h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
     }
@@ -1974,9 +2064,52 @@ public:
                                    d_flags_, d_part_spmv_, lo, hi, n_nodes_);
             return;
         }
+        if (d_bidx_) {
+            if (d_cols16_) launch_spmv_dict<true>(x, y, lo, hi, dot, grid, d_cols16_);
+            else launch_spmv_dict<false>(x, y, lo, hi, dot, grid, d_cols_);
+            return;
+        }
         if (d_cols16_) launch_spmv_c<RPL, true>(x, y, lo, hi, dot, grid, d_cols16_);
         else launch_spmv_c<RPL, false>(x, y, lo, hi, dot, grid, d_cols_);
     }
+    // value dictionary (k_spmv_dict): table in LDS when it fits kDictLdsBytes, else read through the caches
+    static constexpr size_t kDictLdsBytes = 60 * 1024;
+    unsigned short *d_bidx_ = nullptr;
+    double *d_dict_ = nullptr;
+    int n_unique_ = 0;
+    bool dict_lds_ = false;
+    // Workgroup size of the dictionary kernel: every workgroup holds one copy of the table in LDS, so larger workgroups
+    // put more waves behind one copy.  0 = automatic: 256 threads while four copies fit next to each other on a CU
+    // (tables up to ~40 KB), else 512.  PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 1024).
+    int dict_block_ = 0;
+    template <bool COL16>
+    void launch_spmv_dict(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
+    {
+        const size_t lds = dict_lds_ ? (size_t)n_unique_ * 72 : 0;
+        const int64_t fit = lds ? std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds + 128))) : 8;     // copies per CU (160 KB LDS)
+        int blk = dict_block_ ? dict_block_ : (fit >= 4 ? 256 : 512);
+        // workgroups per CU: what LDS leaves room for, and at most 16 waves per CU in flight (95 VGPRs: 5 per SIMD)
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(fit, (blk == 256 ? spmv_blocks_per_cu_ : 1024 / blk)));
+        const int wpb = blk / 64;
+        int64_t g = std::min<int64_t>((hi - lo + wpb - 1) / wpb, std::min<int64_t>((int64_t)n_cu_ * per_cu, kMaxPartials));
+        g = std::max<int64_t>(8, (g + 7) / 8 * 8);
+        grid = (int)g;
+#define PCG_LAUNCH_DICT(D, L, B)                                                                                                  \
+        hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols, d_colbase_, d_bidx_,   \
+                           d_dict_, n_unique_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_)
+#define PCG_LAUNCH_DICT_B(B)                                                                                                      \
+        do {                                                                                                                      \
+            if (dot) { if (lds) PCG_LAUNCH_DICT(true, true, B); else PCG_LAUNCH_DICT(true, false, B); }                           \
+            else { if (lds) PCG_LAUNCH_DICT(false, true, B); else PCG_LAUNCH_DICT(false, false, B); }                             \
+        } while (0)
+        if (blk == 1024) PCG_LAUNCH_DICT_B(1024);
+        else if (blk == 512) PCG_LAUNCH_DICT_B(512);
+        else PCG_LAUNCH_DICT_B(256);
+#undef PCG_LAUNCH_DICT_B
+#undef PCG_LAUNCH_DICT
+        last_spmv_grid_ = grid;
+    }
+    int last_spmv_grid_ = 0;
     template <int RPL, bool COL16>
     void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
@@ -1994,11 +2127,12 @@ public:
         const int grid = spmv_grid(hi - lo);
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
+        last_spmv_grid_ = grid;
         if (C_ == 64) launch_spmv<1>(x, y, lo, hi, with_dot, grid);
         else launch_spmv<2>(x, y, lo, hi, with_dot, grid);
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (hi == n_slices_) ++ev_applies_; }
-        if (with_dot) cnt_spmv_ = grid;
+        if (with_dot) cnt_spmv_ = last_spmv_grid_;          // (the dictionary kernel may have launched a smaller grid)
     }
     void halo_pack(const double *y, double *send) override
     {

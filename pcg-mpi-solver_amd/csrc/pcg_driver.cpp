@@ -48,6 +48,7 @@ struct pcg_engine {
     int32_t kind = 0;                 // 0 = assembled SELL-BSR3 operator, 1 = matrix-free (EBE)
     int64_t n_bnd_dofs = 0;           // dofs [0, n_bnd_dofs) may receive interface contributions
     int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
+    int64_t n_unique = 0;             // distinct 3x3 blocks when the values are dictionary-compressed (0: plain values)
     int32_t n_colors = 0;
     int64_t n_chunks = 0;
     double op_bytes = 0, op_flops = 0;    // what one local operator apply has to move / compute (stored structures)
@@ -438,10 +439,22 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
             if (rowptr[i + 1] < rowptr[i]) return set_error("pcg_create: rowptr must be non-decreasing");
         for (int64_t k = 0; k < rowptr[n_nodes]; ++k)
             if (cols[k] < 0 || cols[k] >= n_nodes) return set_error("pcg_create: block column index out of range");
+        // format flag in rows_per_lane: bit 8 = replace the values by a dictionary of the matrix's distinct 3x3 blocks when
+        // there are at most 65535 of them (lossless; k_spmv_dict); PCG_SPMV_DICT=0/1 overrides the caller either way
+        bool want_dict = (rows_per_lane & PCG_FORMAT_DICTIONARY) != 0;
+        if (const char *ev = std::getenv("PCG_SPMV_DICT")) want_dict = std::atoi(ev) != 0;
+        rows_per_lane &= 0xff;
+        if (want_dict) rows_per_lane = 1;                   // the dictionary kernel is written for 64-row slices
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);                       // throws when no usable device: no fallback
         SellHost m;
         bsr_to_sell(n_nodes, rowptr, cols, vals, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
+        if (want_dict) {
+            int64_t cap = 65535;
+            if (const char *ev = std::getenv("PCG_SPMV_DICT_MAX")) cap = std::max(1, std::atoi(ev));
+            (void)compress_blocks(m, cap, 16);              // false: too many distinct blocks - the plain format stays
+        }
+        e->n_unique = m.n_unique();
         e->n_nodes = n_nodes;
         e->n = 3 * n_nodes;
         e->n_slices = m.n_slices;
@@ -456,6 +469,9 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         // once, the slice pointers
         const int cb = e->be->col_index_bytes();
         e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
+        if (e->n_unique > 0)                                // dictionary format: a 2-byte index instead of the 72 bytes of values
+            e->op_bytes = (2.0 + cb) * (double)e->stored_blocks + 72.0 * (double)e->n_unique + 16.0 * (double)e->n +
+                          (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
         e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
         e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
         e->be->set_status_block(e->d_st);
@@ -476,6 +492,9 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
 {
     return guarded("pcg_create_csr", [&]() -> int {
         if (!out || !rowptr || !col || !val || n <= 0) return set_error("pcg_create_csr: bad argument");
+        const bool dict = (block & PCG_FORMAT_DICTIONARY) != 0;
+        block &= 0xff;
+        if (dict && block == 1) return set_error("pcg_create_csr: the value dictionary needs 3x3 node blocks (block = 0/3)");
         if (block == 1) {                                    // keep the scalar format: one f64 + one i32 per non-zero
             auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
             e->be = make_backend(device);
@@ -526,7 +545,7 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
                 }
             brow[i + 1] = (int64_t)bcol.size();
         }
-        return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, 0, out);
+        return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, dict ? PCG_FORMAT_DICTIONARY : 0, out);
     });
 }
 
@@ -980,6 +999,13 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
 }
 
 // ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
+int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique)
+{
+    if (!e || !n_unique) return set_error("pcg_matrix_dictionary: null");
+    *n_unique = e->kind == 0 ? e->n_unique : 0;
+    return 0;
+}
+
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first)
 {
     return guarded("pcg_k_update_p", e, [&]() -> int {

@@ -32,12 +32,24 @@ struct SellHost {
     std::vector<int32_t> cols;
     std::vector<double> vals;
     std::vector<double> diag;     // diag(A) local, length 3*n_nodes (extracted at build time)
+    // Value dictionary (compress_blocks): the 9 values of stored block q = (slice_ptr[s] + k) * C + lane are
+    // dict[9 * bidx[q] .. +9) (row-major 3x3) and `vals` is empty - 2 bytes per stored block instead of 72.
+    std::vector<uint16_t> bidx;
+    std::vector<double> dict;
+    int64_t n_unique() const { return (int64_t)(dict.size() / 9); }
 };
 
 void csr_to_sell1(int64_t n, const int64_t *rowptr, const int32_t *cols, const double *vals, int64_t n_boundary_rows,
                   int n_threads, SellHost &out);
 void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
                  int64_t n_boundary_nodes, int32_t rows_per_lane, int n_threads, SellHost &out);
+
+// Replace the values of a 3x3-block SELL matrix (C = 64) by indices into a dictionary of its DISTINCT blocks (compared by
+// bit pattern: lossless).  Pattern-based meshes - the reference's domain: a few element stiffness patterns scaled by a few
+// material factors (partition_mesh.py:443-491) - assemble to a few hundred distinct blocks however large the mesh is.
+// Returns false and leaves `m` unchanged when there are more than max_unique (<= 65535) of them.  The dictionary is sorted
+// by bit pattern, i.e. independent of the thread count.
+bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads);
 
 // ---- matrix-free (element-by-element) operator ------------------------------------------------
 // The reference's own algorithm (pcg_solver.py:265-300): per element gather x, flip signs, multiply

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
 #include "pcg_internal.hpp"
 
@@ -68,6 +69,106 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
         }
         for (auto &t : th) t.join();
     }
+}
+
+namespace {
+
+struct BlockKey {
+    uint64_t w[9];
+    bool operator==(const BlockKey &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+    bool operator<(const BlockKey &o) const
+    {
+        for (int c = 0; c < 9; ++c)
+            if (w[c] != o.w[c]) return w[c] < o.w[c];
+        return false;
+    }
+};
+struct BlockHash {
+    size_t operator()(const BlockKey &k) const
+    {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (int c = 0; c < 9; ++c) {
+            h ^= k.w[c] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 33;
+        }
+        return (size_t)h;
+    }
+};
+
+}  // namespace
+
+bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
+{
+    if (m.bs != 3 || m.C != 64) return false;
+    max_unique = std::min<int64_t>(max_unique, 65535);
+    const int C = m.C;
+    const int64_t tot = m.slice_ptr[m.n_slices];
+    if (m.vals.size() != (size_t)tot * C * 9) return false;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, m.n_slices / 64 + 1));
+    std::vector<uint16_t> bidx((size_t)tot * C);
+    std::vector<std::vector<BlockKey>> local((size_t)nt);              // thread t's distinct blocks, by local id
+    std::vector<char> failed((size_t)nt, 0);
+    const int64_t chunk = (m.n_slices + nt - 1) / nt;
+    auto scan = [&](int t) {
+        std::unordered_map<BlockKey, uint32_t, BlockHash> tab;
+        auto &dict = local[t];
+        BlockKey tile[64];
+        const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
+        for (int64_t q = m.slice_ptr[s_lo]; q < m.slice_ptr[s_hi]; ++q) {      // q = (slice, k): 64 blocks, value-component major
+            for (int c = 0; c < 9; ++c) {
+                const double *v = &m.vals[((size_t)q * 9 + c) * C];
+                for (int l = 0; l < 64; ++l) std::memcpy(&tile[l].w[c], v + l, 8);
+            }
+            for (int l = 0; l < 64; ++l) {
+                auto it = tab.find(tile[l]);
+                uint32_t id;
+                if (it != tab.end()) {
+                    id = it->second;
+                } else {
+                    if ((int64_t)dict.size() >= max_unique) { failed[t] = 1; return; }
+                    id = (uint32_t)dict.size();
+                    dict.push_back(tile[l]);
+                    tab.emplace(tile[l], id);
+                }
+                bidx[(size_t)q * C + l] = (uint16_t)id;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+    }
+    for (char f : failed)
+        if (f) return false;
+    std::vector<BlockKey> all;
+    for (const auto &d : local) all.insert(all.end(), d.begin(), d.end());
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if ((int64_t)all.size() > max_unique) return false;
+    std::vector<std::vector<uint16_t>> remap((size_t)nt);
+    for (int t = 0; t < nt; ++t) {
+        remap[t].resize(local[t].size());
+        for (size_t i = 0; i < local[t].size(); ++i)
+            remap[t][i] = (uint16_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin());
+    }
+    auto apply = [&](int t) {
+        const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
+        for (size_t i = (size_t)m.slice_ptr[s_lo] * C, e = (size_t)m.slice_ptr[s_hi] * C; i < e; ++i) bidx[i] = remap[t][bidx[i]];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(apply, t);
+        apply(0);
+        for (auto &x : th) x.join();
+    }
+    m.dict.resize(all.size() * 9);
+    for (size_t i = 0; i < all.size(); ++i) std::memcpy(&m.dict[i * 9], all[i].w, sizeof(all[i].w));
+    m.bidx.swap(bidx);
+    std::vector<double>().swap(m.vals);                                // the values now live in the dictionary only
+    return true;
 }
 
 // scalar rows: the same slice layout with 1 value per entry (vals[(slice_ptr[s]+k)*C + lane]); duplicates summed

@@ -121,11 +121,11 @@ class Operator:
         n = len(rowptr) - 1
         h = C.c_void_p()
         check(L.pcg_create_csr(device, n, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data, 0, int(block),
-                               C.byref(h)), "pcg_create_csr")
+                               C.byref(h)), "pcg_create_csr")          # block may carry _lib.FORMAT_DICTIONARY
         self._L, self._h, self.kind = L, h, "sell"
         self.n, self.n_nodes, self._map = n, n // 3, None
         info = self.matrix_info()
-        self.nnzb, self.nnz = info["nnzb"], (1 if block == 1 else 9) * info["nnzb"]
+        self.nnzb, self.nnz = info["nnzb"], (1 if (block & 0xff) == 1 else 9) * info["nnzb"]
         self._comm = self._hooks = None
         self.glob_n_eff = None
         self.last_result = None
@@ -289,6 +289,12 @@ class Operator:
         check(self._L.pcg_operator_cost(self._h, C.byref(b), C.byref(f)), "pcg_operator_cost")
         return b.value, f.value
 
+    def matrix_dictionary(self):
+        """Distinct 3x3 blocks of the value dictionary (PCG_FORMAT_DICTIONARY); 0 = plain values."""
+        n = C.c_int64()
+        check(self._L.pcg_matrix_dictionary(self._h, C.byref(n)), "pcg_matrix_dictionary")
+        return n.value
+
     def matrix_info(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         check(self._L.pcg_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pcg_matrix_info")
@@ -336,7 +342,9 @@ def _blocked_node_order(xyz, is_b, block=8):
 
 def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell", ebe_chunked=True):
     """Build the GPU operator of one RefMeshPart (see module docstring for the keys read).
-    kind: "sell" = assembled SELL-BSR3 matrix (default), "ebe" = matrix-free element-by-element."""
+    kind: "sell" = assembled SELL-BSR3 matrix (default), "dict" = the same matrix with its values replaced by a dictionary of
+    its distinct 3x3 blocks (PCG_FORMAT_DICTIONARY; falls back to "sell" storage when there are too many),
+    "ebe" = matrix-free element-by-element."""
     ndof = int(part["NDOF"])
     if ndof % 3:
         raise PcgError("NDOF must be a multiple of 3 (dof = 3*node + dir, partition_mesh.py:826)")
@@ -363,9 +371,10 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
     if kind == "ebe":
         op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm,
                       node_coords=xyz, ebe_chunked=ebe_chunked)
-    elif kind == "sell":
+    elif kind in ("sell", "dict"):
         rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
-        op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, rows_per_lane)
+        op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device,
+                      int(rows_per_lane) | (_lib.FORMAT_DICTIONARY if kind == "dict" else 0))
     else:
         raise ValueError(kind)
     w = np.asarray(part["DofWeightVector"], float)

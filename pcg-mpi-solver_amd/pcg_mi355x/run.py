@@ -174,7 +174,7 @@ def main(argv=None):
     ap.add_argument("--tol", type=float, default=1e-7)
     ap.add_argument("--max-iter", type=int, default=10000)
     ap.add_argument("--results", required=True, help="result directory (Results_Run<R>)")
-    ap.add_argument("--operator", choices=["sell", "ebe"], default="sell")
+    ap.add_argument("--operator", choices=["sell", "dict", "ebe"], default="sell")
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N > 1: native = RCCL calls issued by the engine (default); torch = torch.distributed callbacks")
     ap.add_argument("--speed-test", action="store_true")

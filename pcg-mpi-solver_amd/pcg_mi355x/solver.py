@@ -35,7 +35,8 @@ _cfg = {"comm": None, "device": 0, "rows_per_lane": 0, "operator": "sell", "ebe_
 
 def configure(comm=None, device=0, rows_per_lane=0, operator="sell", ebe_chunked=True):
     """Set the process-wide communicator / device (the reference's module globals Comm, Rank :968-970)
-    and the operator kind ("sell" = assembled matrix, "ebe" = matrix-free like the reference)."""
+    and the operator kind ("sell" = assembled matrix, "dict" = assembled with a dictionary of its distinct 3x3 blocks,
+    "ebe" = matrix-free like the reference)."""
     _cfg.update(comm=comm, device=device, rows_per_lane=rows_per_lane, operator=operator, ebe_chunked=ebe_chunked)
 
 

@@ -153,9 +153,11 @@ public:
                 double t[3] = {0, 0, 0};
                 for (int64_t k = 0; k < w; ++k) {
                     const int64_t j = m_.cols[(size_t)(base + k) * C + l];
+                    // dictionary format (compress_blocks): the block's 9 values are dict[9 * bidx[q]..], q = the stored slot
+                    const double *blk = m_.bidx.empty() ? nullptr : &m_.dict[(size_t)9 * m_.bidx[(size_t)(base + k) * C + l]];
                     for (int a = 0; a < 3; ++a)
                         for (int b = 0; b < 3; ++b)
-                            t[a] += m_.vals[((size_t)(base + k) * 9 + a * 3 + b) * C + l] * x[3 * j + b];
+                            t[a] += (blk ? blk[a * 3 + b] : m_.vals[((size_t)(base + k) * 9 + a * 3 + b) * C + l]) * x[3 * j + b];
                 }
                 for (int a = 0; a < 3; ++a) {
                     y[3 * r + a] = t[a];

@@ -137,6 +137,29 @@ def main():
         o = run_rank(P, probe[P["DofVector"]], comm, kind, device, timing)
         np.savez(os.path.join(outdir, f"{case}_{kind}_rank{rank}.npz"), **o)
         comm.close()
+    elif mode == "torchpg":
+        # the launch shape of bench.py / pcg_mi355x.run at N > 1, at world size 1: torch.distributed with the NCCL (= RCCL)
+        # backend as control plane AND the engine's own communicators on the same librccl in the same process
+        case, kind, outdir, port = sys.argv[2:6]
+        import datetime
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
+        dist.barrier()
+        comm = RcclComm.from_torch(0)                         # unique id through broadcast_object_list on the NCCL group
+        parts, probe = build(case)
+        P = parts[0]
+        o = run_rank(P, probe[P["DofVector"]], comm, kind, 0, timing)
+        torch.cuda.synchronize()
+        dist.barrier()                                         # torch's communicator still works next to the engine's two
+        box = [None]
+        dist.all_gather_object(box, float(o["relres"]))
+        assert box[0] == float(o["relres"])
+        np.savez(os.path.join(outdir, f"{case}_{kind}_rank0.npz"), **o)
+        comm.close()
+        dist.destroy_process_group()
     elif mode == "selfloop":
         # ONE rank on real librccl whose part lists ITSELF as its only neighbour (PCG_RCCL_ALLOW_SELF=1): the interface
         # exchange then delivers the part's own partial sums back to it, so y = A_local x with the interface dofs doubled.
@@ -163,7 +186,7 @@ def main():
                  n_halo=st["n_halo"])
         comm.close()
     else:
-        raise SystemExit("mode must be threads, group, proc or selfloop")
+        raise SystemExit("mode must be threads, group, proc, torchpg or selfloop")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,215 @@
+"""The value dictionary of the assembled operator (PCG_FORMAT_DICTIONARY, csrc/sell.cpp compress_blocks, k_spmv_dict):
+every stored 3x3 block becomes a 16-bit index into the table of the matrix's DISTINCT blocks.  Lossless by construction -
+blocks are compared by bit pattern and the kernel multiplies the same values in the same order - so the contract is
+BIT-IDENTITY with the plain format, on top of the usual parity with the reference fixtures (pcg_solver.py:242-336, :356-598).
+
+CPU tier: the host code (dictionary builder, the driver's format switch, byte accounting) on the test double, whose SpMV
+reads through the dictionary.  GPU tier: k_spmv_dict with the table in LDS and read through the caches."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_cases
+import pcg_oracle
+from pcg_mi355x.brick import Brick, make_parts, block_partition
+from util import golden, relerr, check_solution_against_golden
+
+
+def _spmv_local(op, xl):
+    from pcg_mi355x._lib import check
+    xe = op.to_engine(xl)
+    y = np.empty(op.n)
+    pxy = C.c_double()
+    check(op._L.pcg_k_spmv_local(op._h, xe.ctypes.data, y.ctypes.data, C.byref(pxy)))
+    return op.from_engine(y), pxy.value
+
+
+def _pair(P, **kw):
+    from pcg_mi355x.operator import from_refmeshpart
+    return from_refmeshpart(P, kind="sell", **kw), from_refmeshpart(P, kind="dict", **kw)
+
+
+def _check_identical(P, seed=3, with_diag=True, dot_exact=True, **kw):
+    plain, dic = _pair(P, **kw)
+    try:
+        assert plain.matrix_dictionary() == 0 and dic.matrix_dictionary() > 0
+        ip, idc = plain.matrix_info(), dic.matrix_info()
+        assert (ip["nnzb"], ip["stored_blocks"], ip["n_slices"]) == (idc["nnzb"], idc["stored_blocks"], idc["n_slices"])
+        x = np.random.default_rng(seed).standard_normal(plain.n)
+        ya, da = _spmv_local(plain, x)
+        yb, db = _spmv_local(dic, x)
+        assert np.array_equal(ya, yb)                                    # same values, same order: the same bits
+        # the fused p.Ap: identical when the partial sums are grouped alike (same workgroup shape), else a different tree
+        assert da == db if dot_exact else abs(da - db) <= 1e-13 * np.dot(np.abs(x), np.abs(ya))
+        if with_diag:                                                    # (diag() of a part with neighbours exchanges)
+            assert np.array_equal(plain.diag(), dic.diag())
+        assert relerr(yb, pcg_oracle.matvec_local(P, x)) < 1e-14
+        bp, fp = plain.operator_cost()
+        bd, fd = dic.operator_cost()
+        assert fp == fd and bd < 0.2 * bp                                # 4-6 B per stored block instead of 74-76 (+ the table)
+        return dic.matrix_dictionary()
+    finally:
+        plain.close(); dic.close()
+
+
+@pytest.mark.parametrize("n_types", [1, 3])
+def test_dictionary_spmv_is_bit_identical_on_the_test_double(hostops, n_types):
+    b = Brick(9, n_types=n_types)
+    n_unique = _check_identical(make_parts(b)[0])
+    # two material factors x a few stencil positions: a few hundred distinct blocks at most, whatever the mesh size
+    assert n_unique < 1500 and n_unique < b.nnz // 9 // 4
+
+
+def test_dictionary_size_does_not_grow_with_the_mesh(hostops):
+    from pcg_mi355x.operator import from_refmeshpart
+    sizes = []
+    for N in (9, 13):
+        op = from_refmeshpart(make_parts(Brick(N, seed=0))[0], kind="dict")
+        sizes.append(op.matrix_dictionary())
+        op.close()
+    assert sizes[1] <= 1.25 * sizes[0]
+
+
+def test_too_many_distinct_blocks_keep_the_plain_format(hostops, monkeypatch):
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_SPMV_DICT_MAX", "20")
+    P = make_parts(Brick(7, seed=0))[0]
+    op = from_refmeshpart(P, kind="dict")
+    try:
+        assert op.matrix_dictionary() == 0
+        x = np.random.default_rng(1).standard_normal(op.n)
+        assert relerr(_spmv_local(op, x)[0], pcg_oracle.matvec_local(P, x)) < 1e-14
+    finally:
+        op.close()
+
+
+def test_dictionary_from_a_scalar_csr_matrix(hostops):
+    """pcg_create_csr(block = 3 | PCG_FORMAT_DICTIONARY): an assembled scipy matrix in, dictionary format behind it."""
+    import scipy.sparse as sp
+    from pcg_mi355x import _lib
+    from pcg_mi355x.operator import assemble_bsr3, Operator
+    b = Brick(6, n_types=2)
+    P = make_parts(b)[0]
+    rp, c, v = assemble_bsr3(P["SubDomainData"]["StrucDataList"], b.n_node)
+    A = sp.bsr_matrix((v, c, rp), shape=(b.n_dof, b.n_dof)).tocsr()
+    op = Operator.from_csr(A.indptr, A.indices, A.data, block=3 | _lib.FORMAT_DICTIONARY)
+    ref = Operator.from_csr(A.indptr, A.indices, A.data)
+    try:
+        assert op.matrix_dictionary() > 0 and ref.matrix_dictionary() == 0
+        x = np.random.default_rng(9).standard_normal(b.n_dof)
+        assert np.array_equal(op.apply(x), ref.apply(x))
+        with pytest.raises(_lib.PcgError, match="needs 3x3 node blocks"):
+            Operator.from_csr(A.indptr, A.indices, A.data, block=1 | _lib.FORMAT_DICTIONARY)
+    finally:
+        op.close(); ref.close()
+
+
+@pytest.mark.parametrize("case", ["n9_p1", "n9_flag4", "n9_maxiter", "oct_p1", "n17_p1"])
+def test_dictionary_solve_matches_reference_fixture(hostops, case):
+    import pcg_mi355x as pm
+    _, parts = golden_cases.build_case(case)
+    g = golden(case)
+    P = parts[0]
+    pm.configure(comm=None, operator="dict")
+    try:
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P, history=True)
+        assert pm.get_operator(P).matrix_dictionary() > 0
+        info = P["_pcg_mi355x_info"]
+        check_solution_against_golden(g, info.flag, info.iter, info.relres, P["Un"], info.history,
+                                      tol_u=1e-8 if int(g["flag"]) == 0 else 1e-6)
+    finally:
+        P.pop("_pcg_mi355x_operator").close()
+        pm.configure(comm=None, operator="sell")
+
+
+@pytest.mark.parametrize("case", ["n9_p8", "oct_p3"])
+def test_dictionary_multi_part(hostops, case):
+    """Interface rows first, exchange, fix-up - unchanged by the storage format: the group run equals the plain one bit for bit."""
+    from pcg_mi355x.group import GroupSolver
+    outs = {}
+    for kind in ("sell", "dict"):
+        _, parts = golden_cases.build_case(case)
+        gs = GroupSolver(parts, operator=kind)
+        try:
+            gs.updateBC(); gs.updatePreconditioner(); gs.PCG(history=True)
+            assert all((op.matrix_dictionary() > 0) == (kind == "dict") for op in gs.group.ops)
+            outs[kind] = (parts[0]["_pcg_mi355x_info"].history.copy(), [P["Un"].copy() for P in parts])
+        finally:
+            gs.close()
+    assert np.array_equal(outs["sell"][0], outs["dict"][0])
+    for a, b in zip(outs["sell"][1], outs["dict"][1]):
+        assert np.array_equal(a, b)
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("lds,block", [("1", "256"), ("1", "512"), ("1", "1024"), ("0", "256")])
+def test_dictionary_kernel_is_bit_identical_on_gpu(gpu_lib, monkeypatch, lds, block):
+    """k_spmv_dict (table in LDS / read through the caches) against k_spmv on the same matrix: same bits, with and without
+    the fused p.Ap, single part and a part with interface rows (two launches: interface slices, interior slices)."""
+    monkeypatch.setenv("PCG_SPMV_DICT_LDS", lds)
+    monkeypatch.setenv("PCG_SPMV_DICT_BLOCK", block)
+    b = Brick(24, seed=0, n_types=2)
+    _check_identical(make_parts(b)[0], dot_exact=block == "256")
+    parts = make_parts(b, block_partition(b, 2, 1, 2))
+
+    class NoComm:
+        rank = 0
+        native = False
+        def make_hooks(self, op):
+            from pcg_mi355x import _lib
+            return _lib.CommHooks()
+        def reraise(self):
+            pass
+        def release_stream(self, p):
+            pass
+    _check_identical(parts[3], with_diag=False, dot_exact=block == "256", comm=NoComm())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["n9_p1", "n9_flag4", "oct_p1", "n17_p1"])
+def test_dictionary_solve_on_gpu(gpu_lib, case, monkeypatch):
+    """Whole solves: against the reference fixture, and - with the workgroup shape of k_spmv (256 threads: the partial sums
+    of the fused p.Ap are then grouped alike) - bit-identical to the plain format, iteration for iteration."""
+    import pcg_mi355x as pm
+    monkeypatch.setenv("PCG_SPMV_DICT_BLOCK", "256")
+    outs = {}
+    g = golden(case)
+    for kind in ("sell", "dict"):
+        _, parts = golden_cases.build_case(case)
+        P = parts[0]
+        pm.configure(comm=None, device=0, operator=kind)
+        try:
+            pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P, history=True)
+            info = P["_pcg_mi355x_info"]
+            outs[kind] = (info.history.copy(), P["Un"].copy())
+            check_solution_against_golden(g, info.flag, info.iter, info.relres, P["Un"], info.history,
+                                          tol_u=1e-8 if int(g["flag"]) == 0 else 1e-6)
+        finally:
+            P.pop("_pcg_mi355x_operator").close()
+            pm.configure(comm=None, device=0, operator="sell")
+    assert np.array_equal(outs["sell"][0], outs["dict"][0]) and np.array_equal(outs["sell"][1], outs["dict"][1])
+
+
+@pytest.mark.gpu
+def test_dictionary_at_1m_dof_on_gpu(gpu_lib):
+    """BASELINE configs[1] size: 1 M dof, ~420 distinct blocks among 9.2 M stored ones; operator vs the oracle's CPU mat-vec,
+    bit-identity with the plain format, and the dictionary's device footprint."""
+    from pcg_mi355x.operator import from_refmeshpart
+    b = Brick(70, seed=0)
+    P = make_parts(b)[0]
+    plain, dic = _pair(P)
+    try:
+        n_unique = dic.matrix_dictionary()
+        assert 0 < n_unique < 1000
+        x = np.random.default_rng(0).standard_normal(plain.n)
+        ya = plain.apply(x)
+        yb = dic.apply(x)
+        assert np.array_equal(ya, yb)
+        assert relerr(yb, pcg_oracle.matvec_local(P, x, use_c=True)) < 1e-13
+        bp, _ = plain.operator_cost()
+        bd, _ = dic.operator_cost()
+        assert bd < 0.1 * bp
+    finally:
+        plain.close(); dic.close()

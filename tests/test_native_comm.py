@@ -75,6 +75,16 @@ def test_real_rccl_world_size_1(gpu_lib, tmp_path):
         assert 0 < float(outs[0]["t_comm"]) < float(outs[0]["t_total"])
 
 
+def test_native_communicator_next_to_torch_nccl_process_group(gpu_lib, tmp_path):
+    """bench.py / pcg_mi355x.run at N > 1 keep torch.distributed (backend nccl = RCCL) as control plane while the engine
+    issues its own RCCL calls: both on ONE librccl instance in one process.  World size 1 on the one-GPU box: process-group
+    init with device_id, unique-id broadcast on it, native solve, barrier / all_gather_object afterwards, orderly teardown."""
+    r = subprocess.run([sys.executable, WORKER, "torchpg", "n9_p1", "ebe", str(tmp_path), "29733"], env=_env(False),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    _check("n9_p1", "ebe", tmp_path, 1)
+
+
 def test_real_rccl_send_recv_group_on_one_gpu(gpu_lib, tmp_path):
     """The exchange itself on real librccl: one rank whose part lists ITSELF as its neighbour (PCG_RCCL_ALLOW_SELF=1), so
     ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the communication stream and both fence events run on RCCL, not
