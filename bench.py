@@ -421,7 +421,8 @@ def main():
             dictionary = {"note": "the same assembled matrix, values replaced by a dictionary of its distinct 3x3 blocks held in LDS (lossless: "
                                   "the SpMV is bit-identical to the plain format); applies when the matrix has <= 65535 distinct blocks - "
                                   "pattern-based meshes, the reference's domain - otherwise the plain format stays",
-                          "distinct_blocks": nu, "value": args.steps / d["elapsed"], "unit": "iterations/s",
+                          "distinct_blocks": nu, "table": d["op"].matrix_dictionary_info(),
+                          "value": args.steps / d["elapsed"], "unit": "iterations/s",
                           "ms_per_step": d["elapsed"] / args.steps * 1e3, "operator_avg_ms": d["op_ms"], "operator_launches_timed": d["n_op"],
                           "standalone_spmv": d["standalone"], "solve": d["final"], "comm": d["comm"],
                           "roofline": {"kernel": "k_spmv_dict (SELL-64, 16-bit block index + column per stored block, table in LDS)",

@@ -77,7 +77,8 @@ void pcg_asm_destroy(pcg_asm *a);
  * rows_per_lane: SELL slice = 64*rows_per_lane block rows (1 or 2; 0 = library default), optionally OR-ed with
  *   PCG_FORMAT_DICTIONARY: store every stored block as a 2-byte index into a dictionary of the matrix's DISTINCT 3x3 blocks
  *   (compared bit by bit: lossless, the SpMV is bit-identical to the plain format) instead of its 72 bytes of values - 4 to
- *   6 bytes per block, the dictionary stays in LDS.  Pattern-based meshes (the reference's domain: a few element stiffness
+ *   6 bytes per block; the dictionary stays in LDS (its most frequent 1945 entries when it is larger, the rest is read
+ *   through the caches).  Pattern-based meshes (the reference's domain: a few element stiffness
  *   patterns scaled by a few material factors, partition_mesh.py:443-491) assemble to a few hundred distinct blocks whatever
  *   their size; a matrix with more than 65535 distinct blocks silently keeps the plain format (pcg_matrix_dictionary). */
 enum { PCG_FORMAT_DICTIONARY = 0x100 };
@@ -261,7 +262,9 @@ int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free
  * structures) and compute (flops of the un-padded operator): the denominators of the roofline report (bench.py). */
 int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply);
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
-int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique /* distinct blocks of the value dictionary; 0 = plain values */);
+/* n_unique: distinct blocks of the value dictionary (0 = plain values); n_in_lds (may be NULL): how many of them - the most
+ * frequent ones - the SpMV kernel keeps in LDS; lds_share (may be NULL): the share of the stored blocks those cover. */
+int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique, int64_t *n_in_lds, double *lds_share);
 /* single fused kernels on host vectors, for per-kernel parity tests */
 int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_diag, double beta, int32_t first);
 int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r,

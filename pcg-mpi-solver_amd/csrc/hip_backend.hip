@@ -250,10 +250,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
 // slices - and the lanes of a wave read their blocks from there (same index = one broadcast read; the kernel is bound by the
 // LDS read rate and the x gathers, not by HBM: 0.5 GB instead of 6.9 GB per launch at 10 M dof).  !LDSD: tables beyond the LDS
 // budget are read through L1/L2.
-template <bool DOT, bool COL16, bool LDSD, int BLK>
+// MIXED (with LDSD): the table is larger than LDS; its n_lds most frequent entries (the host orders the table by descending
+// frequency) are the LDS copy, a lane whose block is one of the others reads it through L1/L2 - a divergent branch that
+// costs nothing when no lane of the wave needs it.
+template <bool DOT, bool COL16, bool LDSD, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
                                                       const int *__restrict__ colbase, const unsigned short *__restrict__ bidx,
-                                                      const double *__restrict__ dict, int n_unique,
+                                                      const double *__restrict__ dict, int n_lds,
                                                       const double *__restrict__ x, double *__restrict__ y,
                                                       const uint8_t *__restrict__ flags, double *__restrict__ partials,
                                                       int64_t slice_lo, int64_t slice_hi, int64_t n_nodes)
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ s
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int WPB = BLK / 64;                              // waves per workgroup: they share one copy of the table
     if constexpr (LDSD) {
-        for (int i = threadIdx.x; i < 9 * n_unique; i += BLK) sdict[10 * (i / 9) + i % 9] = dict[i];
+        for (int i = threadIdx.x; i < 9 * n_lds; i += BLK) sdict[10 * (i / 9) + i % 9] = dict[i];
         __syncthreads();
     }
     const int64_t wstride = (int64_t)gridDim.x * WPB;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ s
             if constexpr (COL16) j += cb;
             const int id = ntload(ip + (size_t)k * 64);
             double v[9];
-            if constexpr (LDSD) {
+            if (LDSD && (!MIXED || id < n_lds)) {
                 const double2 *e2 = reinterpret_cast<const double2 *>(sdict + 10 * id);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const double2 t = e2[c]; v[2 * c] = t.x; v[2 * c + 1] = t.y; }
@@ -1769,8 +1772,33 @@ public:
             d_dict_ = (double *)alloc(sizeof(double) * std::max<size_t>(9, m.dict.size()));
             h2d(d_bidx_, m.bidx.data(), sizeof(unsigned short) * m.bidx.size());
             h2d(d_dict_, m.dict.data(), sizeof(double) * m.dict.size());
-            dict_lds_ = (size_t)n_unique_ * 80 <= kDictLdsBytes;
-            if (const char *e = getenv("PCG_SPMV_DICT_LDS")) dict_lds_ = dict_lds_ && atoi(e) != 0;
+            dict_lds_ = true;
+            if (const char *e = getenv("PCG_SPMV_DICT_LDS")) dict_lds_ = atoi(e) != 0;
+            n_lds_ = dict_lds_ ? n_unique_ : 0;
+            dict_mixed_ = false;
+            if (dict_lds_ && (size_t)n_unique_ * 80 > kDictLdsBytes) {
+                // larger than a workgroup's default LDS window: ONE 1024-thread workgroup per CU (16 waves share the copy)
+                // with up to kDictLdsBytesMax of the table's head; the tail is read through the caches (k_spmv_dict MIXED)
+                n_lds_ = (int)std::min<size_t>((size_t)n_unique_, kDictLdsBytesMax / 80);
+                dict_mixed_ = n_lds_ < n_unique_;
+                if (const char *e = getenv("PCG_SPMV_DICT_LDS_ENTRIES")) {        // tests: force a small head
+                    n_lds_ = std::max(1, std::min(n_unique_, atoi(e)));
+                    dict_mixed_ = n_lds_ < n_unique_;
+                }
+                const int bytes = (int)kDictLdsBytesMax;
+                auto raise = [&](const void *fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); };
+                raise((const void *)k_spmv_dict<true, true, true, 1024, true>);   raise((const void *)k_spmv_dict<false, true, true, 1024, true>);
+                raise((const void *)k_spmv_dict<true, false, true, 1024, true>);  raise((const void *)k_spmv_dict<false, false, true, 1024, true>);
+                raise((const void *)k_spmv_dict<true, true, true, 1024, false>);  raise((const void *)k_spmv_dict<false, true, true, 1024, false>);
+                raise((const void *)k_spmv_dict<true, false, true, 1024, false>); raise((const void *)k_spmv_dict<false, false, true, 1024, false>);
+                dict_big_ = true;
+            } else if (dict_lds_) {
+                if (const char *e = getenv("PCG_SPMV_DICT_LDS_ENTRIES")) {
+                    n_lds_ = std::max(1, std::min(n_unique_, atoi(e)));
+                    dict_mixed_ = n_lds_ < n_unique_;
+                    if (dict_mixed_) dict_big_ = true;                            // the MIXED kernel exists for 1024 threads only
+                }
+            }
         } else {
             h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
         }
@@ -2082,33 +2110,38 @@ public:
     double *d_dict_ = nullptr;
     int n_unique_ = 0;
     bool dict_lds_ = false;
-    // Workgroup size of the dictionary kernel: every workgroup holds one copy of the table in LDS, so larger workgroups
+    // Workgroup size of the dictionary kernel: every workgroup holds one copy of the table (head) in LDS, so larger workgroups
     // put more waves behind one copy.  0 = automatic: 256 threads while four copies fit next to each other on a CU
-    // (tables up to ~40 KB), else 512.  PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 1024).
+    // (tables up to ~40 KB), else 512; tables beyond kDictLdsBytes: 1024 threads, one workgroup per CU.
+    // PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 1024) for tables within kDictLdsBytes.
     int dict_block_ = 0;
+    static constexpr size_t kDictLdsBytesMax = 152 * 1024;   // of the CU's 160 KB (1945 entries)
+    int n_lds_ = 0;                                           // entries of the LDS copy (all of them unless dict_mixed_)
+    bool dict_mixed_ = false, dict_big_ = false;
+    int64_t dict_lds_entries() const override { return n_lds_; }
     template <bool COL16>
     void launch_spmv_dict(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
-        const size_t lds = dict_lds_ ? (size_t)n_unique_ * 80 : 0;          // entries padded to 80 B in LDS
+        const size_t lds = dict_lds_ ? (size_t)n_lds_ * 80 : 0;            // entries padded to 80 B in LDS
         const int64_t fit = lds ? std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds + 128))) : 8;     // copies per CU (160 KB LDS)
-        int blk = dict_block_ ? dict_block_ : (fit >= 4 ? 256 : 512);
+        int blk = dict_big_ ? 1024 : (dict_block_ ? dict_block_ : (fit >= 4 ? 256 : 512));
         // workgroups per CU: what LDS leaves room for, and at most 16 waves per CU in flight (95 VGPRs: 5 per SIMD)
         const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(fit, (blk == 256 ? spmv_blocks_per_cu_ : 1024 / blk)));
         const int wpb = blk / 64;
         int64_t g = std::min<int64_t>((hi - lo + wpb - 1) / wpb, std::min<int64_t>((int64_t)n_cu_ * per_cu, kMaxPartials));
         g = std::max<int64_t>(8, (g + 7) / 8 * 8);
         grid = (int)g;
-#define PCG_LAUNCH_DICT(D, L, B)                                                                                                  \
-        hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols, d_colbase_, d_bidx_,   \
-                           d_dict_, n_unique_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_)
-#define PCG_LAUNCH_DICT_B(B)                                                                                                      \
+#define PCG_LAUNCH_DICT(D, L, B, M)                                                                                               \
+        hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B, M>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols, d_colbase_, d_bidx_, \
+                           d_dict_, n_lds_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_)
+#define PCG_LAUNCH_DICT_B(B, M)                                                                                                   \
         do {                                                                                                                      \
-            if (dot) { if (lds) PCG_LAUNCH_DICT(true, true, B); else PCG_LAUNCH_DICT(true, false, B); }                           \
-            else { if (lds) PCG_LAUNCH_DICT(false, true, B); else PCG_LAUNCH_DICT(false, false, B); }                             \
+            if (dot) { if (lds) PCG_LAUNCH_DICT(true, true, B, M); else PCG_LAUNCH_DICT(true, false, B, false); }                 \
+            else { if (lds) PCG_LAUNCH_DICT(false, true, B, M); else PCG_LAUNCH_DICT(false, false, B, false); }                   \
         } while (0)
-        if (blk == 1024) PCG_LAUNCH_DICT_B(1024);
-        else if (blk == 512) PCG_LAUNCH_DICT_B(512);
-        else PCG_LAUNCH_DICT_B(256);
+        if (blk == 1024) { if (dict_mixed_) PCG_LAUNCH_DICT_B(1024, true); else PCG_LAUNCH_DICT_B(1024, false); }
+        else if (blk == 512) PCG_LAUNCH_DICT_B(512, false);
+        else PCG_LAUNCH_DICT_B(256, false);
 #undef PCG_LAUNCH_DICT_B
 #undef PCG_LAUNCH_DICT
         last_spmv_grid_ = grid;

@@ -49,6 +49,8 @@ struct pcg_engine {
     int64_t n_bnd_dofs = 0;           // dofs [0, n_bnd_dofs) may receive interface contributions
     int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
     int64_t n_unique = 0;             // distinct 3x3 blocks when the values are dictionary-compressed (0: plain values)
+    int64_t n_dict_lds = 0;           // ... of which the SpMV kernel keeps the most frequent ones in LDS
+    double dict_lds_share = 0;        // ... share of the stored blocks those cover
     int32_t n_colors = 0;
     int64_t n_chunks = 0;
     double op_bytes = 0, op_flops = 0;    // what one local operator apply has to move / compute (stored structures)
@@ -469,6 +471,12 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         // once, the slice pointers
         const int cb = e->be->col_index_bytes();
         e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
+        if (e->n_unique > 0) {
+            e->n_dict_lds = std::min<int64_t>(e->n_unique, e->be->dict_lds_entries());
+            double hot = 0, all = 0;
+            for (int64_t i = 0; i < e->n_unique; ++i) { all += (double)m.dict_count[i]; if (i < e->n_dict_lds) hot += (double)m.dict_count[i]; }
+            e->dict_lds_share = all > 0 ? hot / all : 0;
+        }
         if (e->n_unique > 0)                                // dictionary format: a 2-byte index instead of the 72 bytes of values
             e->op_bytes = (2.0 + cb) * (double)e->stored_blocks + 72.0 * (double)e->n_unique + 16.0 * (double)e->n +
                           (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
@@ -999,10 +1007,12 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
 }
 
 // ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
-int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique)
+int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique, int64_t *n_in_lds, double *lds_share)
 {
     if (!e || !n_unique) return set_error("pcg_matrix_dictionary: null");
     *n_unique = e->kind == 0 ? e->n_unique : 0;
+    if (n_in_lds) *n_in_lds = e->kind == 0 ? e->n_dict_lds : 0;
+    if (lds_share) *lds_share = e->kind == 0 ? e->dict_lds_share : 0;
     return 0;
 }
 

@@ -35,7 +35,8 @@ struct SellHost {
     // Value dictionary (compress_blocks): the 9 values of stored block q = (slice_ptr[s] + k) * C + lane are
     // dict[9 * bidx[q] .. +9) (row-major 3x3) and `vals` is empty - 2 bytes per stored block instead of 72.
     std::vector<uint16_t> bidx;
-    std::vector<double> dict;
+    std::vector<double> dict;             // most frequent block first
+    std::vector<int64_t> dict_count;      // stored blocks per entry (descending)
     int64_t n_unique() const { return (int64_t)(dict.size() / 9); }
 };
 
@@ -48,7 +49,7 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
 // bit pattern: lossless).  Pattern-based meshes - the reference's domain: a few element stiffness patterns scaled by a few
 // material factors (partition_mesh.py:443-491) - assemble to a few hundred distinct blocks however large the mesh is.
 // Returns false and leaves `m` unchanged when there are more than max_unique (<= 65535) of them.  The dictionary is sorted
-// by bit pattern, i.e. independent of the thread count.
+// by descending frequency (ties by bit pattern), i.e. independent of the thread count.
 bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads);
 
 // ---- matrix-free (element-by-element) operator ------------------------------------------------
@@ -176,6 +177,7 @@ public:
     virtual bool ebe_can_split() const = 0;
     virtual void reload_tuning() {}                        // re-read the environment switches a solve may be A/B-tested with
     virtual int col_index_bytes() const { return 4; }      // bytes per stored block column after upload_matrix (2: 16-bit offsets)
+    virtual int64_t dict_lds_entries() const { return 0; } // value dictionary: leading entries the SpMV kernel keeps in LDS
     virtual void upload_masks(const uint8_t *flags, int64_t n) = 0;
     virtual void upload_halo(const HaloHost &h) = 0;
 

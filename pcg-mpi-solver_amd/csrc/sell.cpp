@@ -108,11 +108,13 @@ bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, m.n_slices / 64 + 1));
     std::vector<uint16_t> bidx((size_t)tot * C);
     std::vector<std::vector<BlockKey>> local((size_t)nt);              // thread t's distinct blocks, by local id
+    std::vector<std::vector<int64_t>> local_cnt((size_t)nt);           // ... and how often each occurs in t's slices
     std::vector<char> failed((size_t)nt, 0);
     const int64_t chunk = (m.n_slices + nt - 1) / nt;
     auto scan = [&](int t) {
         std::unordered_map<BlockKey, uint32_t, BlockHash> tab;
         auto &dict = local[t];
+        auto &cnt = local_cnt[t];
         BlockKey tile[64];
         const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
         for (int64_t q = m.slice_ptr[s_lo]; q < m.slice_ptr[s_hi]; ++q) {      // q = (slice, k): 64 blocks, value-component major
@@ -129,8 +131,10 @@ bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
                     if ((int64_t)dict.size() >= max_unique) { failed[t] = 1; return; }
                     id = (uint32_t)dict.size();
                     dict.push_back(tile[l]);
+                    cnt.push_back(0);
                     tab.emplace(tile[l], id);
                 }
+                cnt[id] += 1;
                 bidx[(size_t)q * C + l] = (uint16_t)id;
             }
         }
@@ -148,11 +152,21 @@ bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
     std::sort(all.begin(), all.end());
     all.erase(std::unique(all.begin(), all.end()), all.end());
     if ((int64_t)all.size() > max_unique) return false;
+    // final order: most frequent block first (the device keeps the head of the table in LDS when the whole does not fit),
+    // ties by bit pattern - a function of the matrix alone, not of the thread count
+    std::vector<int64_t> count(all.size(), 0);
+    for (int t = 0; t < nt; ++t)
+        for (size_t i = 0; i < local[t].size(); ++i)
+            count[(size_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin())] += local_cnt[t][i];
+    std::vector<uint32_t> order(all.size()), rank(all.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
+    for (size_t r = 0; r < order.size(); ++r) rank[order[r]] = (uint32_t)r;
     std::vector<std::vector<uint16_t>> remap((size_t)nt);
     for (int t = 0; t < nt; ++t) {
         remap[t].resize(local[t].size());
         for (size_t i = 0; i < local[t].size(); ++i)
-            remap[t][i] = (uint16_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin());
+            remap[t][i] = (uint16_t)rank[(size_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin())];
     }
     auto apply = [&](int t) {
         const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
@@ -165,7 +179,11 @@ bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
         for (auto &x : th) x.join();
     }
     m.dict.resize(all.size() * 9);
-    for (size_t i = 0; i < all.size(); ++i) std::memcpy(&m.dict[i * 9], all[i].w, sizeof(all[i].w));
+    m.dict_count.resize(all.size());
+    for (size_t r = 0; r < order.size(); ++r) {
+        std::memcpy(&m.dict[r * 9], all[order[r]].w, sizeof(all[order[r]].w));
+        m.dict_count[r] = count[order[r]];
+    }
     m.bidx.swap(bidx);
     std::vector<double>().swap(m.vals);                                // the values now live in the dictionary only
     return true;

@@ -291,9 +291,14 @@ class Operator:
 
     def matrix_dictionary(self):
         """Distinct 3x3 blocks of the value dictionary (PCG_FORMAT_DICTIONARY); 0 = plain values."""
-        n = C.c_int64()
-        check(self._L.pcg_matrix_dictionary(self._h, C.byref(n)), "pcg_matrix_dictionary")
-        return n.value
+        return self.matrix_dictionary_info()["distinct_blocks"]
+
+    def matrix_dictionary_info(self):
+        """{"distinct_blocks", "in_lds": the most frequent entries the SpMV kernel keeps in LDS, "lds_share": the share of the
+        stored blocks those cover}."""
+        n, h, sh = C.c_int64(), C.c_int64(), C.c_double()
+        check(self._L.pcg_matrix_dictionary(self._h, C.byref(n), C.byref(h), C.byref(sh)), "pcg_matrix_dictionary")
+        return {"distinct_blocks": n.value, "in_lds": h.value, "lds_share": sh.value}
 
     def matrix_info(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()

@@ -41,6 +41,8 @@ def _check_identical(P, seed=3, with_diag=True, dot_exact=True, **kw):
         yb, db = _spmv_local(dic, x)
         assert np.array_equal(ya, yb)                                    # same values, same order: the same bits
         # the fused p.Ap: identical when the partial sums are grouped alike (same workgroup shape), else a different tree
+        if dot_exact and dic.matrix_dictionary() * 80 > 60 * 1024:      # a table beyond 60 KB runs 1024-thread workgroups whatever was asked
+            dot_exact = False
         assert da == db if dot_exact else abs(da - db) <= 1e-13 * np.dot(np.abs(x), np.abs(ya))
         if with_diag:                                                    # (diag() of a part with neighbours exchanges)
             assert np.array_equal(plain.diag(), dic.diag())
@@ -59,6 +61,16 @@ def test_dictionary_spmv_is_bit_identical_on_the_test_double(hostops, n_types):
     n_unique = _check_identical(make_parts(b)[0])
     # two material factors x a few stencil positions: a few hundred distinct blocks at most, whatever the mesh size
     assert n_unique < 1500 and n_unique < b.nnz // 9 // 4
+
+
+def test_dictionary_info_on_the_test_double(hostops):
+    from pcg_mi355x.operator import from_refmeshpart
+    op = from_refmeshpart(make_parts(Brick(7, seed=0))[0], kind="dict")
+    try:
+        info = op.matrix_dictionary_info()
+        assert info["distinct_blocks"] > 0 and info["in_lds"] == 0 and info["lds_share"] == 0     # the double has no LDS
+    finally:
+        op.close()
 
 
 def test_dictionary_size_does_not_grow_with_the_mesh(hostops):
@@ -165,6 +177,35 @@ def test_dictionary_kernel_is_bit_identical_on_gpu(gpu_lib, monkeypatch, lds, bl
         def release_stream(self, p):
             pass
     _check_identical(parts[3], with_diag=False, dot_exact=block == "256", comm=NoComm())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head", ["auto", "100"])
+def test_dictionary_larger_than_lds_on_gpu(gpu_lib, monkeypatch, head):
+    """A two-level octree mesh with hanging-node patterns has ~2200 distinct blocks (176 KB of table): the 1945 most frequent
+    stay in LDS (one 1024-thread workgroup per CU), the rest is read through the caches by the lanes that need it - and the
+    same with a head of only 100 entries, so that most waves take both branches.  Bit-identical to the plain format."""
+    from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
+    from pcg_mi355x.operator import from_refmeshpart
+    if head != "auto":
+        monkeypatch.setenv("PCG_SPMV_DICT_LDS_ENTRIES", head)
+    P = make_octree_parts(TwoLevelMesh(24, 24, 10, 4, seed=0), 1, axis=0)[0]
+    plain, dic = _pair(P)
+    try:
+        info = dic.matrix_dictionary_info()
+        assert info["distinct_blocks"] > 1945
+        assert info["in_lds"] == (1945 if head == "auto" else 100) and 0.5 < info["lds_share"] < 1.0
+        assert info["lds_share"] > (0.97 if head == "auto" else 0.5)        # frequency order: the head covers most stored blocks
+        x = np.random.default_rng(5).standard_normal(plain.n)
+        ya, da = _spmv_local(plain, x)
+        yb, db = _spmv_local(dic, x)
+        assert np.array_equal(ya, yb)
+        assert abs(da - db) <= 1e-13 * np.dot(np.abs(x), np.abs(ya))
+        assert relerr(yb, pcg_oracle.matvec_local(P, x)) < 1e-14
+    finally:
+        plain.close(); dic.close()
+    if head == "100":                                                       # the brick's 693-entry table with a 100-entry head
+        _check_identical(make_parts(Brick(24, seed=0, n_types=2))[0], dot_exact=False)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """A/B of the assembled operator's storage formats on one GPU: plain SELL-BSR3 values vs the value dictionary
-(PCG_FORMAT_DICTIONARY, k_spmv_dict).  usage: python tools/dict_lab.py [N=150] [steps=200]"""
+(PCG_FORMAT_DICTIONARY, k_spmv_dict).  usage: python tools/dict_lab.py [N=150; 0 = the octree workload] [steps=200] [kinds=sell,dict]"""
 import os
 import sys
 import time
@@ -15,8 +15,12 @@ from pcg_mi355x.operator import from_refmeshpart
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["sell", "dict"]
-b = Brick(N, seed=0)
-P = make_parts(b)[0]
+if N == 0:                                                  # the bench's octree workload: two levels, hanging-node patterns
+    from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
+    P = make_octree_parts(TwoLevelMesh(96, 96, 40, 8, seed=0), 1, axis=0)[0]
+else:
+    b = Brick(N, seed=0)
+    P = make_parts(b)[0]
 ys = {}
 for kind in kinds:
     t0 = time.perf_counter()
@@ -39,7 +43,7 @@ for kind in kinds:
     op.solve_run(-1)
     xs, res = op.solve_end()
     t_rest = time.perf_counter() - t0
-    print(f"{kind:5s} N={N} dof={op.n} unique={op.matrix_dictionary()} setup {t_setup:.1f}s bytes/apply {by/1e9:.3f} GB | spmv standalone "
+    print(f"{kind:5s} N={N} dof={op.n} dict={op.matrix_dictionary_info()} setup {t_setup:.1f}s bytes/apply {by/1e9:.3f} GB | spmv standalone "
           f"median {np.median(ms):.4f} min {ms.min():.4f} ms | in-loop {r.spmv_ms_sum / max(1, r.spmv_count):.4f} ms | "
           f"{steps / dt:.0f} it/s ({dt / steps * 1e3:.4f} ms/it) | solve flag {res.flag} iter {res.iter} relres {res.relres:.3e} "
           f"({dt + t_rest:.2f}s for the rest)", flush=True)
