@@ -1626,11 +1626,12 @@ class HipBackend : public Backend {
     // bit 2: the vector kernels' streaming loads are non-temporal too: 845 / 3184 it/s.
     // bit 1: non-temporal y stores in k_spmv: no effect, off.  Results are bit-identical in every combination.
     int vec_nt_ = 5;
-    // Arrays of 32 MB and more are requested as physically contiguous VRAM (hipDeviceMallocContiguous; plain hipMalloc when
-    // that fails): on boxes whose free VRAM is fragmented the SpMV ran 2.7-4 % faster with it in alternating same-box
-    // processes (1.199 -> 1.151 ms, 1.186 -> 1.154 ms; profiles/r02_alloc_contiguous_ab.txt).  PCG_ALLOC_CONTIG=0 disables,
-    // =2 reports every such allocation on stderr.
-    int alloc_contig_ = 1;
+    // PCG_ALLOC_CONTIG=1: arrays of 32 MB and more are requested as physically contiguous VRAM (hipDeviceMallocContiguous; plain
+    // hipMalloc when that fails), =2 also reports every such allocation on stderr.  OFF by default: in alternating same-box
+    // processes it made the SpMV 2.7-4 % faster on one box (1.199 -> 1.151 ms, profiles/r02_alloc_contiguous_ab.txt), changed
+    // nothing on another (1.027 vs 1.039 ms) and made the matrix-free operator 17 % SLOWER there (3220 -> 2685 it/s at 10 M
+    // dof, twice each; profiles/r02_alloc_contiguous_ab.txt, session AN).
+    int alloc_contig_ = 0;
     // PCG_EBE_MFMA=1: hex8 chunks on the matrix cores (k_ebe_mfma) instead of the v_fma kernel (k_ebe_chunk).  Off by
     // default: measured 0.25 ms vs 0.20 ms per apply at 10 M dof - neither kernel is bound by its arithmetic
     // (profiles/r01_pmc_ebe_mfma.md).
