@@ -57,16 +57,43 @@ def test_package_does_not_import_oracle():
             assert "pcg_oracle" not in src and "import oracle" not in src and "ref_shim" not in src, f
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="solve_csr", double=False):
+    """gcc examples/<name>.c against the product library (or, double=True, the CPU test double: same C ABI)."""
     import subprocess
     from util import ROOT
-    import __graft_entry__
-    __graft_entry__.build_engine()
-    exe = str(tmp_path / "solve_csr")
-    libdir = os.path.join(ROOT, "pcg-mpi-solver_amd", "lib")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "solve_csr.c"),
-                           "-L" + libdir, "-lpcg_mi355x", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    if double:
+        import conftest
+        libdir, lib = os.path.dirname(conftest.build_hostops()), "pcg_hostops"
+    else:
+        import __graft_entry__
+        __graft_entry__.build_engine()
+        libdir, lib = os.path.join(ROOT, "pcg-mpi-solver_amd", "lib"), "pcg_mi355x"
+    exe = str(tmp_path / (name + ("_double" if double else "")))
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
+                           "-L" + libdir, "-l" + lib, "-Wl,-rpath," + libdir, "-lm", "-o", exe])
     return exe
+
+
+def test_group_c_example(tmp_path):
+    """examples/solve_group.c - pcg_group_* from plain C: a spring chain cut into G parts (interface nodes first, ownership
+    flags, neighbour lists as the reference's partitioner builds them), solved by ONE process, checked against its closed
+    form.  Links against the product library (and stops at the device check without a GPU); its logic runs here against
+    the CPU test double, which exports the same C ABI: 1, 2, 4 and 8 parts take the same number of iterations."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path, "solve_group", double=True)
+    its = set()
+    for g in ("1", "2", "4", "8"):
+        r = subprocess.run([exe, g, "193"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{g} part(s)" in r.stdout and "flag 0" in r.stdout
+        its.add(r.stdout.split(" iterations")[0].split()[-1])
+    assert len(its) == 1
+    assert subprocess.run([exe, "5", "193"], capture_output=True, text=True).returncode == 1       # 192 springs do not split into 5
+    prod = _build_c_example(tmp_path, "solve_group")
+    if not torch.cuda.is_available():
+        r = subprocess.run([prod, "2"], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
 
 
 def test_c_abi_from_plain_c_without_gpu(tmp_path):
