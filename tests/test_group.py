@@ -159,6 +159,29 @@ def test_group_load_step_driver_writes_the_n_rank_files(hostops, tmp_path):
     assert rec["dT_Calc"] > 0 and rec["dT_CommWait"] >= 0
 
 
+def test_run_cli_in_group_mode(hostops, tmp_path, capsys):
+    """`python -m pcg_mi355x.run --group --n-parts 3 --partition-prefix ...` (here in-process on the test double): the files
+    the reference's solver stage leaves behind - ResVecData/U_<k>, Dof, NodeId, Time_T and PlotData/TimeData with the
+    calc / comm-wait split averaged over the parts (file_operations.py:101-109)."""
+    from pcg_mi355x import io as pio, run as prun
+    _, parts = golden_cases.build_case("oct_p3")
+    g = golden("oct_p3")
+    prefix = str(tmp_path / "MPI" / "")
+    pio.write_partition(prefix, parts)
+    results = str(tmp_path / "Results_Run1")
+    prun.main(["--group", "--n-parts", "3", "--partition-prefix", prefix, "--results", results, "--operator", "dict"])
+    out = capsys.readouterr().out
+    assert ">calculation time:" in out and ">communication time:" in out
+    td = np.load(os.path.join(results, "PlotData", "TimeData.npz"))
+    assert int(td["Flag"][1]) == int(g["flag"]) and abs(int(td["Iter"][1]) - int(g["iter"])) <= 1
+    dof = pio.read_result_vector(os.path.join(results, "ResVecData", "Dof"))
+    u1 = pio.read_result_vector(os.path.join(results, "ResVecData", "U_1"))
+    assert len(np.unique(dof)) == len(dof) == len(g["Un"]) and relerr(u1, g["Un"][dof]) < 1e-7
+    assert float(td["CalcTime"]) > 0 and float(td["TotalTime"]) > 0
+    with pytest.raises(SystemExit, match="n-parts"):
+        prun.main(["--group", "--partition-prefix", prefix, "--results", results])
+
+
 def test_group_argument_errors(hostops):
     from pcg_mi355x.group import DeviceGroup
     from pcg_mi355x.operator import from_refmeshpart
