@@ -163,6 +163,31 @@ def cpu_baseline_single(part, budget_s=10.0):
             "matvec_ms": t_mv * 1e3}
 
 
+def scipy_csr_spmv_point(n_side=70):
+    """SURVEY 8(d), informational: scipy.sparse CSR `A @ x` on one host core for the assembled operator of the 1 M-dof brick
+    (the same generator, N = 70: 81 M non-zeros, 1 GB of CSR) - the CPU SpMV reference point in the algorithmic bytes
+    12 nnz + 20 n the GPU figure `csr_equivalent_GBps` uses.  Never part of the product path."""
+    import numpy as np
+    import scipy.sparse as sp
+    from pcg_mi355x.brick import Brick, make_parts
+    from pcg_mi355x.operator import assemble_bsr3
+    b = Brick(n_side, seed=0)
+    P = make_parts(b)[0]
+    rp, c, v = assemble_bsr3(P["SubDomainData"]["StrucDataList"], b.n_node)       # host code of the engine library (pcg_asm_*)
+    A = sp.bsr_matrix((v, c, rp), shape=(b.n_dof, b.n_dof)).tocsr()
+    del rp, c, v
+    x = np.random.default_rng(0).standard_normal(b.n_dof)
+    A @ x
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        A @ x
+        t.append(time.perf_counter() - t0)
+    ms = float(np.median(t)) * 1e3
+    return {"note": "scipy.sparse CSR A @ x, 1 thread, assembled 1 M-dof brick (N = 70) - informational CPU SpMV point",
+            "n": int(b.n_dof), "nnz": int(A.nnz), "ms": ms, "GBps_algorithmic": (12.0 * A.nnz + 20.0 * b.n_dof) / (ms * 1e-3) / 1e9}
+
+
 def cpu_baseline(part, N, ranks=0, workload="brick"):
     """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core."""
     import mp_baseline
@@ -170,6 +195,10 @@ def cpu_baseline(part, N, ranks=0, workload="brick"):
     single = cpu_baseline_single(part)
     out = {"kind": "port", "unit": "iterations/s", "host_cpu": _cpu_model(), "host_cores_available": avail,
            "single_core": single}
+    try:
+        out["scipy_csr_spmv"] = scipy_csr_spmv_point()
+    except Exception as ex:      # noqa: BLE001 - informational only
+        log(f"scipy CSR SpMV point failed: {ex!r}")
     R = ranks or min(avail, 64)
     if workload != "brick" or R < 2:
         out.update(value=single["value"], cores=1, sample=single["sample"])
