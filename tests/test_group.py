@@ -85,6 +85,50 @@ def test_group_is_bit_identical_to_one_thread_per_part_over_the_callback_seam(ho
         assert np.array_equal(A["Un"], B["Un"])
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_group_with_a_member_without_neighbours(hostops, kind):
+    """A disconnected component as its own part: the member takes part in every all-reduce but in no exchange - the native
+    exchange is point-to-point like the reference's Isend/Recv loops over an empty NbrMPIdVector (pcg_solver.py:318-328).
+    Against the oracle's run of the same three parts."""
+    import pcg_oracle
+    from pcg_mi355x.group import GroupSolver
+    from util import island_parts
+    ref = island_parts()
+    out = pcg_oracle.solve_step(ref)
+    parts = island_parts()
+    gs = GroupSolver(parts, operator=kind)
+    try:
+        gs.updateBC(); gs.updatePreconditioner(); gs.PCG()
+        i0 = parts[0]["_pcg_mi355x_info"]
+        assert i0.flag == out["flag"] == 0 and abs(i0.iter - out["iter"]) <= 1
+        for P, R in zip(parts, ref):
+            assert relerr(P["Un"], R["Un"]) < 1e-8
+        st = [c.stats() for c in gs.group.comms]
+        assert st[2]["n_halo"] == 0 and st[0]["n_halo"] > 0 and st[2]["n_allreduce"] == st[0]["n_allreduce"] > 0
+    finally:
+        gs.close()
+
+
+def test_group_of_one(hostops):
+    """A single member: no exchange, all-reduces over one rank - the fixture of the one-part run."""
+    parts, infos = _run_case_one()
+    assert len(parts) == 1
+
+
+def _run_case_one():
+    from pcg_mi355x.group import GroupSolver
+    _, parts = golden_cases.build_case("n9_p1")
+    g = golden("n9_p1")
+    gs = GroupSolver(parts)
+    try:
+        gs.updateBC(); gs.updatePreconditioner(); gs.PCG(history=True)
+        info = parts[0]["_pcg_mi355x_info"]
+        check_solution_against_golden(g, info.flag, info.iter, info.relres, parts[0]["Un"], info.history)
+        return parts, [info]
+    finally:
+        gs.close()
+
+
 def test_group_raises_where_the_reference_raises(hostops):
     """pcg_solver.py:549 raise Warning('PCG : TooSmallTolerance') - on every rank there, once for the group here."""
     from pcg_mi355x.group import GroupSolver
