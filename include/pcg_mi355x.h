@@ -84,6 +84,11 @@ void pcg_asm_destroy(pcg_asm *a);
 enum { PCG_FORMAT_DICTIONARY = 0x100 };
 int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols,
                const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
+/* The same engine straight from the host assembler: no 3x3-block CSR copy in the caller's hands; with PCG_FORMAT_DICTIONARY
+ * the 72-byte values are never materialised - every row is produced once, hashed and stored as indices (6 bytes of host
+ * memory per stored block instead of 2 x 76; a 100 M-dof operator is 5 GB on the host and 3.7 GB on the device).
+ * The operator is bit-identical to pcg_asm_fill() -> pcg_create(). */
+int pcg_create_asm(int32_t device, const pcg_asm *a, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
 /* The same engine from an already assembled scalar CSR matrix (i64 row pointer, i32 columns, f64 values).
  * block = 0/3: n = 3 * nodes rows (dof = 3*node + dir) grouped into 3x3 blocks internally (the fast format);
  * block = 1:   the scalar format is kept (any n; one f64 + one i32 per non-zero = the literal CSR traffic).
@@ -262,6 +267,10 @@ int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free
  * structures) and compute (flops of the un-padded operator): the denominators of the roofline report (bench.py). */
 int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply);
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
+/* FNV-1a over the host-side operator arrays (slice pointers, columns, values or indices + table, diagonal), recorded at
+ * creation when the environment has PCG_MATRIX_FINGERPRINT (0 otherwise): lets tests assert that two construction paths
+ * produce the same operator. */
+int pcg_matrix_fingerprint(pcg_engine *e, uint64_t *out);
 /* n_unique: distinct blocks of the value dictionary (0 = plain values); n_in_lds (may be NULL): how many of them - the most
  * frequent ones - the SpMV kernel keeps in LDS; lds_share (may be NULL): the share of the stored blocks those cover. */
 int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique, int64_t *n_in_lds, double *lds_share);

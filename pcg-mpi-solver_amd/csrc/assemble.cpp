@@ -38,6 +38,12 @@ struct Assembler {
     std::vector<int32_t> cols;       // pattern (sorted per row)
 };
 
+}  // namespace pcg
+
+struct pcg_asm { pcg::Assembler a; };
+
+namespace pcg {
+
 template <class F>
 static void parallel_for(int64_t n, int n_threads, F f, int64_t serial_below = 1024)
 {
@@ -154,48 +160,138 @@ static int build(Assembler &A, int32_t n_groups, const pcg_elem_group *gs, const
     return 0;
 }
 
+// the blocks of row i (its columns are A.cols[rowptr[i] .. rowptr[i+1])) -> rv (9 doubles per block, row-major 3x3);
+// contributions summed in ascending (group, element, local row slot, local col slot) order
+static void fill_row(const Assembler &A, int64_t i, double *rv, std::vector<int> &pos)
+{
+    const int64_t r0 = A.rowptr[i], r1 = A.rowptr[i + 1];
+    const int32_t *rc = &A.cols[r0];
+    std::memset(rv, 0, sizeof(double) * 9 * (size_t)(r1 - r0));
+    for (int64_t k = A.adj_ptr[i]; k < A.adj_ptr[i + 1]; ++k) {
+        const auto &G = A.groups[A.adj_g[k]];
+        const int64_t e = A.adj_e[k];
+        const int nd = G.nd;
+        const int32_t *en = &G.node[(size_t)e * nd];
+        const uint8_t *ed = &G.dir[(size_t)e * nd];
+        const uint8_t *es = &G.sgn[(size_t)e * nd];
+        const double ck = G.ck[e];
+        pos.resize(nd);
+        for (int b = 0; b < nd; ++b)
+            pos[b] = (int)(std::lower_bound(rc, rc + (r1 - r0), en[b]) - rc);
+        for (int a = 0; a < nd; ++a) {
+            if (en[a] != (int32_t)i) continue;
+            const double *krow = &G.ke[(size_t)a * nd];
+            const int da = ed[a];
+            for (int b = 0; b < nd; ++b) {
+                double v = ck * krow[b];                     // Ck_e * Ke[a,b]
+                if (es[a] != es[b]) v = -v;                  // S_e ... S_e  (exact)
+                rv[(size_t)pos[b] * 9 + da * 3 + ed[b]] += v;
+            }
+        }
+    }
+}
+
+static void fill_values(const Assembler &A, double *vals)
+{
+    parallel_for(A.n_nodes, A.n_threads, [&](int64_t lo, int64_t hi) {
+        std::vector<int> pos;          // column position of each slot of the current element
+        for (int64_t i = lo; i < hi; ++i) fill_row(A, i, vals + A.rowptr[i] * 9, pos);
+    });
+}
+
 static void fill(const Assembler &A, int32_t *cols, double *vals)
 {
-    const int64_t nn = A.n_nodes;
     std::memcpy(cols, A.cols.data(), A.cols.size() * sizeof(int32_t));
-    parallel_for(nn, A.n_threads, [&](int64_t lo, int64_t hi) {
-        std::vector<int> pos;          // column position of each slot of the current element
-        for (int64_t i = lo; i < hi; ++i) {
-            const int64_t r0 = A.rowptr[i], r1 = A.rowptr[i + 1];
-            const int32_t *rc = &A.cols[r0];
-            double *rv = vals + r0 * 9;
-            std::memset(rv, 0, sizeof(double) * 9 * (size_t)(r1 - r0));
-            for (int64_t k = A.adj_ptr[i]; k < A.adj_ptr[i + 1]; ++k) {
-                const auto &G = A.groups[A.adj_g[k]];
-                const int64_t e = A.adj_e[k];
-                const int nd = G.nd;
-                const int32_t *en = &G.node[(size_t)e * nd];
-                const uint8_t *ed = &G.dir[(size_t)e * nd];
-                const uint8_t *es = &G.sgn[(size_t)e * nd];
-                const double ck = G.ck[e];
-                pos.resize(nd);
-                for (int b = 0; b < nd; ++b)
-                    pos[b] = (int)(std::lower_bound(rc, rc + (r1 - r0), en[b]) - rc);
-                for (int a = 0; a < nd; ++a) {
-                    if (en[a] != (int32_t)i) continue;
-                    const double *krow = &G.ke[(size_t)a * nd];
-                    const int da = ed[a];
-                    for (int b = 0; b < nd; ++b) {
-                        double v = ck * krow[b];                     // Ck_e * Ke[a,b]
-                        if (es[a] != es[b]) v = -v;                  // S_e ... S_e  (exact)
-                        rv[(size_t)pos[b] * 9 + da * 3 + ed[b]] += v;
+    fill_values(A, vals);
+}
+
+void asm_views(const pcg_asm *a, int64_t *n_nodes, const int64_t **rowptr, const int32_t **cols)
+{
+    *n_nodes = a->a.n_nodes;
+    *rowptr = a->a.rowptr.data();
+    *cols = a->a.cols.data();
+}
+
+void asm_fill_values(const pcg_asm *a, double *vals) { fill_values(a->a, vals); }
+
+bool asm_to_sell_dict(const pcg_asm *h, int64_t n_boundary_nodes, int64_t max_unique, SellHost &out)
+{
+    const Assembler &A = h->a;
+    const int C = 64;
+    const int64_t nn = A.n_nodes;
+    max_unique = std::min<int64_t>(max_unique, 65535);
+    out = SellHost();
+    out.n_nodes = nn;
+    out.C = C;
+    out.n_slices = (nn + C - 1) / C;
+    out.nnzb = A.rowptr[nn];
+    out.n_bnd_slices = std::min<int64_t>(out.n_slices, (n_boundary_nodes + C - 1) / C);
+    out.slice_ptr.assign(out.n_slices + 1, 0);
+    for (int64_t s = 0; s < out.n_slices; ++s) {
+        int64_t w = 0;
+        for (int64_t r = s * C; r < std::min<int64_t>(nn, (s + 1) * C); ++r) w = std::max<int64_t>(w, A.rowptr[r + 1] - A.rowptr[r]);
+        out.slice_ptr[s + 1] = out.slice_ptr[s] + w;
+    }
+    const int64_t tot = out.slice_ptr[out.n_slices];
+    out.cols.assign((size_t)tot * C, 0);
+    out.diag.assign((size_t)nn * 3, 0.0);
+    std::vector<uint16_t> bidx((size_t)tot * C);
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(A.n_threads, out.n_slices / 64 + 1));
+    std::vector<BlockTable> local((size_t)nt, BlockTable(max_unique));
+    std::vector<std::pair<size_t, size_t>> slots((size_t)nt);
+    std::vector<char> failed((size_t)nt, 0);
+    const int64_t chunk = (out.n_slices + nt - 1) / nt;
+    auto work = [&](int t) {
+        BlockTable &tab = local[t];
+        std::vector<int> pos;
+        std::vector<double> rv;
+        BlockKey key, zero;
+        std::memset(zero.w, 0, sizeof(zero.w));
+        const int64_t s_lo = std::min(out.n_slices, t * chunk), s_hi = std::min(out.n_slices, s_lo + chunk);
+        slots[t] = {(size_t)out.slice_ptr[s_lo] * C, (size_t)out.slice_ptr[s_hi] * C};
+        for (int64_t s = s_lo; s < s_hi; ++s) {
+            const int64_t base = out.slice_ptr[s], w = out.slice_ptr[s + 1] - base;
+            for (int l = 0; l < C; ++l) {
+                const int64_t r = s * C + l;
+                const bool live = r < nn;
+                const int64_t r0 = live ? A.rowptr[r] : 0, len = live ? A.rowptr[r + 1] - r0 : 0;
+                if (live) {
+                    rv.resize((size_t)std::max<int64_t>(1, len) * 9);
+                    fill_row(A, r, rv.data(), pos);
+                }
+                for (int64_t k = 0; k < w; ++k) {
+                    const size_t ci = (size_t)(base + k) * C + l;
+                    const BlockKey *kp = &zero;                    // padding: value 0, a valid column NEAR the slice (as bsr_to_sell)
+                    if (k < len) {
+                        out.cols[ci] = A.cols[r0 + k];
+                        std::memcpy(key.w, &rv[(size_t)k * 9], sizeof(key.w));
+                        kp = &key;
+                        if (A.cols[r0 + k] == r)
+                            for (int a = 0; a < 3; ++a) out.diag[(size_t)r * 3 + a] = rv[(size_t)k * 9 + a * 3 + a];
+                    } else {
+                        out.cols[ci] = (int32_t)(live ? r : nn - 1);
                     }
+                    const int32_t id = tab.add(*kp);
+                    if (id < 0) { failed[t] = 1; return; }
+                    bidx[ci] = (uint16_t)id;
                 }
             }
         }
-    });
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (char f : failed)
+        if (f) return false;
+    return finish_dictionary(out, local, slots, bidx, max_unique);
 }
 
 }  // namespace pcg
 
 using namespace pcg;
-
-struct pcg_asm { Assembler a; };
 
 extern "C" {
 

@@ -51,6 +51,7 @@ struct pcg_engine {
     int64_t n_unique = 0;             // distinct 3x3 blocks when the values are dictionary-compressed (0: plain values)
     int64_t n_dict_lds = 0;           // ... of which the SpMV kernel keeps the most frequent ones in LDS
     double dict_lds_share = 0;        // ... share of the stored blocks those cover
+    uint64_t fingerprint = 0;         // FNV-1a of the host SELL arrays when PCG_MATRIX_FINGERPRINT is set (tests)
     int32_t n_colors = 0;
     int64_t n_chunks = 0;
     double op_bytes = 0, op_flops = 0;    // what one local operator apply has to move / compute (stored structures)
@@ -430,6 +431,74 @@ const char *pcg_last_error(void) { return last_error_string().c_str(); }
 const char *pcg_backend_name(void) { return backend_static_name(); }
 int pcg_device_count(void) { return backend_device_count(); }
 
+// everything after the SELL build: upload, byte accounting, status block, default masks
+static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine **out)
+{
+    const int64_t n_nodes = m.n_nodes;
+    e->n_unique = m.n_unique();
+    e->n_nodes = n_nodes;
+    e->n = 3 * n_nodes;
+    e->n_slices = m.n_slices;
+    e->n_bnd_slices = m.n_bnd_slices;
+    e->n_bnd_dofs = std::min<int64_t>(3 * n_nodes, m.n_bnd_slices * m.C * 3);
+    e->C = m.C;
+    e->nnzb = m.nnzb;
+    e->stored_blocks = m.slice_ptr.back() * m.C;
+    e->op_flops = 18.0 * (double)m.nnzb;
+    if (std::getenv("PCG_MATRIX_FINGERPRINT")) {            // tests: two construction paths must produce the same operator
+        auto fnv = [](uint64_t h, const void *p, size_t n) {
+            const unsigned char *b = (const unsigned char *)p;
+            for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+            return h;
+        };
+        uint64_t h = 0xcbf29ce484222325ull;
+        h = fnv(h, m.slice_ptr.data(), m.slice_ptr.size() * sizeof(int64_t));
+        h = fnv(h, m.cols.data(), m.cols.size() * sizeof(int32_t));
+        h = fnv(h, m.vals.data(), m.vals.size() * sizeof(double));
+        h = fnv(h, m.bidx.data(), m.bidx.size() * sizeof(uint16_t));
+        h = fnv(h, m.dict.data(), m.dict.size() * sizeof(double));
+        h = fnv(h, m.dict_count.data(), m.dict_count.size() * sizeof(int64_t));
+        h = fnv(h, m.diag.data(), m.diag.size() * sizeof(double));
+        e->fingerprint = h;
+    }
+    e->be->upload_matrix(m);
+    // 72 B of values + one column (4 B, or a 2 B offset + 4 B per slice) per stored 3x3 block, x read and y written
+    // once, the slice pointers
+    const int cb = e->be->col_index_bytes();
+    e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
+    if (e->n_unique > 0) {
+        e->n_dict_lds = std::min<int64_t>(e->n_unique, e->be->dict_lds_entries());
+        double hot = 0, all = 0;
+        for (int64_t i = 0; i < e->n_unique; ++i) { all += (double)m.dict_count[i]; if (i < e->n_dict_lds) hot += (double)m.dict_count[i]; }
+        e->dict_lds_share = all > 0 ? hot / all : 0;
+        // dictionary format: a 2-byte index instead of the 72 bytes of values
+        e->op_bytes = (2.0 + cb) * (double)e->stored_blocks + 72.0 * (double)e->n_unique + 16.0 * (double)e->n +
+                      (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
+    }
+    e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
+    e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+    e->be->set_status_block(e->d_st);
+    e->v_minv = e->vec();
+    // default masks: every dof owned and free
+    std::vector<uint8_t> f((size_t)e->n, 3);
+    e->be->upload_masks(f.data(), e->n);
+    *out = e.release();
+    return 0;
+}
+
+// format flag in rows_per_lane: bit 8 = replace the values by a dictionary of the matrix's distinct 3x3 blocks when there are
+// at most 65535 of them (lossless; k_spmv_dict); PCG_SPMV_DICT=0/1 overrides the caller either way
+static bool wants_dictionary(int32_t &rows_per_lane, int64_t &cap)
+{
+    bool want = (rows_per_lane & PCG_FORMAT_DICTIONARY) != 0;
+    if (const char *ev = std::getenv("PCG_SPMV_DICT")) want = std::atoi(ev) != 0;
+    rows_per_lane &= 0xff;
+    if (want) rows_per_lane = 1;                            // the dictionary kernel is written for 64-row slices
+    cap = 65535;
+    if (const char *ev = std::getenv("PCG_SPMV_DICT_MAX")) cap = std::max(1, std::atoi(ev));
+    return want;
+}
+
 int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, const double *vals,
                int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out)
 {
@@ -441,54 +510,42 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
             if (rowptr[i + 1] < rowptr[i]) return set_error("pcg_create: rowptr must be non-decreasing");
         for (int64_t k = 0; k < rowptr[n_nodes]; ++k)
             if (cols[k] < 0 || cols[k] >= n_nodes) return set_error("pcg_create: block column index out of range");
-        // format flag in rows_per_lane: bit 8 = replace the values by a dictionary of the matrix's distinct 3x3 blocks when
-        // there are at most 65535 of them (lossless; k_spmv_dict); PCG_SPMV_DICT=0/1 overrides the caller either way
-        bool want_dict = (rows_per_lane & PCG_FORMAT_DICTIONARY) != 0;
-        if (const char *ev = std::getenv("PCG_SPMV_DICT")) want_dict = std::atoi(ev) != 0;
-        rows_per_lane &= 0xff;
-        if (want_dict) rows_per_lane = 1;                   // the dictionary kernel is written for 64-row slices
+        int64_t cap;
+        const bool want_dict = wants_dictionary(rows_per_lane, cap);
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);                       // throws when no usable device: no fallback
         SellHost m;
         bsr_to_sell(n_nodes, rowptr, cols, vals, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
-        if (want_dict) {
-            int64_t cap = 65535;
-            if (const char *ev = std::getenv("PCG_SPMV_DICT_MAX")) cap = std::max(1, std::atoi(ev));
-            (void)compress_blocks(m, cap, 16);              // false: too many distinct blocks - the plain format stays
-        }
-        e->n_unique = m.n_unique();
-        e->n_nodes = n_nodes;
-        e->n = 3 * n_nodes;
-        e->n_slices = m.n_slices;
-        e->n_bnd_slices = m.n_bnd_slices;
-        e->n_bnd_dofs = std::min<int64_t>(3 * n_nodes, m.n_bnd_slices * m.C * 3);
-        e->C = m.C;
-        e->nnzb = m.nnzb;
-        e->stored_blocks = m.slice_ptr.back() * m.C;
-        e->op_flops = 18.0 * (double)m.nnzb;
-        e->be->upload_matrix(m);
-        // 72 B of values + one column (4 B, or a 2 B offset + 4 B per slice) per stored 3x3 block, x read and y written
-        // once, the slice pointers
-        const int cb = e->be->col_index_bytes();
-        e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
-        if (e->n_unique > 0) {
-            e->n_dict_lds = std::min<int64_t>(e->n_unique, e->be->dict_lds_entries());
-            double hot = 0, all = 0;
-            for (int64_t i = 0; i < e->n_unique; ++i) { all += (double)m.dict_count[i]; if (i < e->n_dict_lds) hot += (double)m.dict_count[i]; }
-            e->dict_lds_share = all > 0 ? hot / all : 0;
-        }
-        if (e->n_unique > 0)                                // dictionary format: a 2-byte index instead of the 72 bytes of values
-            e->op_bytes = (2.0 + cb) * (double)e->stored_blocks + 72.0 * (double)e->n_unique + 16.0 * (double)e->n +
-                          (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
-        e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
-        e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
-        e->be->set_status_block(e->d_st);
-        e->v_minv = e->vec();
-        // default masks: every dof owned and free
-        std::vector<uint8_t> f((size_t)e->n, 3);
-        e->be->upload_masks(f.data(), e->n);
-        *out = e.release();
-        return 0;
+        if (want_dict) (void)compress_blocks(m, cap, 16);   // false: too many distinct blocks - the plain format stays
+        return finish_create(std::move(e), m, out);
+    });
+}
+
+// The same engine straight from the host assembler (pcg_asm_create): no 3x3-block CSR copy in the caller's hands, and with
+// PCG_FORMAT_DICTIONARY the 72-byte values are never materialised at all - every row is produced once, hashed and stored
+// as indices (6 bytes of host memory per stored block instead of 2 x 76).  Bit-identical operator to
+// pcg_asm_fill -> pcg_create (tested through PCG_MATRIX_FINGERPRINT).
+int pcg_create_asm(int32_t device, const pcg_asm *a, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out)
+{
+    return guarded("pcg_create_asm", [&]() -> int {
+        if (!out || !a) return set_error("pcg_create_asm: bad argument");
+        int64_t n_nodes = 0;
+        const int64_t *rowptr = nullptr;
+        const int32_t *cols = nullptr;
+        asm_views(a, &n_nodes, &rowptr, &cols);
+        if (n_boundary_nodes < 0 || n_boundary_nodes > n_nodes) return set_error("pcg_create_asm: bad n_boundary_nodes");
+        int64_t cap;
+        const bool want_dict = wants_dictionary(rows_per_lane, cap);
+        auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
+        e->be = make_backend(device);
+        SellHost m;
+        if (want_dict && asm_to_sell_dict(a, n_boundary_nodes, cap, m)) return finish_create(std::move(e), m, out);
+        std::vector<double> vals((size_t)rowptr[n_nodes] * 9);                 // plain values (or too many distinct blocks)
+        asm_fill_values(a, vals.data());
+        m = SellHost();
+        bsr_to_sell(n_nodes, rowptr, cols, vals.data(), n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
+        std::vector<double>().swap(vals);
+        return finish_create(std::move(e), m, out);
     });
 }
 
@@ -1007,6 +1064,13 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
 }
 
 // ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
+int pcg_matrix_fingerprint(pcg_engine *e, uint64_t *out)
+{
+    if (!e || !out) return set_error("pcg_matrix_fingerprint: null");
+    *out = e->fingerprint;
+    return 0;
+}
+
 int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique, int64_t *n_in_lds, double *lds_share)
 {
     if (!e || !n_unique) return set_error("pcg_matrix_dictionary: null");

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "pcg_mi355x.h"
@@ -51,6 +53,35 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
 // Returns false and leaves `m` unchanged when there are more than max_unique (<= 65535) of them.  The dictionary is sorted
 // by descending frequency (ties by bit pattern), i.e. independent of the thread count.
 bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads);
+
+// Building blocks of the dictionary (shared by compress_blocks and the streaming assembler path, assemble.cpp).
+struct BlockKey {                     // the bit pattern of a 3x3 block
+    uint64_t w[9];
+    bool operator==(const BlockKey &o) const;
+    bool operator<(const BlockKey &o) const;
+};
+struct BlockHash { size_t operator()(const BlockKey &k) const; };
+class BlockTable {                    // one thread's distinct blocks in first-seen order, with their occurrence counts
+    std::unordered_map<BlockKey, uint32_t, BlockHash> tab_;
+    int64_t cap_;
+public:
+    explicit BlockTable(int64_t cap = 65535) : cap_(cap) {}
+    std::vector<BlockKey> keys;
+    std::vector<int64_t> count;
+    int32_t add(const BlockKey &k);   // local id, or -1 when the table would exceed its capacity
+};
+// bidx holds LOCAL ids, thread t having written the stored slots [slots[t].first, slots[t].second): merges the tables into
+// m.dict / m.dict_count (descending frequency, ties by bit pattern), rewrites bidx to final ids and moves it into m.bidx;
+// m.vals is released.  false (m untouched) when the union has more than max_unique entries.
+bool finish_dictionary(SellHost &m, std::vector<BlockTable> &local, const std::vector<std::pair<size_t, size_t>> &slots,
+                       std::vector<uint16_t> &bidx, int64_t max_unique);
+// SELL-64 + dictionary straight from the host assembler, row by row: the 72-byte values of the stored blocks are never
+// materialised (cols + 2-byte indices only: 6 B instead of 76 + 76 B of host memory per stored block).  Same SellHost as
+// pcg_asm_fill -> bsr_to_sell -> compress_blocks.  false (out unspecified) when there are more than max_unique distinct blocks.
+bool asm_to_sell_dict(const pcg_asm *a, int64_t n_boundary_nodes, int64_t max_unique, SellHost &out);
+// the assembled 3x3-block CSR arrays of a pcg_asm (views into it) / its values (pcg_asm_fill without the column copy)
+void asm_views(const pcg_asm *a, int64_t *n_nodes, const int64_t **rowptr, const int32_t **cols);
+void asm_fill_values(const pcg_asm *a, double *vals);
 
 // ---- matrix-free (element-by-element) operator ------------------------------------------------
 // The reference's own algorithm (pcg_solver.py:265-300): per element gather x, flip signs, multiply

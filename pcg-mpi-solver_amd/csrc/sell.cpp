@@ -71,106 +71,66 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
     }
 }
 
-namespace {
-
-struct BlockKey {
-    uint64_t w[9];
-    bool operator==(const BlockKey &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
-    bool operator<(const BlockKey &o) const
-    {
-        for (int c = 0; c < 9; ++c)
-            if (w[c] != o.w[c]) return w[c] < o.w[c];
-        return false;
-    }
-};
-struct BlockHash {
-    size_t operator()(const BlockKey &k) const
-    {
-        uint64_t h = 0x9e3779b97f4a7c15ull;
-        for (int c = 0; c < 9; ++c) {
-            h ^= k.w[c] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
-            h *= 0xff51afd7ed558ccdull;
-            h ^= h >> 33;
-        }
-        return (size_t)h;
-    }
-};
-
-}  // namespace
-
-bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
+bool BlockKey::operator==(const BlockKey &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+bool BlockKey::operator<(const BlockKey &o) const
 {
-    if (m.bs != 3 || m.C != 64) return false;
-    max_unique = std::min<int64_t>(max_unique, 65535);
-    const int C = m.C;
-    const int64_t tot = m.slice_ptr[m.n_slices];
-    if (m.vals.size() != (size_t)tot * C * 9) return false;
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, m.n_slices / 64 + 1));
-    std::vector<uint16_t> bidx((size_t)tot * C);
-    std::vector<std::vector<BlockKey>> local((size_t)nt);              // thread t's distinct blocks, by local id
-    std::vector<std::vector<int64_t>> local_cnt((size_t)nt);           // ... and how often each occurs in t's slices
-    std::vector<char> failed((size_t)nt, 0);
-    const int64_t chunk = (m.n_slices + nt - 1) / nt;
-    auto scan = [&](int t) {
-        std::unordered_map<BlockKey, uint32_t, BlockHash> tab;
-        auto &dict = local[t];
-        auto &cnt = local_cnt[t];
-        BlockKey tile[64];
-        const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
-        for (int64_t q = m.slice_ptr[s_lo]; q < m.slice_ptr[s_hi]; ++q) {      // q = (slice, k): 64 blocks, value-component major
-            for (int c = 0; c < 9; ++c) {
-                const double *v = &m.vals[((size_t)q * 9 + c) * C];
-                for (int l = 0; l < 64; ++l) std::memcpy(&tile[l].w[c], v + l, 8);
-            }
-            for (int l = 0; l < 64; ++l) {
-                auto it = tab.find(tile[l]);
-                uint32_t id;
-                if (it != tab.end()) {
-                    id = it->second;
-                } else {
-                    if ((int64_t)dict.size() >= max_unique) { failed[t] = 1; return; }
-                    id = (uint32_t)dict.size();
-                    dict.push_back(tile[l]);
-                    cnt.push_back(0);
-                    tab.emplace(tile[l], id);
-                }
-                cnt[id] += 1;
-                bidx[(size_t)q * C + l] = (uint16_t)id;
-            }
-        }
-    };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
-        scan(0);
-        for (auto &x : th) x.join();
+    for (int c = 0; c < 9; ++c)
+        if (w[c] != o.w[c]) return w[c] < o.w[c];
+    return false;
+}
+size_t BlockHash::operator()(const BlockKey &k) const
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (int c = 0; c < 9; ++c) {
+        h ^= k.w[c] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
     }
-    for (char f : failed)
-        if (f) return false;
+    return (size_t)h;
+}
+
+int32_t BlockTable::add(const BlockKey &k)
+{
+    auto it = tab_.find(k);
+    if (it != tab_.end()) {
+        count[it->second] += 1;
+        return (int32_t)it->second;
+    }
+    if ((int64_t)keys.size() >= cap_) return -1;
+    const uint32_t id = (uint32_t)keys.size();
+    keys.push_back(k);
+    count.push_back(1);
+    tab_.emplace(k, id);
+    return (int32_t)id;
+}
+
+bool finish_dictionary(SellHost &m, std::vector<BlockTable> &local, const std::vector<std::pair<size_t, size_t>> &slots,
+                       std::vector<uint16_t> &bidx, int64_t max_unique)
+{
+    const int nt = (int)local.size();
     std::vector<BlockKey> all;
-    for (const auto &d : local) all.insert(all.end(), d.begin(), d.end());
+    for (const auto &d : local) all.insert(all.end(), d.keys.begin(), d.keys.end());
     std::sort(all.begin(), all.end());
     all.erase(std::unique(all.begin(), all.end()), all.end());
     if ((int64_t)all.size() > max_unique) return false;
     // final order: most frequent block first (the device keeps the head of the table in LDS when the whole does not fit),
-    // ties by bit pattern - a function of the matrix alone, not of the thread count
+    // ties by bit pattern - a function of the matrix alone, not of the thread count or the scan order
     std::vector<int64_t> count(all.size(), 0);
     for (int t = 0; t < nt; ++t)
-        for (size_t i = 0; i < local[t].size(); ++i)
-            count[(size_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin())] += local_cnt[t][i];
+        for (size_t i = 0; i < local[t].keys.size(); ++i)
+            count[(size_t)(std::lower_bound(all.begin(), all.end(), local[t].keys[i]) - all.begin())] += local[t].count[i];
     std::vector<uint32_t> order(all.size()), rank(all.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
     for (size_t r = 0; r < order.size(); ++r) rank[order[r]] = (uint32_t)r;
     std::vector<std::vector<uint16_t>> remap((size_t)nt);
     for (int t = 0; t < nt; ++t) {
-        remap[t].resize(local[t].size());
-        for (size_t i = 0; i < local[t].size(); ++i)
-            remap[t][i] = (uint16_t)rank[(size_t)(std::lower_bound(all.begin(), all.end(), local[t][i]) - all.begin())];
+        remap[t].resize(local[t].keys.size());
+        for (size_t i = 0; i < local[t].keys.size(); ++i)
+            remap[t][i] = (uint16_t)rank[(size_t)(std::lower_bound(all.begin(), all.end(), local[t].keys[i]) - all.begin())];
     }
     auto apply = [&](int t) {
-        const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
-        for (size_t i = (size_t)m.slice_ptr[s_lo] * C, e = (size_t)m.slice_ptr[s_hi] * C; i < e; ++i) bidx[i] = remap[t][bidx[i]];
+        for (size_t i = slots[t].first; i < slots[t].second; ++i) bidx[i] = remap[t][bidx[i]];
     };
     {
         std::vector<std::thread> th;
@@ -187,6 +147,47 @@ bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
     m.bidx.swap(bidx);
     std::vector<double>().swap(m.vals);                                // the values now live in the dictionary only
     return true;
+}
+
+bool compress_blocks(SellHost &m, int64_t max_unique, int n_threads)
+{
+    if (m.bs != 3 || m.C != 64) return false;
+    max_unique = std::min<int64_t>(max_unique, 65535);
+    const int C = m.C;
+    const int64_t tot = m.slice_ptr[m.n_slices];
+    if (m.vals.size() != (size_t)tot * C * 9) return false;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, m.n_slices / 64 + 1));
+    std::vector<uint16_t> bidx((size_t)tot * C);
+    std::vector<BlockTable> local((size_t)nt, BlockTable(max_unique));
+    std::vector<std::pair<size_t, size_t>> slots((size_t)nt);
+    std::vector<char> failed((size_t)nt, 0);
+    const int64_t chunk = (m.n_slices + nt - 1) / nt;
+    auto scan = [&](int t) {
+        BlockTable &tab = local[t];
+        BlockKey tile[64];
+        const int64_t s_lo = std::min(m.n_slices, t * chunk), s_hi = std::min(m.n_slices, s_lo + chunk);
+        slots[t] = {(size_t)m.slice_ptr[s_lo] * C, (size_t)m.slice_ptr[s_hi] * C};
+        for (int64_t q = m.slice_ptr[s_lo]; q < m.slice_ptr[s_hi]; ++q) {      // q = (slice, k): 64 blocks, value-component major
+            for (int c = 0; c < 9; ++c) {
+                const double *v = &m.vals[((size_t)q * 9 + c) * C];
+                for (int l = 0; l < 64; ++l) std::memcpy(&tile[l].w[c], v + l, 8);
+            }
+            for (int l = 0; l < 64; ++l) {
+                const int32_t id = tab.add(tile[l]);
+                if (id < 0) { failed[t] = 1; return; }
+                bidx[(size_t)q * C + l] = (uint16_t)id;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+    }
+    for (char f : failed)
+        if (f) return false;
+    return finish_dictionary(m, local, slots, bidx, max_unique);
 }
 
 // scalar rows: the same slice layout with 1 value per entry (vals[(slice_ptr[s]+k)*C + lane]); duplicates summed

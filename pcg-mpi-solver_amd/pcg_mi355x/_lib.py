@@ -68,6 +68,7 @@ _SIGS = {
     "pcg_asm_fill": (C.c_int, [_P, _P, _P]),
     "pcg_asm_destroy": (None, [_P]),
     "pcg_create": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    "pcg_create_asm": (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "pcg_create_csr": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "pcg_create_ebe": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.POINTER(ElemGroup), _P, C.c_int64, _P, C.c_int32, C.POINTER(_P)]),
     "pcg_destroy": (None, [_P]),
@@ -114,6 +115,7 @@ _SIGS = {
     "pcg_operator_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "pcg_operator_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcg_matrix_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "pcg_matrix_fingerprint": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "pcg_matrix_dictionary": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pcg_k_update_p": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32]),
     "pcg_k_fused_update": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P, _P]),

@@ -109,6 +109,41 @@ class Operator:
         self.last_result = None
 
     @classmethod
+    def from_assembler(cls, groups, n_nodes, node_perm=None, n_boundary_nodes=0, dof_new_of_old=None, device=0, rows_per_lane=0,
+                       n_threads=0):
+        """Assembled operator straight from the reference's type-group tables through the native assembler (pcg_asm_create ->
+        pcg_create_asm): no 3x3-block CSR arrays on the Python side, and with rows_per_lane | FORMAT_DICTIONARY the values
+        are never materialised (rows are produced once, hashed and stored as table indices)."""
+        self = cls.__new__(cls)
+        L = _lib.lib()
+        arr, keep = _pack_groups(groups)
+        perm = None if node_perm is None else np.ascontiguousarray(node_perm, dtype=np.int64)
+        a = C.c_void_p()
+        check(L.pcg_asm_create(int(n_nodes), len(groups), arr, perm.ctypes.data if perm is not None else None, int(n_threads), C.byref(a)),
+              "pcg_asm_create")
+        h = C.c_void_p()
+        try:
+            nnzb = int(L.pcg_asm_nnzb(a))
+            check(L.pcg_create_asm(device, a, int(n_boundary_nodes), int(rows_per_lane), C.byref(h)), "pcg_create_asm")
+        finally:
+            L.pcg_asm_destroy(a)
+        del keep
+        self._L, self._h, self.kind = L, h, "sell"
+        self.n_nodes, self.n = int(n_nodes), 3 * int(n_nodes)
+        self._map = None if dof_new_of_old is None else np.ascontiguousarray(dof_new_of_old, dtype=np.int64)
+        self.nnzb, self.nnz = nnzb, 9 * nnzb
+        self._comm = self._hooks = None
+        self.glob_n_eff = None
+        self.last_result = None
+        return self
+
+    def matrix_fingerprint(self):
+        """FNV-1a of the host-side operator arrays (0 unless PCG_MATRIX_FINGERPRINT was set when the operator was built)."""
+        out = C.c_uint64()
+        check(self._L.pcg_matrix_fingerprint(self._h, C.byref(out)), "pcg_matrix_fingerprint")
+        return out.value
+
+    @classmethod
     def from_csr(cls, rowptr, cols, vals, device=0, block=0):
         """Engine operator from an assembled scalar CSR matrix (e.g. scipy.sparse.csr_matrix: indptr, indices,
         data), pcg_create_csr.  block = 0/3: n = 3*nodes rows regrouped into 3x3 node blocks (the fast format);
@@ -377,9 +412,14 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
         op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm,
                       node_coords=xyz, ebe_chunked=ebe_chunked)
     elif kind in ("sell", "dict"):
-        rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
-        op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device,
-                      int(rows_per_lane) | (_lib.FORMAT_DICTIONARY if kind == "dict" else 0))
+        fmt = int(rows_per_lane) | (_lib.FORMAT_DICTIONARY if kind == "dict" else 0)
+        # "dict": rows go from the assembler straight into the table format, the values are never materialised
+        # (pcg_create_asm); PCG_ASM_STREAM=0 / =1 forces the array path / the assembler path for either kind
+        if os.environ.get("PCG_ASM_STREAM", "1" if kind == "dict" else "0") == "1":
+            op = Operator.from_assembler(groups, n_nodes, node_perm, n_bnd, dof_map, device, fmt, n_threads)
+        else:
+            rowptr, cols, vals = assemble_bsr3(groups, n_nodes, node_perm, n_threads)
+            op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, fmt)
     else:
         raise ValueError(kind)
     w = np.asarray(part["DofWeightVector"], float)

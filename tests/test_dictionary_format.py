@@ -63,6 +63,60 @@ def test_dictionary_spmv_is_bit_identical_on_the_test_double(hostops, n_types):
     assert n_unique < 1500 and n_unique < b.nnz // 9 // 4
 
 
+@pytest.mark.parametrize("case,part", [("n9_p1", 0), ("n9_p8", 5), ("oct_p3", 1), ("n13_t3_p4_ud", 2), ("n17_p1", 0)])
+@pytest.mark.parametrize("kind", ["sell", "dict"])
+def test_assembler_path_builds_the_same_operator(hostops, monkeypatch, case, part, kind):
+    """pcg_create_asm (rows straight from the assembler; for "dict" the values are never materialised) against
+    pcg_asm_fill -> pcg_create -> compress_blocks: the same slice pointers, columns, values / indices + table (same order, same
+    counts) and diagonal - compared through a fingerprint of the host arrays - and the same SpMV bits."""
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_MATRIX_FINGERPRINT", "1")
+    _, parts = golden_cases.build_case(case)
+    P = parts[part]
+
+    class NoComm:
+        rank = 0
+        native = False
+        def make_hooks(self, op):
+            from pcg_mi355x import _lib
+            return _lib.CommHooks()
+        def reraise(self):
+            pass
+        def release_stream(self, p):
+            pass
+    comm = NoComm() if len(parts) > 1 else None
+    ops = []
+    for stream in ("0", "1"):
+        monkeypatch.setenv("PCG_ASM_STREAM", stream)
+        ops.append(from_refmeshpart(P, kind=kind, comm=comm))
+    try:
+        fa, fb = ops[0].matrix_fingerprint(), ops[1].matrix_fingerprint()
+        assert fa != 0 and fa == fb
+        assert ops[0].matrix_dictionary_info() == ops[1].matrix_dictionary_info()
+        assert (ops[0].nnzb, ops[0].matrix_info()) == (ops[1].nnzb, ops[1].matrix_info())
+        x = np.random.default_rng(2).standard_normal(ops[0].n)
+        ya, da = _spmv_local(ops[0], x)
+        yb, db = _spmv_local(ops[1], x)
+        assert np.array_equal(ya, yb) and da == db
+    finally:
+        for op in ops:
+            op.close()
+
+
+def test_assembler_path_falls_back_when_the_table_overflows(hostops, monkeypatch):
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_SPMV_DICT_MAX", "20")
+    monkeypatch.setenv("PCG_ASM_STREAM", "1")
+    P = make_parts(Brick(7, seed=0))[0]
+    op = from_refmeshpart(P, kind="dict")
+    try:
+        assert op.matrix_dictionary() == 0
+        x = np.random.default_rng(1).standard_normal(op.n)
+        assert relerr(_spmv_local(op, x)[0], pcg_oracle.matvec_local(P, x)) < 1e-14
+    finally:
+        op.close()
+
+
 def test_dictionary_info_on_the_test_double(hostops):
     from pcg_mi355x.operator import from_refmeshpart
     op = from_refmeshpart(make_parts(Brick(7, seed=0))[0], kind="dict")
