@@ -84,9 +84,10 @@ void pcg_asm_destroy(pcg_asm *a);
 enum { PCG_FORMAT_DICTIONARY = 0x100 };
 int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int32_t *cols,
                const double *vals, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
-/* The same engine straight from the host assembler: no 3x3-block CSR copy in the caller's hands; with PCG_FORMAT_DICTIONARY
- * the 72-byte values are never materialised - every row is produced once, hashed and stored as indices (6 bytes of host
- * memory per stored block instead of 2 x 76; a 100 M-dof operator is 5 GB on the host and 3.7 GB on the device).
+/* The same engine straight from the host assembler, slice by slice: every block row is produced once and written into the
+ * SELL layout, no 3x3-block CSR copy of the values in between; with PCG_FORMAT_DICTIONARY the 72-byte values are never
+ * materialised at all - the row's blocks are hashed and stored as indices (6 bytes of host memory per stored block instead
+ * of 2 x 76; a 100 M-dof operator is 5 GB on the host and 3.7 GB on the device).
  * The operator is bit-identical to pcg_asm_fill() -> pcg_create(). */
 int pcg_create_asm(int32_t device, const pcg_asm *a, int64_t n_boundary_nodes, int32_t rows_per_lane, pcg_engine **out);
 /* The same engine from an already assembled scalar CSR matrix (i64 row pointer, i32 columns, f64 values).

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -214,10 +215,12 @@ void asm_views(const pcg_asm *a, int64_t *n_nodes, const int64_t **rowptr, const
 
 void asm_fill_values(const pcg_asm *a, double *vals) { fill_values(a->a, vals); }
 
-bool asm_to_sell_dict(const pcg_asm *h, int64_t n_boundary_nodes, int64_t max_unique, SellHost &out)
+bool asm_to_sell(const pcg_asm *h, int64_t n_boundary_nodes, int32_t rows_per_lane, bool want_dict, int64_t max_unique, SellHost &out)
 {
     const Assembler &A = h->a;
-    const int C = 64;
+    if (want_dict) rows_per_lane = 1;
+    if (rows_per_lane != 1 && rows_per_lane != 2) throw std::runtime_error("rows_per_lane must be 1 or 2");
+    const int C = 64 * rows_per_lane;
     const int64_t nn = A.n_nodes;
     max_unique = std::min<int64_t>(max_unique, 65535);
     out = SellHost();
@@ -235,7 +238,8 @@ bool asm_to_sell_dict(const pcg_asm *h, int64_t n_boundary_nodes, int64_t max_un
     const int64_t tot = out.slice_ptr[out.n_slices];
     out.cols.assign((size_t)tot * C, 0);
     out.diag.assign((size_t)nn * 3, 0.0);
-    std::vector<uint16_t> bidx((size_t)tot * C);
+    std::vector<uint16_t> bidx(want_dict ? (size_t)tot * C : 0);
+    if (!want_dict) out.vals.assign((size_t)tot * C * 9, 0.0);
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(A.n_threads, out.n_slices / 64 + 1));
     std::vector<BlockTable> local((size_t)nt, BlockTable(max_unique));
     std::vector<std::pair<size_t, size_t>> slots((size_t)nt);
@@ -264,13 +268,15 @@ bool asm_to_sell_dict(const pcg_asm *h, int64_t n_boundary_nodes, int64_t max_un
                     const BlockKey *kp = &zero;                    // padding: value 0, a valid column NEAR the slice (as bsr_to_sell)
                     if (k < len) {
                         out.cols[ci] = A.cols[r0 + k];
-                        std::memcpy(key.w, &rv[(size_t)k * 9], sizeof(key.w));
-                        kp = &key;
+                        if (want_dict) { std::memcpy(key.w, &rv[(size_t)k * 9], sizeof(key.w)); kp = &key; }
+                        else
+                            for (int c = 0; c < 9; ++c) out.vals[((size_t)(base + k) * 9 + c) * C + l] = rv[(size_t)k * 9 + c];
                         if (A.cols[r0 + k] == r)
                             for (int a = 0; a < 3; ++a) out.diag[(size_t)r * 3 + a] = rv[(size_t)k * 9 + a * 3 + a];
                     } else {
                         out.cols[ci] = (int32_t)(live ? r : nn - 1);
                     }
+                    if (!want_dict) continue;
                     const int32_t id = tab.add(*kp);
                     if (id < 0) { failed[t] = 1; return; }
                     bidx[ci] = (uint16_t)id;
@@ -286,7 +292,7 @@ bool asm_to_sell_dict(const pcg_asm *h, int64_t n_boundary_nodes, int64_t max_un
     }
     for (char f : failed)
         if (f) return false;
-    return finish_dictionary(out, local, slots, bidx, max_unique);
+    return want_dict ? finish_dictionary(out, local, slots, bidx, max_unique) : true;
 }
 
 }  // namespace pcg

@@ -539,12 +539,8 @@ int pcg_create_asm(int32_t device, const pcg_asm *a, int64_t n_boundary_nodes, i
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);
         SellHost m;
-        if (want_dict && asm_to_sell_dict(a, n_boundary_nodes, cap, m)) return finish_create(std::move(e), m, out);
-        std::vector<double> vals((size_t)rowptr[n_nodes] * 9);                 // plain values (or too many distinct blocks)
-        asm_fill_values(a, vals.data());
-        m = SellHost();
-        bsr_to_sell(n_nodes, rowptr, cols, vals.data(), n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
-        std::vector<double>().swap(vals);
+        if (want_dict && asm_to_sell(a, n_boundary_nodes, 1, true, cap, m)) return finish_create(std::move(e), m, out);
+        (void)asm_to_sell(a, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, false, cap, m);   // plain values (or too many distinct blocks)
         return finish_create(std::move(e), m, out);
     });
 }

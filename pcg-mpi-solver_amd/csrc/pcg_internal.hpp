@@ -75,10 +75,12 @@ public:
 // m.vals is released.  false (m untouched) when the union has more than max_unique entries.
 bool finish_dictionary(SellHost &m, std::vector<BlockTable> &local, const std::vector<std::pair<size_t, size_t>> &slots,
                        std::vector<uint16_t> &bidx, int64_t max_unique);
-// SELL-64 + dictionary straight from the host assembler, row by row: the 72-byte values of the stored blocks are never
-// materialised (cols + 2-byte indices only: 6 B instead of 76 + 76 B of host memory per stored block).  Same SellHost as
-// pcg_asm_fill -> bsr_to_sell -> compress_blocks.  false (out unspecified) when there are more than max_unique distinct blocks.
-bool asm_to_sell_dict(const pcg_asm *a, int64_t n_boundary_nodes, int64_t max_unique, SellHost &out);
+// SELL straight from the host assembler, slice by slice: every block row is produced once and written into the slice
+// layout - no 3x3-block CSR copy of the values in between.  want_dict: the blocks are hashed and stored as table indices,
+// the 72-byte values are never materialised (cols + 2-byte indices: 6 B instead of 76 + 76 B of host memory per stored
+// block); false (out unspecified) when there are more than max_unique distinct blocks.  Same SellHost as
+// pcg_asm_fill -> bsr_to_sell (-> compress_blocks).
+bool asm_to_sell(const pcg_asm *a, int64_t n_boundary_nodes, int32_t rows_per_lane, bool want_dict, int64_t max_unique, SellHost &out);
 // the assembled 3x3-block CSR arrays of a pcg_asm (views into it) / its values (pcg_asm_fill without the column copy)
 void asm_views(const pcg_asm *a, int64_t *n_nodes, const int64_t **rowptr, const int32_t **cols);
 void asm_fill_values(const pcg_asm *a, double *vals);
