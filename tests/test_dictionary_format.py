@@ -104,6 +104,40 @@ def test_assembler_path_builds_the_same_operator(hostops, monkeypatch, case, par
             op.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_formats_and_paths_agree_on_random_unstructured_meshes(hostops, monkeypatch, seed):
+    """Random connectivity, several pattern sizes and slot orders, random sign masks and random Ck (every block distinct: the
+    table is as large as the matrix; capped so that some seeds overflow and keep the plain format), a hub node of high
+    valence, rows of very different lengths (ragged slices, padding): the four ways to build the operator - arrays or
+    assembler path, plain or dictionary - give the same SpMV bits, and the two paths the same host arrays."""
+    from test_irregular_meshes import random_part
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_MATRIX_FINGERPRINT", "1")
+    if seed % 2:
+        monkeypatch.setenv("PCG_SPMV_DICT_MAX", "500")                      # fewer entries than distinct blocks: fall back
+    spec = [[(8, 200), (4, 150), (9, 60)], [(8, 240), (6, 90)], [(20, 120), (5, 40), (13, 70)], [(4, 500)]][seed]
+    P = random_part(97, spec, seed=40 + seed, hub=seed == 1)
+    x = np.random.default_rng(seed).standard_normal(P["NDOF"])
+    want = pcg_oracle.matvec_local(P, x)
+    ys, fps, dicts = {}, {}, {}
+    for kind in ("sell", "dict"):
+        for stream in ("0", "1"):
+            monkeypatch.setenv("PCG_ASM_STREAM", stream)
+            op = from_refmeshpart(P, kind=kind)
+            try:
+                ys[kind, stream] = _spmv_local(op, x)[0]
+                fps[kind, stream] = op.matrix_fingerprint()
+                dicts[kind, stream] = op.matrix_dictionary()
+            finally:
+                op.close()
+    assert fps["sell", "0"] == fps["sell", "1"] != 0 and fps["dict", "0"] == fps["dict", "1"] != 0
+    assert dicts["dict", "0"] == dicts["dict", "1"] and dicts["sell", "0"] == 0
+    assert (dicts["dict", "1"] == 0) == bool(seed % 2)
+    for k, y in ys.items():
+        assert np.array_equal(y, ys["sell", "0"]), k
+    assert relerr(ys["dict", "1"], want) < 1e-13
+
+
 def test_assembler_path_falls_back_when_the_table_overflows(hostops, monkeypatch):
     from pcg_mi355x.operator import from_refmeshpart
     monkeypatch.setenv("PCG_SPMV_DICT_MAX", "20")
