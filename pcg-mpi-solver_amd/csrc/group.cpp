@@ -111,7 +111,7 @@ struct pcg_group {
     }
     ~pcg_group()
     {
-        if (!w.empty() && !comm.empty())                   // the communicators go on the threads that created them
+        if ((int)w.size() == n && (int)comm.size() == n)   // the communicators go on the threads that created them
             (void)run_all("pcg_group_destroy", [this](int k) {
                 if (comm[k]) pcg_comm_destroy(comm[k]);
                 comm[k] = nullptr;
