@@ -257,9 +257,7 @@ int pcg_group_set_timing(pcg_group *g, int32_t on);           /* pcg_comm_set_ti
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */
 int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each /* reps */);
 /* HBM stream microbenchmark on the engine's device and stream (16 B per lane, non-temporal, grid-stride - the access
- * shape of the solver's kernels): mode 0 reads `bytes`, mode 1 copies `bytes` (read + write = 2 * bytes of traffic);
- * modes 2-4 are access-pattern probes that read `bytes` the way k_spmv streams the values of its slices (2: one wave
- * per contiguous region, 8 B per lane; 3: the same with 16 B per lane; 4: step-major across the grid).
+ * shape of the solver's kernels): mode 0 reads `bytes`, mode 1 copies `bytes` (read + write = 2 * bytes of traffic).
  * The practical bandwidth ceiling of the box a number was measured on, reported beside the 8 TB/s spec (bench.py). */
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each /* reps */);
 int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free */, int64_t *n_elem, int64_t *n_slots,
@@ -280,6 +278,13 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
 int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const double *q, double *r,
                        const double *x_old, double *x_new, const double *inv_diag,
                        double *sums5 /* sqP, sqX, sqR, rho_next, n_inf */);
+/* The whole vector phase of one iteration on given vectors (pcg_solver.py:501-516 and :447-479 of the next iteration):
+ * r and x updated with the given alpha, the five sums, p_next = M^-1 r' + (rho' / rho) p.  fused != 0: the single launch of
+ * the single-part solve loop (grid-wide reduction inside the kernel); 0: the split form of the multi-GPU loop (update,
+ * reduce, k_update_p).  Both produce the same bits (tests). */
+int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p, const double *q, double *r,
+                        const double *x_old, double *x_new, const double *inv_diag, double *p_next,
+                        double *sums5 /* sqP, sqX, sqR, rho_next, n_inf */, int32_t fused);
 int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, const double *inv_diag,
                    double *sums3 /* sqR, rho, n_inf */);
 int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy /* sum x*y*w or NULL */);

@@ -16,1507 +16,13 @@
 // the assembled operator (+ fused p.Ap.w :487); k_fixup = :332-334; k_update_p = :447,:472-479;
 // k_fused_update = :501-516 plus :447-462 of the next iteration; k_residual = :413-416/:530-533;
 // k_dot_w = np.dot(a, b*w) :381.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <stdexcept>
-#include <string>
-#include <type_traits>
-
-#include "pcg_internal.hpp"
-
-#define HIP_CHECK(expr)                                                                                  \
-    do {                                                                                                 \
-        hipError_t _e = (expr);                                                                          \
-        if (_e != hipSuccess)                                                                            \
-            throw std::runtime_error(std::string(#expr) + " -> " + hipGetErrorString(_e));               \
-    } while (0)
+#include "hip_common.hpp"
+#include "kernels_spmv.hpp"
+#include "kernels_ebe.hpp"
+#include "kernels_vector.hpp"
+#include "kernels_probe.hpp"
 
 namespace pcg {
-
-constexpr int kBlock = 256;            // 4 wave64 per workgroup
-constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kMaxPartials = 4096;     // upper bound on blocks that write a partial
-
-// ------------------------------------------------------------------------------------------------
-// reductions
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;                           // valid in lane 0
-}
-
-// block-level sum of NV per-thread values; result valid in thread 0.  Fixed order -> deterministic.
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* NV * kWavesPerBlock */)
-{
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = wave_sum(v[k]);
-        if (lane == 0) lds[k * kWavesPerBlock + wid] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            double s = lds[k * kWavesPerBlock];
-#pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) s += lds[k * kWavesPerBlock + w];
-            v[k] = s;
-        }
-    }
-}
-
-// out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x.
-// One block per value; every thread keeps 4 independent partial sums (loads in flight), then a
-// fixed wave/LDS tree -> deterministic.
-// alpha_mode: out is the status block: st[PQ] = sum, rho = st[RHO_NEXT], then alpha / stop exactly like k_scalar_alpha (:492-498).
-// mirror (may be null): host-visible copy of the words written, so the host needs no device->host copy.
-__global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
-                                                   const double *__restrict__ pb, int count_b, double *out,
-                                                   double *mirror, int alpha_mode)
-{
-    __shared__ double lds[kWavesPerBlock];
-    const int k = blockIdx.x;
-    const double *src = pa + (size_t)k * stride;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = threadIdx.x;
-    for (; b + 3 * kBlock < count_a; b += 4 * kBlock) {
-        s0 += src[b]; s1 += src[b + kBlock]; s2 += src[b + 2 * kBlock]; s3 += src[b + 3 * kBlock];
-    }
-    for (; b < count_a; b += kBlock) s0 += src[b];
-    if (pb)
-        for (int c = threadIdx.x; c < count_b; c += kBlock) s1 += pb[c];
-    double v[1] = {(s0 + s1) + (s2 + s3)};
-    block_sum<1>(v, lds);
-    if (threadIdx.x == 0) {
-        if (!alpha_mode) {
-            out[k] = v[0];
-            if (mirror) mirror[k] = v[0];
-        } else {
-            const double pq = v[0], rho = out[ST_RHO_NEXT];
-            double stop = out[ST_STOP], alpha = out[ST_ALPHA];   // STOP is sticky: an iteration enqueued behind a broken one stays frozen
-            if (pq <= 0.0 || isinf(pq)) stop = 1.0;
-            else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
-            out[ST_RHO] = rho; out[ST_PQ] = pq; out[ST_ALPHA] = alpha; out[ST_STOP] = stop;
-            if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// SpMV over the SELL-C 3x3-block matrix.  One wave per slice at a time; RPL rows per lane
-// (RPL=1: C=64, 8-B lane loads; RPL=2: C=128, 16-B lane loads).
-// ------------------------------------------------------------------------------------------------
-template <int RPL> struct VecT;
-template <> struct VecT<1> { using d = double; using i = int; };
-template <> struct VecT<2> { using d = double2; using i = int2; };
-
-__device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ int ntload(const int *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ unsigned ntload(const unsigned *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ double2 ntload(const double2 *p)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(p));
-    return make_double2(t.x, t.y);
-}
-__device__ __forceinline__ void ntstore(double2 *p, double2 v)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    v2 w; w.x = v.x; w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(p));
-}
-__device__ __forceinline__ int2 ntload(const int2 *p)
-{
-    typedef int v2 __attribute__((ext_vector_type(2)));
-    v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(p));
-    return make_int2(t.x, t.y);
-}
-
-__device__ __forceinline__ int ntload(const unsigned short *p) { return (int)__builtin_nontemporal_load(p); }
-__device__ __forceinline__ int2 ntload(const ushort2 *p)
-{
-    const unsigned t = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
-    return make_int2((int)(t & 0xffffu), (int)(t >> 16));
-}
-
-// COL16: the block columns of a slice are stored as 16-bit offsets from the slice's smallest column (colbase[s]) -
-// 74 instead of 76 bytes per stored block; chosen at upload when every slice spans fewer than 65536 block columns
-// (node numberings with a bandwidth below 32 k nodes, e.g. the 10 M-dof brick: 22 651).  Same columns, same order,
-// same arithmetic: results are bit-identical to the 32-bit form.
-#ifndef PCG_SPMV_ABL
-#define PCG_SPMV_ABL 0     // development builds only (tools/spmv_ablation.sh): 1 = no x gather (columns still loaded), 2 = gather from a
-#endif                     // 24 KB window of x (always cache hits), 4 = no column loads either.  Ablated kernels compute WRONG results.
-template <int RPL, bool DOT, bool COL16>
-__global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
-                                                 const int *__restrict__ colbase,
-                                                 const double *__restrict__ vals, const double *__restrict__ x,
-                                                 double *__restrict__ y, const uint8_t *__restrict__ flags,
-                                                 double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
-                                                 int64_t n_nodes, int xcd_aware)
-{
-    constexpr int C = 64 * RPL;
-    using DV = typename VecT<RPL>::d;
-    using IV = typename VecT<RPL>::i;
-    using CV = typename std::conditional<COL16, typename std::conditional<RPL == 1, unsigned short, ushort2>::type, IV>::type;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // Slice -> wave mapping.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
-    // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
-    // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
-    const int64_t S = slice_hi - slice_lo;
-    const bool xa = (xcd_aware & 1) != 0;                    // bit 1 of the argument: non-temporal y stores
-    const int xcd = xa ? (blockIdx.x & 7) : 0;
-    const int64_t lb = xa ? (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t blocks_per_xcd = xa ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
-    const int64_t c_lo = xa ? slice_lo + (S * xcd) / 8 : slice_lo;
-    const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
-    const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
-    double dot = 0.0;
-    for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
-        const int64_t base = slice_ptr[s];
-        const int w = (int)(slice_ptr[s + 1] - base);
-        const DV *vp = reinterpret_cast<const DV *>(vals + (size_t)base * 9 * C) + lane;
-        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
-        int cb = 0;
-        if constexpr (COL16) cb = colbase[s];
-        double acc[RPL][3];
-#pragma unroll
-        for (int h = 0; h < RPL; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.0;
-#pragma unroll 3
-        for (int k = 0; k < w; ++k) {
-            IV jv = (PCG_SPMV_ABL & 4) ? IV{} : ntload(cp + (size_t)k * 64);
-            if constexpr (COL16) {
-                if constexpr (RPL == 1) jv += cb; else { jv.x += cb; jv.y += cb; }
-            }
-            if constexpr ((PCG_SPMV_ABL & 2) != 0 && RPL == 1) jv &= 1023;
-            DV v[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
-            if constexpr (RPL == 1) {
-                const double *xp = x + 3 * (size_t)jv;
-                double x0, x1, x2;
-                if constexpr ((PCG_SPMV_ABL & 1) != 0) { x0 = (double)jv; x1 = 2.0; x2 = 3.0; }      // column consumed, no gather
-                else { x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    acc[0][a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[0][a])));
-            } else {
-                const double *xa = x + 3 * (size_t)jv.x, *xb = x + 3 * (size_t)jv.y;
-                const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
-                const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    acc[0][a] = fma(v[3 * a + 2].x, a2, fma(v[3 * a + 1].x, a1, fma(v[3 * a].x, a0, acc[0][a])));
-                    acc[1][a] = fma(v[3 * a + 2].y, b2, fma(v[3 * a + 1].y, b1, fma(v[3 * a].y, b0, acc[1][a])));
-                }
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < RPL; ++h) {
-            const int64_t row = s * C + (int64_t)lane * RPL + h;
-            if (row < n_nodes) {
-                double *yp = y + 3 * row;
-                if (xcd_aware & 2) {
-                    __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
-                    __builtin_nontemporal_store(acc[h][2], yp + 2);
-                } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
-                if constexpr (DOT) {
-                    const uint8_t *fp = flags + 3 * row;
-                    const double *xp = x + 3 * row;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-                        if ((fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
-                }
-            }
-        }
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-// Dictionary variant (SellHost::bidx / dict, sell.cpp compress_blocks; PCG_FORMAT_DICTIONARY): a stored block is a column and a
-// 16-bit index into the table of the matrix's DISTINCT 3x3 blocks, 4-6 bytes instead of 74-76.  The same lanes multiply the
-// same values in the same order as k_spmv: results are bit-identical, only where the values come from differs.  LDSD: the
-// table (72 B per entry) is copied into LDS once per workgroup - the workgroups are persistent, each wave walks many
-// slices - and the lanes of a wave read their blocks from there (same index = one broadcast read; the kernel is bound by the
-// LDS read rate and the x gathers, not by HBM: 0.5 GB instead of 6.9 GB per launch at 10 M dof).  !LDSD: tables beyond the LDS
-// budget are read through L1/L2.
-// MIXED (with LDSD): the table is larger than LDS; its n_lds most frequent entries (the host orders the table by descending
-// frequency) are the LDS copy, a lane whose block is one of the others reads it through L1/L2 - a divergent branch that
-// costs nothing when no lane of the wave needs it.
-template <bool DOT, bool COL16, bool LDSD, int BLK, bool MIXED = false>
-__global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
-                                                      const int *__restrict__ colbase, const unsigned short *__restrict__ bidx,
-                                                      const double *__restrict__ dict, int n_lds,
-                                                      const double *__restrict__ x, double *__restrict__ y,
-                                                      const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                      int64_t slice_lo, int64_t slice_hi, int64_t n_nodes)
-{
-    // LDS copy of the table: entries padded to 80 B (16-B aligned) so that a block is four ds_read_b128 + one ds_read_b64 -
-    // 256 B/clk per CU; the 72-B layout compiles to ds_read2_b64 pairs, which run at half that rate (MI355X_MICROARCH.md, LDS)
-    extern __shared__ __align__(16) double sdict[];
-    using CV = typename std::conditional<COL16, unsigned short, int>::type;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int WPB = BLK / 64;                              // waves per workgroup: they share one copy of the table
-    if constexpr (LDSD) {
-        for (int i = threadIdx.x; i < 9 * n_lds; i += BLK) sdict[10 * (i / 9) + i % 9] = dict[i];
-        __syncthreads();
-    }
-    const int64_t wstride = (int64_t)gridDim.x * WPB;
-    double dot = 0.0;
-    for (int64_t s = slice_lo + (int64_t)blockIdx.x * WPB + wid; s < slice_hi; s += wstride) {
-        const int64_t base = slice_ptr[s];
-        const int w = (int)(slice_ptr[s + 1] - base);
-        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
-        const unsigned short *ip = bidx + (size_t)base * 64 + lane;
-        int cb = 0;
-        if constexpr (COL16) cb = colbase[s];
-        double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll 3
-        for (int k = 0; k < w; ++k) {
-            int j = ntload(cp + (size_t)k * 64);
-            if constexpr (COL16) j += cb;
-            const int id = ntload(ip + (size_t)k * 64);
-            double v[9];
-            if (LDSD && (!MIXED || id < n_lds)) {
-                const double2 *e2 = reinterpret_cast<const double2 *>(sdict + 10 * id);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const double2 t = e2[c]; v[2 * c] = t.x; v[2 * c + 1] = t.y; }
-                v[8] = sdict[10 * id + 8];
-            } else {
-                const double *b = dict + 9 * (size_t)id;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) v[c] = b[c];
-            }
-            const double *xp = x + 3 * (size_t)j;
-            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
-        }
-        const int64_t row = s * 64 + lane;
-        if (row < n_nodes) {
-            double *yp = y + 3 * row;
-            yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
-            if constexpr (DOT) {
-                const uint8_t *fp = flags + 3 * row;
-                const double *xr = x + 3 * row;
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
-            }
-        }
-    }
-    if constexpr (DOT) {                                       // fixed order: lanes (shuffle tree), then the waves in turn
-        __shared__ double lds[WPB];
-        const double ws = wave_sum(dot);
-        if (lane == 0) lds[wid] = ws;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = lds[0];
-#pragma unroll
-            for (int q = 1; q < WPB; ++q) t += lds[q];
-            partials[blockIdx.x] = t;
-        }
-    }
-}
-
-// Scalar-row variant (SellHost::bs == 1): one lane per matrix ROW, one f64 value + one i32 column per stored
-// entry - the literal CSR data volume (12 B per non-zero), in the same slice layout, so a wave's loads of a
-// slice column are one 512 B + one 256 B coalesced line.  Used by pcg_create_csr(block = 1): systems whose
-// rows are not 3-dof node blocks, and the "CSR-format" point of the measurement table.
-template <bool DOT>
-__global__ __launch_bounds__(kBlock) void k_spmv_scalar(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
-                                                        const double *__restrict__ vals, const double *__restrict__ x,
-                                                        double *__restrict__ y, const uint8_t *__restrict__ flags,
-                                                        double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
-                                                        int64_t n_rows)
-{
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
-    double dot = 0.0;
-    for (int64_t s = slice_lo + (int64_t)blockIdx.x * kWavesPerBlock + wid; s < slice_hi; s += wstride) {
-        const int64_t base = slice_ptr[s];
-        const int w = (int)(slice_ptr[s + 1] - base);
-        const double *vp = vals + (size_t)base * 64 + lane;
-        const int *cp = cols + (size_t)base * 64 + lane;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        int k = 0;
-        for (; k + 9 <= w; k += 9) {                            // 9 independent gathers in flight per lane
-            int j[9];
-            double v[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) { j[c] = ntload(cp + (size_t)(k + c) * 64); v[c] = ntload(vp + (size_t)(k + c) * 64); }
-#pragma unroll
-            for (int c = 0; c < 9; c += 3) {
-                a0 = fma(v[c], x[j[c]], a0);
-                a1 = fma(v[c + 1], x[j[c + 1]], a1);
-                a2 = fma(v[c + 2], x[j[c + 2]], a2);
-            }
-        }
-        for (; k < w; ++k) a0 = fma(ntload(vp + (size_t)k * 64), x[ntload(cp + (size_t)k * 64)], a0);
-        const int64_t row = s * 64 + lane;
-        if (row < n_rows) {
-            const double r = (a0 + a1) + a2;
-            y[row] = r;
-            if constexpr (DOT)
-                if ((flags[row] & 3) == 3) dot += x[row] * r;
-        }
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Matrix-free operator (the reference's element-by-element form, pcg_solver.py:277-280 + :300).
-// One thread per element of ONE colour (no two elements of a launch share a node -> plain
-// read-modify-write of y, no atomics, summation order = colour order).  All lanes of a wave work on
-// the same pattern type, so Ke[a][b] is wave-uniform: it is fetched with scalar loads into SGPRs and
-// used as the scalar operand of v_fma_f64 - no LDS, no per-lane copy of the 24x24 matrix.  Four
-// output rows are accumulated at a time (independent FMA chains).
-// ------------------------------------------------------------------------------------------------
-template <int ND>
-__global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, const unsigned *__restrict__ sgn,
-                                                const double *__restrict__ ck, const double *__restrict__ ke,
-                                                const double *__restrict__ x, double *__restrict__ y, int64_t ne,
-                                                int64_t e_lo, int64_t e_hi)
-{
-    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    if (e >= e_hi) return;
-    int d[ND];
-    double u[ND];
-#pragma unroll
-    for (int a = 0; a < ND; ++a) d[a] = __builtin_nontemporal_load(dof + (size_t)a * ne + e);
-    const unsigned sg = __builtin_nontemporal_load(sgn + e);
-    const double c = __builtin_nontemporal_load(ck + e);
-#pragma unroll
-    for (int b = 0; b < ND; ++b) {
-        double v = x[d[b]];                                  // :277 gather
-        if ((sg >> b) & 1u) v = -v;                          // :278
-        u[b] = c * v;                                        // :279 Ck * U
-    }
-    static_assert(ND % 4 == 0, "ND must be a multiple of 4");
-#pragma unroll
-    for (int a0 = 0; a0 < ND; a0 += 4) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int b = 0; b < ND; ++b) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fma(ke[(a0 + i) * ND + b], u[b], acc[i]);   // :279 Ke @ (.)
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double o = acc[i];
-            if ((sg >> (a0 + i)) & 1u) o = -o;               // :280
-            y[d[a0 + i]] += o;                               // :300 (conflict-free inside a colour)
-        }
-    }
-}
-
-// Chunked form (EbeChunkedHost): one workgroup (256 threads, EPT elements each) = one chunk of node-blocked
-// elements with at most NNP nodes (NDP = 3*NNP dofs; the hex8 fast path is NNP = 8).
-//   1. the chunk's unique nodes are staged into LDS (x tile) with node-contiguous global loads,
-//   2. each lane = one element: u_b from the LDS tile, NDP independent FMA chains acc[a] += Ke[a][b]*u_b
-//      with Ke (column-major, zero padded, wave-uniform) streamed through SGPRs by scalar loads,
-//   3. LDS-staged partial sums: the lanes add their outputs into the LDS y tile sub-colour by sub-colour
-//      (no two lanes of a sub-colour share a node; fixed order -> deterministic),
-//   4. tile nodes owned by this chunk alone are stored straight to y; nodes shared with other chunks go
-//      to this chunk's slots of the boundary buffer, summed afterwards by k_ebe_shared in chunk order.
-// All chunks of a phase and node-count class are ONE launch (no colour-by-colour launches, no
-// read-modify-write of y).
-template <int NNP, int EPT> struct ChunkLB { static constexpr int w = NNP == 8 ? (EPT == 1 ? 4 : 3) : 2; };
-
-// FULL: every element of the launch has exactly NNP nodes (the hex8 class): the `< nd` guards compile away.
-template <int NNP, int EPT, bool FULL, bool DOT>
-__global__ __launch_bounds__(kChunkThreads, (ChunkLB<NNP, EPT>::w)) void k_ebe_chunk(
-    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
-    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
-    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
-{
-    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
-    constexpr int CE = kChunkThreads * EPT;                  // element slots per chunk
-    constexpr int NDP = 3 * NNP;
-    constexpr int W = NDP / 32 + 1;                          // sign words; bits 24..31 of the last one = sub-colour
-    __shared__ double xs[3 * kChunkMaxNodes];
-    __shared__ double ys[3 * kChunkMaxNodes];
-    const int chunk = chunk_list[blockIdx.x];
-    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
-    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
-    const int kci = h2.x, nd = FULL ? 3 * NNP : h2.y;
-    // ---- issue every global load of this chunk up front: element data, node ids, x tile ---------------
-    unsigned sg[EPT][W];
-    double c[EPT];
-    int l3[EPT][NNP];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const size_t lane = j * kChunkThreads + threadIdx.x;
-#pragma unroll
-        for (int w = 0; w < W; ++w) sg[j][w] = __builtin_nontemporal_load(sgn + ((size_t)kci * W + w) * CE + lane);
-        c[j] = __builtin_nontemporal_load(ck + (size_t)kci * CE + lane);
-#pragma unroll
-        for (int k = 0; k < NNP; ++k) l3[j][k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
-    }
-    int dst[NPT], sl3[NPT];
-    double dot = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        int g = -1;
-        dst[j] = 0;
-        sl3[j] = 0;
-        if (n < h.y) {
-            g = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n);
-            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
-        }
-        if (g >= 0) {
-            const double *xp = x + 3 * (size_t)g;
-            xs[sl3[j]] = xp[0]; xs[sl3[j] + 1] = xp[1]; xs[sl3[j] + 2] = xp[2];
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
-        }
-    }
-    __syncthreads();
-    const double *K = ke_col + (size_t)h.w * NDP * NDP;
-    // output rows are produced RB at a time (register budget: RB accumulators per element); one pass for
-    // <= 24-node patterns, two for 32-node ones
-    constexpr int RB = NNP == 32 ? 48 : NDP;
-    // nd is block-uniform, so every `x < nd` below is a scalar compare + uniform branch; the loops stay
-    // fully unrolled (no `break`), which keeps the accumulators in registers
-#pragma unroll
-    for (int a0 = 0; a0 < NDP; a0 += RB) {
-        if (a0 < nd) {
-            double acc[EPT][RB];
-#pragma unroll
-            for (int j = 0; j < EPT; ++j)
-#pragma unroll
-                for (int a = 0; a < RB; ++a) acc[j][a] = 0.0;
-#pragma unroll
-            for (int b = 0; b < NDP; ++b) {
-                if (b < nd) {
-                    double u[EPT];
-#pragma unroll
-                    for (int j = 0; j < EPT; ++j) {
-                        double v = xs[l3[j][b / 3] + b % 3];             // :277 gather (from the LDS tile)
-                        if ((sg[j][b >> 5] >> (b & 31)) & 1u) v = -v;    // :278
-                        u[j] = c[j] * v;                                 // :279 Ck * U
-                    }
-#pragma unroll
-                    for (int a = 0; a < RB; ++a) {
-                        const double k = K[b * NDP + a0 + a];            // wave-uniform -> SGPR pair
-#pragma unroll
-                        for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);   // :279 Ke @ (.)
-                    }
-                }
-            }
-            for (int s = 0; s < h.z; ++s) {
-#pragma unroll
-                for (int j = 0; j < EPT; ++j)
-                    if ((int)(sg[j][W - 1] >> 24) == s) {    // the targets of one element are distinct: batch the reads
-#pragma unroll
-                        for (int q0 = 0; q0 < RB; q0 += 24) {
-                            if (a0 + q0 < nd) {
-                                double old[24];
-#pragma unroll
-                                for (int q = 0; q < 24; ++q) {
-                                    const int a = a0 + q0 + q;
-                                    old[q] = a < nd ? ys[l3[j][a / 3] + a % 3] : 0.0;
-                                }
-#pragma unroll
-                                for (int q = 0; q < 24; ++q) {
-                                    const int a = a0 + q0 + q;
-                                    if (a < nd) {                        // padded slots alias local node 0: never write them
-                                        double o = acc[j][q0 + q];
-                                        if ((sg[j][a >> 5] >> (a & 31)) & 1u) o = -o;   // :280
-                                        ys[l3[j][a / 3] + a % 3] = old[q] + o;          // :300, LDS-staged partial sums
-                                    }
-                                }
-                            }
-                        }
-                    }
-                __syncthreads();
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        if (n < h.y) {
-            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            out[0] = ys[sl3[j]]; out[1] = ys[sl3[j] + 1]; out[2] = ys[sl3[j] + 2];
-            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                const uint8_t *fp = flags + dst[j];
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    if ((fp[d] & 3) == 3) dot += xs[sl3[j] + d] * ys[sl3[j] + d];
-            }
-        }
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// hex8 chunks, second form (k_ebe_hex).  Same algorithm, same summation order per node and the same host-side chunk
-// structures as k_ebe_chunk; what changes is how a workgroup gets to its arithmetic and back:
-//   * per-LAUNCH tables (HexTab): block b finds its header, node list (padded to MAXN entries, -1 = none) and element
-//     slots at fixed strides of b - no chunk-id list, no header -> offsets dependency: the node ids, the element data
-//     and the header are three independent loads issued together, the x gather is the only dependent round trip
-//     (k_ebe_chunk: chunk id -> header -> node ids -> x);
-//   * element slot of thread t, copy j: ((t >> 6) * EPT + j) * 64 + (t & 63): a wave owns EPT consecutive 64-slot runs,
-//     so slot order = (wave, j) order, and the LDS accumulation runs wave after wave (each wave its sub-colours in
-//     ascending order, LDS operations of one wave are ordered) with ONE block barrier per wave instead of one per
-//     sub-colour: 4 instead of 8-10 per chunk, same order of additions;
-//   * a sign is an XOR of the sign bit (shift, and, xor) instead of compare + select + two moves.
-// EPT / NPT (tile nodes per thread) / LB (blocks per CU asked of the register allocator) are template parameters so that
-// the occupancy trade-off can be measured (PCG_EBE_HEX, tools/ebe_lab.py).
-// ------------------------------------------------------------------------------------------------
-#ifndef PCG_EBE_ABL
-#define PCG_EBE_ABL 0      // development builds only (tools/ebe_ablation.sh): 1 = no contraction, 2 = no LDS accumulation, 4 = no stores, 8 = no x gather
-#endif
-struct HexTab {
-    const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, any sign bit set
-    const int *nodes;             // [n][MAXN]  node id, -1 = padding
-    const int *dst;               // [n][MAXN]  >= 0: y offset (exclusive node); < 0: -(boundary slot + 1)
-    const unsigned short *tslot;  // [n][MAXN]  bits 0..9 slot in the LDS tile; bits 12..14: dof 0..2 of the node is owned and free
-                                  //            (the weight of the fused p.Ap, patched in by upload_masks: no flag loads in the kernel)
-    const unsigned short *lid;    // [n][8][CE]
-    const double *ck;             // [n][CE]
-    const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
-};
-
-__device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
-{
-    const unsigned long long m = (unsigned long long)((sg >> b) & 1u) << 63;
-    return __longlong_as_double(__double_as_longlong(v) ^ (long long)m);
-}
-
-// ACCM: how a lane adds its 24 outputs into the LDS y tile.  0: read - add - write in two batches of 12 (the signs are
-// applied beforehand, outside the serial part, and the wave whose turn it is runs at raised priority: its few VALU adds
-// must not queue behind the other workgroups' FMA streams while three waves wait at the barrier).  1: ds_add_f64 - the
-// LDS unit adds in place, the serial part of a wave is 24 * EPT LDS instructions and no VALU work at all.  The order of
-// additions per node is the same in both modes (wave after wave, sub-colour after sub-colour): bit-reproducible.
-template <int EPT, int NPT, int LB, bool DOT, int ACCM>
-__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
-                                                               double *__restrict__ y, double *__restrict__ buf,
-                                                               const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                               long long dot_lo)
-{
-    constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
-    __shared__ double xs[3 * MAXN];
-    __shared__ double ys[3 * MAXN];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6;
-    const int4 h = T.hdr[b];
-    // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
-    unsigned sg[EPT];
-    double c[EPT];
-    int l3[EPT][8];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const size_t slot = (size_t)b * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63);
-        sg[j] = ntload(T.sgn + slot);
-        c[j] = ntload(T.ck + slot);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            l3[j][k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63));
-    }
-    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
-        g[j] = ntload(T.nodes + n);
-        dst[j] = ntload(T.dst + n);
-        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
-        sl3[j] = 3 * (ts & 0x3ff);
-        wmask[j] = ts >> 12;
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
-            const double *xp = x + 3 * (size_t)g[j];
-            const double x0 = (PCG_EBE_ABL & 8) ? 1.0 : xp[0], x1 = (PCG_EBE_ABL & 8) ? 2.0 : xp[1], x2 = (PCG_EBE_ABL & 8) ? 3.0 : xp[2];
-            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
-        }
-    __syncthreads();
-    const double *K = ke_col + (size_t)h.z * ND * ND;
-    double acc[EPT][ND];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j)
-#pragma unroll
-        for (int a = 0; a < ND; ++a) acc[j][a] = 0.0;
-    // h.w: some element of this chunk has a sign bit set (ElemList_SignVector, :278,:280); chunks without any - every chunk
-    // of a mesh whose patterns are in reference orientation - skip the two sign passes (block-uniform branch)
-    auto contract = [&](auto with_signs) {
-        constexpr bool SIG = decltype(with_signs)::value;
-#pragma unroll
-        for (int bb = 0; bb < ND; ++bb) {
-            double u[EPT];
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const double xv = xs[l3[j][bb / 3] + bb % 3];                                            // :277 gather
-                u[j] = c[j] * (SIG ? flip_sign(xv, sg[j], bb) : xv);                                     // :278-279 sign, Ck
-            }
-            if constexpr ((PCG_EBE_ABL & 1) != 0) {
-#pragma unroll
-                for (int j = 0; j < EPT; ++j) acc[j][bb] += u[j];
-            } else {
-#pragma unroll
-                for (int a = 0; a < ND; ++a) {
-                    const double k = K[bb * ND + a];                                                     // wave-uniform -> SGPR pair
-#pragma unroll
-                    for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);                   // :279 Ke @ (.)
-                }
-            }
-        }
-        if constexpr (SIG) {
-#pragma unroll
-            for (int j = 0; j < EPT; ++j)
-#pragma unroll
-                for (int a = 0; a < ND; ++a) acc[j][a] = flip_sign(acc[j][a], sg[j], a);                 // :280 (every wave at once)
-        }
-    };
-    if (h.w) contract(std::true_type());
-    else contract(std::false_type());
-    // ---- LDS-staged partial sums, wave after wave (slot order = sub-colour order) ----------------------------------
-    if constexpr ((PCG_EBE_ABL & 2) != 0) {           // keep the values alive without the serial LDS part
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < EPT; ++j)
-#pragma unroll
-            for (int a = 0; a < ND; ++a) t += acc[j][a];
-        if (t == 1.2345e-300) ys[0] = t;
-        __syncthreads();
-    } else
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-        if (wave == w) {
-            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
-            for (int s = 0; s < h.y; ++s) {
-#pragma unroll
-                for (int j = 0; j < EPT; ++j)
-                    if ((int)(sg[j] >> 24) == s) {
-                        if constexpr (ACCM == 1) {
-#pragma unroll
-                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
-                                __hip_atomic_fetch_add(&ys[l3[j][a / 3] + a % 3], acc[j][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
-#pragma unroll
-                            for (int q0 = 0; q0 < ND; q0 += 12) {
-                                double old[12];
-#pragma unroll
-                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[l3[j][a / 3] + a % 3]; }
-#pragma unroll
-                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[l3[j][a / 3] + a % 3] = old[q] + acc[j][a]; }   // :300
-                            }
-                        }
-                    }
-            }
-            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-    }
-    double dot = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
-            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
-            if ((PCG_EBE_ABL & 4) == 0 || y0 == 1.2345e-300) { out[0] = y0; out[1] = y1; out[2] = y2; }
-            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
-                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
-                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
-            }
-        }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// hex8 chunks of 512 elements in TWO sequential passes of 256 (k_ebe_hexs).  The geometry of the 512-element chunk (an
-// 8x8x8 cell: 729 tile nodes, 386 of them shared with other chunks = 0.75 boundary slots per element, against 1.0 for
-// the 8x8x4 cells of the 256-element chunks) with the register footprint of one element per thread (96 VGPRs): the two
-// halves of the cell are contracted and accumulated one after the other into the SAME LDS y tile, so the plane between
-// them never leaves the workgroup and the tile is staged / written out once.  Why bytes matter here: at 10 M dof an apply
-// moves ~0.65 GB with 256-element chunks (0.49 GB with 512), of which a third is the boundary-slot round trip; the
-// element kernel + shared-node sums run within 1.4x of what that traffic costs at the stream rate.
-// Slot of thread t in pass p: p * 256 + t, i.e. slot order = (pass, wave) order = sub-colour order: same sums as k_ebe_hex.
-// ------------------------------------------------------------------------------------------------
-template <int LB, bool DOT, int ACCM>
-__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
-                                                                double *__restrict__ y, double *__restrict__ buf,
-                                                                const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                                long long dot_lo)
-{
-    constexpr int SEQ = 2, NPT = 3, CE = kChunkThreads * SEQ, MAXN = kChunkThreads * NPT, ND = 24;
-    __shared__ double xs[3 * MAXN];
-    __shared__ double ys[3 * MAXN];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6;
-    const int4 h = T.hdr[b];
-    unsigned sg;
-    double c;
-    int l3[8];
-    auto load_elem = [&](int ps) {
-        const size_t slot = (size_t)b * CE + ps * kChunkThreads + threadIdx.x;
-        sg = ntload(T.sgn + slot);
-        c = ntload(T.ck + slot);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + ps * kChunkThreads + threadIdx.x);
-    };
-    load_elem(0);
-    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
-        g[j] = ntload(T.nodes + n);
-        dst[j] = ntload(T.dst + n);
-        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
-        sl3[j] = 3 * (ts & 0x3ff);
-        wmask[j] = ts >> 12;
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
-            const double *xp = x + 3 * (size_t)g[j];
-            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
-            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
-        }
-    __syncthreads();
-    const double *K = ke_col + (size_t)h.z * ND * ND;
-#pragma unroll
-    for (int ps = 0; ps < SEQ; ++ps) {
-        double acc[ND];
-#pragma unroll
-        for (int a = 0; a < ND; ++a) acc[a] = 0.0;
-        auto contract = [&](auto with_signs) {
-            constexpr bool SIG = decltype(with_signs)::value;
-#pragma unroll
-            for (int bb = 0; bb < ND; ++bb) {
-                const double xv = xs[l3[bb / 3] + bb % 3];                                               // :277 gather
-                const double u = c * (SIG ? flip_sign(xv, sg, bb) : xv);                                 // :278-279 sign, Ck
-#pragma unroll
-                for (int a = 0; a < ND; ++a) acc[a] = fma(K[bb * ND + a], u, acc[a]);                    // :279 Ke @ (.)
-            }
-            if constexpr (SIG) {
-#pragma unroll
-                for (int a = 0; a < ND; ++a) acc[a] = flip_sign(acc[a], sg, a);                          // :280
-            }
-        };
-        if (h.w) contract(std::true_type());
-        else contract(std::false_type());
-        const unsigned my_colour = sg >> 24;
-        const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
-        if (ps + 1 < SEQ) load_elem(ps + 1);                 // the other half's slots arrive under this accumulation
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            if (wave == w) {
-                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
-                for (int s = 0; s < h.y; ++s)
-                    if ((int)my_colour == s) {
-                        if constexpr (ACCM == 1) {
-#pragma unroll
-                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
-                                __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
-#pragma unroll
-                            for (int q0 = 0; q0 < ND; q0 += 12) {
-                                double old[12];
-#pragma unroll
-                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[a0[a / 3] + a % 3]; }
-#pragma unroll
-                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[a0[a / 3] + a % 3] = old[q] + acc[a]; }
-                            }
-                        }
-                    }
-                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
-            }
-            __syncthreads();
-        }
-    }
-    double dot = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
-            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
-            out[0] = y0; out[1] = y1; out[2] = y2;
-            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
-                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
-                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
-            }
-        }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Pattern types other than the full hex8 class (hanging-node octree patterns with up to 32 nodes, and patterns with fewer
-// than 8): k_ebe_rows.  A chunk is 64 elements - ONE per lane - and the four waves of the workgroup each contract a
-// quarter of the output rows (whole local nodes: NDP/4 = 6 / 12 / 18 / 24 rows) of the same 64 elements:
-//   * a lane carries NDP/4 accumulators instead of NDP (12 instead of 48 for the 13-node transition cells): 5-8 waves
-//     per SIMD instead of 2, and a workgroup's critical path is a quarter of the element's contraction;
-//   * four times as many workgroups for the same elements.  On the two-level octree mesh of bench.py (4 608 transition
-//     cells among 1.1 M hex8 cells) the round-1 kernel ran 18 workgroups for 47.6 us - more than the 33 us the 1.1 M
-//     hex8 cells took - because each of them streamed a 48 x 48 Ke through one wave per SIMD with nothing to hide the
-//     scalar-load waits behind;
-//   * Ke is laid out per wave (ke_rows: wave, column, row-in-wave), so a wave's slice of a column is one contiguous
-//     scalar load; the wave index is read with readfirstlane so the loads stay scalar.
-// Gather, signs, Ck, LDS accumulation (wave after wave, sub-colour after sub-colour, ds_add_f64) and the exclusive /
-// shared write-out are those of k_ebe_hex; every wave gathers all NDP inputs (the tile is in LDS, the redundancy is 4 LDS
-// reads instead of 1 per input).
-// ------------------------------------------------------------------------------------------------
-template <int NNP, bool DOT>
-__global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
-    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
-    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-    const double *__restrict__ ke_rows, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
-    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
-{
-    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
-    constexpr int CE = 64, NDP = 3 * NNP, RPW = NDP / 4, NPW = NNP / 4, W = NDP / 32 + 1;
-    static_assert(RPW % 3 == 0, "a wave owns whole local nodes");
-    __shared__ double xs[3 * kChunkMaxNodes];
-    __shared__ double ys[3 * kChunkMaxNodes];
-    const int chunk = chunk_list[blockIdx.x];
-    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
-    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
-    const int kci = h2.x, nd = h2.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // element `lane` of the chunk (every wave loads it: same cache lines)
-    unsigned sg[W];
-    int l3[NNP], lown[NPW];
-#pragma unroll
-    for (int w = 0; w < W; ++w) sg[w] = ntload(sgn + ((size_t)kci * W + w) * CE + lane);
-    const double c = ntload(ck + (size_t)kci * CE + lane);
-#pragma unroll
-    for (int k = 0; k < NNP; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) lown[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + wave * NPW + k) * CE + lane);
-    int dst[NPT], sl3[NPT];
-    double dot = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        int g = -1;
-        dst[j] = 0;
-        sl3[j] = 0;
-        if (n < h.y) {
-            g = ntload(nodes + h.x + n); dst[j] = ntload(dstl + h.x + n);
-            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
-        }
-        if (g >= 0) {
-            const double *xp = x + 3 * (size_t)g;
-            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
-            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
-        }
-    }
-    __syncthreads();
-    const double *K = ke_rows + ((size_t)h.w * 4 + wave) * NDP * RPW;       // this wave's rows: [column b][row a]
-    double acc[RPW];
-#pragma unroll
-    for (int a = 0; a < RPW; ++a) acc[a] = 0.0;
-#pragma unroll
-    for (int b = 0; b < NDP; ++b) {
-        if (b < nd) {                                        // nd is block-uniform: scalar compare, loops stay unrolled
-            const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);                   // :277-279
-#pragma unroll
-            for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                       // :279 Ke @ (.)
-        }
-    }
-    const int row0 = wave * RPW;                             // global row of acc[0]
-#pragma unroll
-    for (int a = 0; a < RPW; ++a) {                          // :280 (dynamic bit position: the wave index is not a constant)
-        const int r = row0 + a;
-        acc[a] = flip_sign(acc[a], sg[W == 1 ? 0 : (r >> 5)], r & 31);
-    }
-    const int my_colour = (int)(sg[W - 1] >> 24);
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-        if (wave == w)
-            for (int s = 0; s < h.z; ++s)
-                if (my_colour == s) {
-#pragma unroll
-                    for (int a = 0; a < RPW; ++a)
-                        if (row0 + a < nd)                   // padded rows alias local node 0: never add them
-                            __hip_atomic_fetch_add(&ys[lown[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
-                }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        if (n < h.y) {
-            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
-            out[0] = y0; out[1] = y1; out[2] = y2;
-            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                const uint8_t *fp = flags + dst[j];
-                if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
-                if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
-                if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
-            }
-        }
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// hex8 chunks on the matrix cores.  The reference computes Ke @ (Ck * U) for all elements of a type as ONE
-// dgemm (pcg_solver.py:279): Y(24 x Ne) = Ke(24 x 24) . U(24 x Ne).  That is what v_mfma_f64_16x16x4_f64 is
-// for: M = output dofs (24 -> two 16-row tiles, 25 % padding), N = 16 elements, K = 24 = 6 steps of 4.
-//   A (16 x 4): lane l holds Ke[16 mt + (l & 15)][4 ks + (l >> 4)]         - 12 doubles per lane, loaded once
-//   B (4 x 16): lane l holds u[dof 4 ks + (l >> 4)] of element (l & 15)    - gathered from the LDS x tile
-//   D (16x16): lane l, register r holds y[dof 16 mt + (l >> 4) + 4 r] of element (l & 15)
-// so a lane gathers AND scatters the same six dofs {g, g+4, .., g+20}, g = l >> 4, of "its" element: the six LDS
-// addresses are computed once.  A tile holds 16 elements of ONE sub-colour (build_ebe pads every sub-colour
-// group of a hex8 chunk to a multiple of 16 slots), so the 64 lanes of a scatter instruction never collide;
-// sub-colours are processed in order with a block barrier in between -> the same deterministic summation
-// order per node as k_ebe_chunk.  f64 MFMA peak equals the vector peak on MI355X (78.6 TF); the idea is the issue
-// port: 12 MFMA per 16 elements instead of 576 v_fma per element leave the VALU/LDS pipes to the gather/scatter.
-// Measured (10 M dof): correct (same parity tests), 62 cycles per MFMA as expected, but the matrix pipe is busy
-// only 29 % of the time and the apply takes 0.25 ms vs 0.20 ms for k_ebe_chunk: a wave lives ~35 k cycles for
-// 3 k cycles of MFMA; the rest is the load chain at the head of the block, the LDS phases and ten block
-// barriers per chunk.  Kept as an opt-in (PCG_EBE_MFMA=1) for the next round's work on that structure.
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-template <int EPT, bool DOT>
-__global__ __launch_bounds__(kChunkThreads, 2) void k_ebe_mfma(
-    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
-    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
-    const double *__restrict__ ke_col, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
-    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
-{
-    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
-    constexpr int CE = kChunkThreads * EPT;                  // element slots per chunk
-    constexpr int TPW = CE / 16 / kWavesPerBlock;            // tiles a wave may own (tile t -> wave t & 3)
-    __shared__ double xs[3 * kChunkMaxNodes];
-    __shared__ double ys[3 * kChunkMaxNodes];
-    const int chunk = chunk_list[blockIdx.x];
-    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
-    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, tiles in use
-    const int kci = h2.x, n_tiles = h2.w;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, col = lane & 15;
-    // ---- x tile -> LDS, y tile = 0 -----------------------------------------------------------------------
-    int dst[NPT], sl3[NPT];
-    double dot = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        int gn = -1;
-        dst[j] = 0;
-        sl3[j] = 0;
-        if (n < h.y) {
-            gn = __builtin_nontemporal_load(nodes + h.x + n); dst[j] = __builtin_nontemporal_load(dstl + h.x + n);
-            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
-        }
-        if (gn >= 0) {
-            const double *xp = x + 3 * (size_t)gn;
-            xs[sl3[j]] = xp[0]; xs[sl3[j] + 1] = xp[1]; xs[sl3[j] + 2] = xp[2];
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
-        }
-    }
-    // ---- A operand: the pattern matrix, once per wave (ke_col is column-major: ke_col[b * 24 + a] = Ke[a][b]) ----
-    const double *K = ke_col + (size_t)h.w * 24 * 24;
-    double A0[6], A1[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        const int b = 4 * ks + g;
-        A0[ks] = K[b * 24 + col];
-        A1[ks] = col < 8 ? K[b * 24 + 16 + col] : 0.0;      // rows 24..31 of the second M tile are padding
-    }
-    // the six dofs of this lane group: dof = g + 4 m -> (node, component)
-    int nd_[6], cp_[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) { const int d = g + 4 * m; nd_[m] = d / 3; cp_[m] = d - 3 * (d / 3); }
-    // ---- element data of the tiles this wave owns: issued up front ---------------------------------------
-    unsigned sg[TPW];
-    double c[TPW];
-    int ad[TPW][6];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int t = wave + kWavesPerBlock * i;
-        sg[i] = 0xff000000u; c[i] = 0.0;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) ad[i][m] = 0;
-        if (t < n_tiles) {
-            const size_t slot = (size_t)t * 16 + col;
-            sg[i] = __builtin_nontemporal_load(sgn + (size_t)kci * CE + slot);
-            c[i] = __builtin_nontemporal_load(ck + (size_t)kci * CE + slot);
-#pragma unroll
-            for (int m = 0; m < 6; ++m)
-                ad[i][m] = 3 * (int)lid[((size_t)kci * 8 + nd_[m]) * CE + slot] + cp_[m];
-        }
-    }
-    __syncthreads();
-    // ---- phase A: every tile of the wave, gather + 12 MFMA; independent of the sub-colours (xs is read-only), so the
-    // matrix pipe sees up to 2 * TPW independent accumulation chains back to back ---------------------------------
-    double o[TPW][6];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        double u[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            double v = xs[ad[i][m]];                                          // :277 gather (from the LDS tile)
-            if ((sg[i] >> (g + 4 * m)) & 1u) v = -v;                          // :278
-            u[m] = c[i] * v;                                                  // :279 Ck * U  (padding slots: Ck = 0)
-        }
-        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {                                      // :279 Ke @ (.)
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[ks], u[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[ks], u[ks], acc1, 0, 0, 0);
-        }
-        o[i][0] = acc0[0]; o[i][1] = acc0[1]; o[i][2] = acc0[2]; o[i][3] = acc0[3]; o[i][4] = acc1[0]; o[i][5] = acc1[1];
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
-            if ((sg[i] >> (g + 4 * m)) & 1u) o[i][m] = -o[i][m];              // :280
-    }
-    // ---- phase B: scatter-add into the LDS y tile, one sub-colour at a time (a tile is sub-colour pure) ----------
-    for (int s = 0; s < h.z; ++s) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            if ((int)(sg[i] >> 24) == s) {                                    // real element of this sub-colour (padding: 255)
-                double old[6];
-#pragma unroll
-                for (int m = 0; m < 6; ++m) old[m] = ys[ad[i][m]];
-#pragma unroll
-                for (int m = 0; m < 6; ++m) ys[ad[i][m]] = old[m] + o[i][m];  // :300, LDS-staged partial sums
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int n = threadIdx.x + j * kChunkThreads;
-        if (n < h.y) {
-            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            out[0] = ys[sl3[j]]; out[1] = ys[sl3[j] + 1]; out[2] = ys[sl3[j] + 2];
-            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
-                const uint8_t *fp = flags + dst[j];
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    if ((fp[d] & 3) == 3) dot += xs[sl3[j] + d] * ys[sl3[j] + d];
-            }
-        }
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-
-// nodes shared by several chunks: y[node] = sum of the chunks' slots, ascending chunk id.  Slots are numbered node-major
-// (ebe.cpp): node k of the phase owns slots slot0 + [sh_ptr[k], sh_ptr[k+1]).  One thread per (node, direction): the
-// three threads of a node and the threads of the next node read adjacent addresses (the launch streams the buffer front
-// to back), and a thread has all its addends in flight before it adds them - in slot order, so the sum is the same.
-template <bool DOT>
-__global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
-                                                       int slot0, const double *__restrict__ buf,
-                                                       double *__restrict__ y, int count, const double *__restrict__ x,
-                                                       const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                       long long dot_lo)
-{
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    const int k = t / 3, d = t - 3 * k;
-    double dot = 0.0;
-    if (k < count) {
-        const int q0 = sh_ptr[k], cnt = sh_ptr[k + 1] - q0;
-        const double *b = buf + 3 * (size_t)(slot0 + q0) + d;
-        double v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = q < cnt ? ntload(b + 3 * q) : 0.0;
-        double s = v[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q)
-            if (q < cnt) s += v[q];
-        for (int q = 8; q < cnt; ++q) s += ntload(b + 3 * q);      // more than 8 chunks at one node: irregular meshes only
-        const size_t dof = 3 * (size_t)sh_node[k] + d;
-        y[dof] = s;
-        if (DOT && (long long)dof >= dot_lo && (flags[dof] & 3) == 3) dot += x[dof] * s;
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-// any nd (hanging-node patterns): same algorithm, x re-gathered per block of 4 output rows
-__global__ __launch_bounds__(kBlock) void k_ebe_generic(const int *__restrict__ dof, const uint8_t *__restrict__ sgn,
-                                                        const double *__restrict__ ck, const double *__restrict__ ke,
-                                                        const double *__restrict__ x, double *__restrict__ y, int nd,
-                                                        int64_t ne, int64_t e_lo, int64_t e_hi)
-{
-    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    if (e >= e_hi) return;
-    const double c = ck[e];
-    for (int a0 = 0; a0 < nd; a0 += 4) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b = 0; b < nd; ++b) {
-            double v = x[dof[(size_t)b * ne + e]];
-            if (sgn[(size_t)b * ne + e]) v = -v;
-            v = c * v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (a0 + i < nd) acc[i] = fma(ke[(size_t)(a0 + i) * nd + b], v, acc[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (a0 + i < nd) {
-                double o = acc[i];
-                if (sgn[(size_t)(a0 + i) * ne + e]) o = -o;
-                y[dof[(size_t)(a0 + i) * ne + e]] += o;
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// interface kernels
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__ y, const int *__restrict__ idx,
-                                                      double *__restrict__ send, int64_t count)
-{
-    for (int64_t m = blockIdx.x * (int64_t)kBlock + threadIdx.x; m < count; m += (int64_t)gridDim.x * kBlock)
-        send[m] = y[idx[m]];
-}
-
-// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
-template <bool DOT>
-__global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
-                                                  const int *__restrict__ fptr, const int *__restrict__ fpos,
-                                                  const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
-                                                  int64_t nb, double *__restrict__ partials)
-{
-    double dot = 0.0;
-    for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
-        double v = y[d];
-        const int q0 = fptr[d], q1 = fptr[d + 1];
-        for (int q = q0; q < q1; ++q) v += recv[fpos[q]];
-        if (q1 > q0) y[d] = v;
-        if constexpr (DOT)
-            if ((flags[d] & 3) == 3) dot += xdot[d] * v;
-    }
-    if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// vector kernels (grid-stride, 16 B per lane, scalar tail)
-// ------------------------------------------------------------------------------------------------
-__global__ void k_scalar_alpha(double *st, double *mirror)
-{
-    const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
-    st[ST_RHO] = rho;
-    double stop = st[ST_STOP], alpha = st[ST_ALPHA];
-    if (pq <= 0.0 || isinf(pq)) stop = 1.0;                       // :492-494
-    else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }      // :495-498
-    st[ST_ALPHA] = alpha;
-    st[ST_STOP] = stop;
-    if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
-}
-
-// beta = rho / rho_prev (:475) with rho = st[RHO_NEXT] read on the device: the host need not know rho yet when it
-// enqueues this kernel (look-ahead), and divides the same two doubles later for its own Flag-4 test (:476-478).
-__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, const double *__restrict__ pi,
-                                                     const double *__restrict__ r, const double *__restrict__ minv,
-                                                     const double *__restrict__ st, double rho_prev, int first, int nt, int64_t n)
-{
-    const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
-    const int64_t n2 = n >> 1;
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    double2 *po2 = reinterpret_cast<double2 *>(po);
-    const double2 *pi2 = reinterpret_cast<const double2 *>(pi);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r), *m2 = reinterpret_cast<const double2 *>(minv);
-    for (int64_t t = t0; t < n2; t += ts) {
-        const double2 rr = (nt & 4) ? ntload(r2 + t) : r2[t], mm = (nt & 4) ? ntload(m2 + t) : m2[t];
-        double2 z = make_double2(mm.x * rr.x, mm.y * rr.y);        // :447
-        if (!first) { const double2 pp = (nt & 4) ? ntload(pi2 + t) : pi2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
-        if (nt & 1) ntstore(po2 + t, z); else po2[t] = z;
-    }
-    if ((n & 1) && t0 == 0) {
-        const int64_t i = n - 1;
-        double z = minv[i] * r[i];
-        if (!first) z = z + beta * pi[i];
-        po[i] = z;
-    }
-}
-
-// whole status block -> host-visible ring slot (multi-GPU: the all-reduce rewrote the block in place)
-__global__ void k_publish(const double *__restrict__ st, double *__restrict__ mirror)
-{
-    if (threadIdx.x < ST_COUNT) mirror[threadIdx.x] = st[threadIdx.x];
-}
-
-struct Up { double sqp, sqx, sqr, rho, ninf; };
-
-__device__ __forceinline__ void update_one(double alpha, double p, double q, double &r, double xo, double &xn, double m,
-                                           uint8_t f, Up &u)
-{
-    const bool w = (f & 3) == 3;
-    if (w) { u.sqp += p * p; u.sqx += xo * xo; }                  // :504-505 (x BEFORE the update)
-    const double rn = r - alpha * q;                               // :501
-    r = rn;
-    xn = xo + alpha * p;                                           // :516
-    const double z = m * rn;                                       // :447 of the next iteration
-    if ((f & 2) && isinf(z)) u.ninf += 1.0;                        // :448
-    if (w) { u.sqr += rn * rn; u.rho += z * rn; }                  // :506, :462
-}
-
-// ALPHA: st[PQ] holds the all-reduced p.Ap; every block forms alpha / stop itself exactly like k_scalar_alpha (same two
-// doubles, same division), block 0 stores them - the separate one-thread launch of the multi-GPU loop is gone.
-template <bool ALPHA>
-__global__ __launch_bounds__(kBlock) void k_fused_update(double *st, double *mirror, const double *__restrict__ p,
-                                                         const double *__restrict__ q, const double *__restrict__ r,
-                                                         double *__restrict__ rn, const double *__restrict__ xo,
-                                                         double *__restrict__ xn,
-                                                         const double *__restrict__ minv, const uint8_t *__restrict__ flags,
-                                                         double *__restrict__ partials, int nt, int64_t n)
-{
-    __shared__ double lds[5 * kWavesPerBlock];
-    Up u = {0, 0, 0, 0, 0};
-    double stop = st[ST_STOP], alpha = st[ST_ALPHA];
-    if constexpr (ALPHA) {                                         // :492-498; the sticky stop flag only ever goes 0 -> 1
-        const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
-        if (pq <= 0.0 || isinf(pq)) stop = 1.0;
-        else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            st[ST_RHO] = rho; st[ST_ALPHA] = alpha; st[ST_STOP] = stop;
-            if (mirror) { mirror[ST_RHO] = rho; mirror[ST_PQ] = pq; mirror[ST_ALPHA] = alpha; mirror[ST_STOP] = stop; }
-        }
-    }
-    if (stop == 0.0) {                                             // frozen when pq/alpha broke down (:492-498)
-        const int64_t n2 = n >> 1;
-        const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-        const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
-        const double2 *x2 = reinterpret_cast<const double2 *>(xo), *m2 = reinterpret_cast<const double2 *>(minv);
-        const double2 *r2 = reinterpret_cast<const double2 *>(r);
-        double2 *rn2 = reinterpret_cast<double2 *>(rn), *xn2 = reinterpret_cast<double2 *>(xn);
-        const uchar2 *f2 = reinterpret_cast<const uchar2 *>(flags);
-        for (int64_t t = t0; t < n2; t += ts) {
-            const bool ntl = (nt & 4) != 0;
-            const double2 pp = ntl ? ntload(p2 + t) : p2[t], qq = ntl ? ntload(q2 + t) : q2[t], xx = ntl ? ntload(x2 + t) : x2[t],
-                          mm = ntl ? ntload(m2 + t) : m2[t];
-            double2 rr = ntl ? ntload(r2 + t) : r2[t], xo2;
-            const uchar2 ff = f2[t];
-            update_one(alpha, pp.x, qq.x, rr.x, xx.x, xo2.x, mm.x, ff.x, u);
-            update_one(alpha, pp.y, qq.y, rr.y, xx.y, xo2.y, mm.y, ff.y, u);
-            if (nt & 1) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
-            else { rn2[t] = rr; xn2[t] = xo2; }
-        }
-        if ((n & 1) && t0 == 0) {
-            const int64_t i = n - 1;
-            double rr = r[i], xnew;
-            update_one(alpha, p[i], q[i], rr, xo[i], xnew, minv[i], flags[i], u);
-            rn[i] = rr;
-            xn[i] = xnew;
-        }
-    }
-    double v[5] = {u.sqp, u.sqx, u.sqr, u.rho, u.ninf};
-    block_sum<5>(v, lds);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
-}
-
-__global__ __launch_bounds__(kBlock) void k_residual(const double *__restrict__ b, const double *__restrict__ ax,
-                                                     double *__restrict__ r, const double *__restrict__ minv,
-                                                     const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
-{
-    __shared__ double lds[3 * kWavesPerBlock];
-    double sqr = 0, rho = 0, ninf = 0;
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double rn = b[i] - ax[i];                            // :414, :531
-        r[i] = rn;
-        const double z = minv[i] * rn;
-        const uint8_t f = flags[i];
-        if ((f & 2) && isinf(z)) ninf += 1.0;
-        if ((f & 3) == 3) { sqr += rn * rn; rho += z * rn; }       // :415, :462
-    }
-    double v[3] = {sqr, rho, ninf};
-    block_sum<3>(v, lds);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
-}
-
-__global__ __launch_bounds__(kBlock) void k_dot_w(const double *__restrict__ a, const double *__restrict__ b,
-                                                  const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
-{
-    __shared__ double lds[kWavesPerBlock];
-    double s = 0;
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        if ((flags[i] & 3) == 3) s += a[i] * b[i];
-    double v[1] = {s};
-    block_sum<1>(v, lds);
-    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-}
-
-__global__ __launch_bounds__(kBlock) void k_invert_free(double *__restrict__ minv, const double *__restrict__ d,
-                                                        const uint8_t *__restrict__ flags, int64_t n)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        minv[i] = (flags[i] & 2) ? 1.0 / d[i] : 0.0;               // :351-352
-}
-
-__global__ __launch_bounds__(kBlock) void k_axpby(double *__restrict__ o, double a, const double *__restrict__ x, double b,
-                                                  const double *__restrict__ y, int64_t n)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        o[i] = a * x[i] + b * y[i];
-}
-
-__global__ __launch_bounds__(kBlock) void k_scale(double *__restrict__ o, double a, const double *__restrict__ x, int64_t n)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) o[i] = a * x[i];
-}
-
-__global__ __launch_bounds__(kBlock) void k_mask_free(double *__restrict__ x, const uint8_t *__restrict__ flags, int64_t n)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        if (!(flags[i] & 2)) x[i] = 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// HBM stream microbenchmarks (pcg_bench_hbm): the practical bandwidth ceiling of THIS box beside the 8 TB/s
-// spec, measured with the access shape of the solver's kernels (16 B per lane, non-temporal, grid-stride).
-// mode 0: read-only (the SpMV is 98 % reads)   mode 1: copy (1 read + 1 write, the vector kernels' mix)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_stream_read(const double2 *__restrict__ a, double *__restrict__ out, int64_t n2)
-{
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    int64_t t = t0;
-    for (; t + 7 * ts < n2; t += 8 * ts) {                 // eight 16-B loads in flight per lane
-        const double2 v0 = ntload(a + t), v1 = ntload(a + t + ts), v2 = ntload(a + t + 2 * ts), v3 = ntload(a + t + 3 * ts);
-        const double2 v4 = ntload(a + t + 4 * ts), v5 = ntload(a + t + 5 * ts), v6 = ntload(a + t + 6 * ts), v7 = ntload(a + t + 7 * ts);
-        s0 += (v0.x + v0.y) + (v4.x + v4.y); s1 += (v1.x + v1.y) + (v5.x + v5.y);
-        s2 += (v2.x + v2.y) + (v6.x + v6.y); s3 += (v3.x + v3.y) + (v7.x + v7.y);
-    }
-    for (; t < n2; t += ts) { const double2 v = ntload(a + t); s0 += v.x + v.y; }
-    const double s = (s0 + s1) + (s2 + s3);
-    if (s == 1.2345e-300) out[0] = s;              // keeps the loads alive, never true for the benchmark data
-}
-
-// Access-pattern probes (modes 2-4 of pcg_bench_hbm; tools only): a wave streams its own contiguous "slice" of
-// W steps x 4608 B like k_spmv reads the values of a slice (nine 512-B planes per step), without gathers or FMAs.
-//   PAT 0: wave g owns region g, g + G, ...; 8-B loads per lane (k_spmv RPL = 1)
-//   PAT 1: the same regions with 16-B loads per lane (two steps = nine 1-KB loads)
-//   PAT 2: step-major across the grid: at step k wave g reads chunk (k * G + g) of its round - one compact window
-template <int PAT>
-__global__ __launch_bounds__(kBlock) void k_stream_slices(const double *__restrict__ a, double *__restrict__ out, int64_t n_regions, int W)
-{
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t G = (int64_t)gridDim.x * kWavesPerBlock, g = (int64_t)blockIdx.x * kWavesPerBlock + wid;
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int64_t r = g; r < n_regions; r += G) {
-        if constexpr (PAT == 0 || PAT == 2) {
-            const int64_t round = r / G;
-#pragma unroll 3
-            for (int k = 0; k < W; ++k) {
-                const double *p = PAT == 0 ? a + ((size_t)r * W + k) * 576 + lane
-                                           : a + (((size_t)round * W + k) * G + g) * 576 + lane;
-                double v[9];
-#pragma unroll
-                for (int c = 0; c < 9; ++c) v[c] = ntload(p + c * 64);
-                s0 += (v[0] + v[1]) + v[2]; s1 += (v[3] + v[4]) + v[5]; s2 += (v[6] + v[7]) + v[8];
-            }
-        } else {
-            const double2 *p2 = reinterpret_cast<const double2 *>(a + (size_t)r * W * 576) + lane;
-            for (int k = 0; k + 1 < W; k += 2) {
-                double2 v[9];
-#pragma unroll
-                for (int c = 0; c < 9; ++c) v[c] = ntload(p2 + ((size_t)k / 2 * 9 + c) * 64);
-#pragma unroll
-                for (int c = 0; c < 9; c += 3) { s0 += v[c].x + v[c].y; s1 += v[c + 1].x + v[c + 1].y; s2 += v[c + 2].x + v[c + 2].y; }
-            }
-        }
-    }
-    const double s = (s0 + s1) + s2;
-    if (s == 1.2345e-300) out[0] = s;
-}
-
-__global__ __launch_bounds__(kBlock) void k_stream_copy(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
-{
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = t0; t < n2; t += ts) b[t] = ntload(a + t);
-}
-
-__global__ __launch_bounds__(kBlock) void k_stream_copy_nt(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = t0; t < n2; t += ts) {
-        const double2 v = ntload(a + t);
-        v2 w; w.x = v.x; w.y = v.y;
-        __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(b + t));
-    }
-}
-// store-flavour probes: MODE 0 = sc1, 1 = sc0 sc1, 2 = nt sc0 sc1 (development, PCG_BENCH_SPMV_CTX)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_stream_copy_sc(const double2 *__restrict__ a, double2 *__restrict__ b, int64_t n2)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = t0; t < n2; t += ts) {
-        const double2 v = ntload(a + t);
-        v4f w;
-        __builtin_memcpy(&w, &v, 16);
-        double2 *p = b + t;
-        if constexpr (MODE == 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-        else if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(w) : "memory");
-    }
-}
-__global__ __launch_bounds__(kBlock) void k_stream_read_plain(const double2 *__restrict__ a, double *__restrict__ out, int64_t n2)
-{
-    double s = 0;
-    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = t0; t < n2; t += ts) { const double2 v = a[t]; s += v.x + v.y; }
-    if (s == 1.2345e-300) out[0] = s;
-}
 
 // ------------------------------------------------------------------------------------------------
 // back end
@@ -1562,14 +68,13 @@ class HipBackend : public Backend {
     std::vector<void *> hex_allocs_;
     std::vector<int> hex_nodes_host_[2];                 // to fold the ownership / free masks into the slot table (upload_masks)
     std::vector<unsigned short> hex_tslot_host_[2];
-    // Same-box A/B at 10 M dof (tools/ebe_lab.py, profiles/r02_ebe_lab_*.log), one apply with the fused p.Ap:
-    //   k_ebe_chunk, 512-element chunks (round 1)                      0.195 ms
-    //   k_ebe_hex,   256-element chunks, 5 blocks per CU, ds_add_f64   0.180 ms
+    // Same-box A/B at 10 M dof (round 2, profiles/r02_ebe_lab_*.log), one apply with the fused p.Ap:
+    //   round-1 kernel (512-element chunks, chunk-id lists)            0.195 ms   (removed in round 3)
+    //   k_ebe_hex,   256-element chunks, 5 blocks per CU, ds_add_f64   0.180 ms   <- meshes below 131 k elements
     //   k_ebe_hexs,  512-element chunks in two passes, ds_add_f64      0.158 ms   <- default for large meshes
     // (512 elements per thread pair at once, 6 blocks per CU, read-add-write accumulation, several chunks per block with the
-    // next one prefetched: all measured, all slower - DESIGN.md section 4b.)  PCG_EBE_HEX=0 selects k_ebe_chunk for the hex8
-    // class too; PCG_EBE_ACC=0 the read-add-write accumulation.
-    int hex_mode_ = 1, hex_ept_ = 2, hex_npt_ = 3, hex_acc_ = 1;
+    // next one prefetched, the matrix cores: all measured, all slower - DESIGN.md section 4b.)
+    int hex_ept_ = 2, hex_npt_ = 3;
     int n_chunks_total_[2] = {0, 0};
     int sh_count_[2] = {0, 0};
     int *d_sh_node_[2] = {nullptr, nullptr}, *d_sh_ptr_[2] = {nullptr, nullptr};
@@ -1632,10 +137,6 @@ class HipBackend : public Backend {
     // nothing on another (1.027 vs 1.039 ms) and made the matrix-free operator 17 % SLOWER there (3220 -> 2685 it/s at 10 M
     // dof, twice each; profiles/r02_alloc_contiguous_ab.txt, session AN).
     int alloc_contig_ = 0;
-    // PCG_EBE_MFMA=1: hex8 chunks on the matrix cores (k_ebe_mfma) instead of the v_fma kernel (k_ebe_chunk).  Off by
-    // default: measured 0.25 ms vs 0.20 ms per apply at 10 M dof - neither kernel is bound by its arithmetic
-    // (profiles/r01_pmc_ebe_mfma.md).
-    bool ebe_mfma_ = false;
 
 public:
     explicit HipBackend(int device)
@@ -1660,6 +161,16 @@ public:
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
+        // fused vector phase (k_vec<true>): its grid barrier needs every workgroup resident - one 1024-thread workgroup per
+        // CU, asked of the occupancy query here; PCG_VEC_FUSED=0 keeps the split form (k_vec<false> + k_reduce + k_update_p)
+        d_vec_sync_ = (unsigned long long *)alloc(sizeof(unsigned long long) * kVecSyncWords);
+        HIP_CHECK(hipMemsetAsync(d_vec_sync_, 0, sizeof(unsigned long long) * kVecSyncWords, st_));
+        {
+            int per_cu = 0;
+            const hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_vec<true>, kVecBlock, 0);
+            vec_fused_hw_ = rc == hipSuccess && per_cu >= 1;
+            (void)hipGetLastError();
+        }
         // development knobs (tools/tune_spmv.py); the defaults are the tuned values
         if (const char *e = getenv("PCG_SPMV_BLOCKS_PER_CU")) spmv_blocks_per_cu_ = std::max(1, atoi(e));
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
@@ -1667,16 +178,13 @@ public:
         if (const char *e = getenv("PCG_ALLOC_CONTIG")) alloc_contig_ = atoi(e);
         if (const char *e = getenv("PCG_SPMV_DICT_BLOCK")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) dict_block_ = b; }
         reload_tuning();
-        if (const char *e = getenv("PCG_EBE_MFMA")) ebe_mfma_ = atoi(e) != 0;
-        if (const char *e = getenv("PCG_EBE_HEX")) hex_mode_ = atoi(e);
-        if (const char *e = getenv("PCG_EBE_ACC")) hex_acc_ = atoi(e);
     }
     ~HipBackend() override
     {
         (void)hipSetDevice(dev_);
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
-                        (void *)d_part_fix_})
+                        (void *)d_part_fix_, (void *)d_vec_sync_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke, (void *)D.ke_rows})
@@ -1863,7 +371,7 @@ public:
                     if (D.count[ph]) up(D.list[ph], K.list[ph]);
                 }
             }
-            if (hex_mode_ > 0 && C.cls[0].n_chunks > 0 && !ebe_mfma_) build_hex_tables(C);
+            if (C.cls[0].n_chunks > 0) build_hex_tables(C);
             for (int ph = 0; ph < 2; ++ph) {
                 sh_count_[ph] = (int)C.sh_node[ph].size();
                 np += (3 * C.sh_node[ph].size() + kBlock - 1) / kBlock;
@@ -1930,14 +438,12 @@ public:
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, hex_tab_[ph], ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
         };
-        if (hex_acc_ == 1) { if (dot) go(k_ebe_hexs<LB, true, 1>); else go(k_ebe_hexs<LB, false, 1>); }
-        else { if (dot) go(k_ebe_hexs<LB, true, 0>); else go(k_ebe_hexs<LB, false, 0>); }
+        if (dot) go(k_ebe_hexs<LB, true, 1>); else go(k_ebe_hexs<LB, false, 1>);
     }
     template <int EPT, int NPT, int LB>
     void launch_hex(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
-        if (hex_acc_ == 1) launch_hex_a<EPT, NPT, LB, 1>(ph, count, ke, x, y, dot, part, dot_lo);
-        else launch_hex_a<EPT, NPT, LB, 0>(ph, count, ke, x, y, dot, part, dot_lo);
+        launch_hex_a<EPT, NPT, LB, 1>(ph, count, ke, x, y, dot, part, dot_lo);
     }
     void ebe_launch_range(const EbeRange &r, const double *x, double *y)
     {
@@ -1949,16 +455,6 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
-    template <int NNP, int EPT, bool FULL>
-    void launch_chunks(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
-    {
-        if (dot)
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
-        else
-            hipLaunchKernelGGL((k_ebe_chunk<NNP, EPT, FULL, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_,
-                               d_ch_nodes_, d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
-    }
     template <int NNP>
     void launch_rows(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
@@ -1969,35 +465,19 @@ public:
             hipLaunchKernelGGL((k_ebe_rows<NNP, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
                                d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
     }
-    template <int EPT>
-    void launch_mfma(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
-    {
-        if (dot)
-            hipLaunchKernelGGL((k_ebe_mfma<EPT, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
-        else
-            hipLaunchKernelGGL((k_ebe_mfma<EPT, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo);
-    }
     // -> number of dot partials the launch writes
     int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         switch (D.nnp) {
         case 8:
-            if (D.full && hex_mode_ > 0 && hex_tab_[ph].hdr) {     // hex8 class through the per-launch tables
+            if (D.full && hex_tab_[ph].hdr) {                     // hex8 class through the per-launch tables
                 if (hex_ept_ == 2 && hex_npt_ == 3) launch_hexs<4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);          // 512-element chunks, two passes
                 else if (hex_ept_ == 1 && hex_npt_ == 2) launch_hex<1, 2, 5>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo);   // 256-element chunks
                 else throw std::runtime_error("k_ebe_hex: unexpected chunk shape");
                 break;
             }
-            if (D.full && ebe_mfma_) {                          // hex8 class on the matrix cores
-                if (D.ept == 2) launch_mfma<2>(D, ph, x, y, dot, part, dot_lo);
-                else launch_mfma<1>(D, ph, x, y, dot, part, dot_lo);
-                break;
-            }
-            if (!D.full) launch_rows<8>(D, ph, x, y, dot, part, dot_lo);             // fewer than 8 nodes, padded
-            else if (D.ept == 2) launch_chunks<8, 2, true>(D, ph, x, y, dot, part, dot_lo);
-            else launch_chunks<8, 1, true>(D, ph, x, y, dot, part, dot_lo);
+            if (D.full) throw std::runtime_error("hex8 class without its launch tables");
+            launch_rows<8>(D, ph, x, y, dot, part, dot_lo);                          // fewer than 8 nodes, padded
             break;
         case 16: launch_rows<16>(D, ph, x, y, dot, part, dot_lo); break;
         case 24: launch_rows<24>(D, ph, x, y, dot, part, dot_lo); break;
@@ -2197,20 +677,10 @@ public:
     {
         if (ebe_)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, red,
-                               mirror_of(red), 0);
+                               mirror_of(red));
         else
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                               cnt_fix_, red, mirror_of(red), 0);
-        HIP_CHECK(hipGetLastError());
-    }
-    void reduce_dot_alpha(double *st) override
-    {
-        if (ebe_)
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_ebe_, cnt_ebe_, 0, d_part_fix_, cnt_fix_, st,
-                               mirror_of(st), 1);
-        else
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_spmv_, cnt_spmv_, kMaxPartials, d_part_fix_,
-                               cnt_fix_, st, mirror_of(st), 1);
+                               cnt_fix_, red, mirror_of(red));
         HIP_CHECK(hipGetLastError());
     }
     // ---- status ring in host-visible (pinned, mapped) memory: kStatusSlots copies of the status block ------------
@@ -2248,6 +718,8 @@ public:
     {
         vec_nt_ = 5;
         if (const char *e = getenv("PCG_VEC_NT")) vec_nt_ = atoi(e);          // bit 0: p / r' / x' stores, bit 1: SpMV y stores, bit 2: vector loads
+        vec_fused_ok_ = vec_fused_hw_;
+        if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_hw_ && atoi(e) != 0;
     }
     void publish_status(bool copy_block) override
     {
@@ -2263,33 +735,51 @@ public:
         const volatile double *m = h_mirror_ + (size_t)slot * ST_COUNT;
         for (int k = 0; k < ST_COUNT; ++k) host_out[k] = m[k];
     }
-    void scalar_alpha(double *st) override
-    {
-        hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, st_, st, mirror_of(st));
-        HIP_CHECK(hipGetLastError());
-    }
     void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
                   bool first) override
     {
         hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, vec_nt_, n_);
         HIP_CHECK(hipGetLastError());
     }
-    void fused_update(double *st, const double *p, const double *q, const double *r, double *rn, const double *xo, double *xn,
-                      const double *minv, bool with_alpha) override
+    // ---- vector phase (k_vec) --------------------------------------------------------------------------------------
+    unsigned long long *d_vec_sync_ = nullptr;     // arrival counters of the fused form's grid barrier (monotonic)
+    unsigned long long vec_seq_ = 0;               // fused launches so far
+    bool vec_fused_hw_ = false, vec_fused_ok_ = false;   // the device admits the grid / and PCG_VEC_FUSED does not say 0
+    int vec_blocks(int64_t n) const
     {
-        cnt_vec_ = vec_grid(n_);
-        if (with_alpha)
-            hipLaunchKernelGGL((k_fused_update<true>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, mirror_of(st), p, q, r, rn, xo, xn, minv,
-                               d_flags_, d_part_, vec_nt_, n_);
-        else
-            hipLaunchKernelGGL((k_fused_update<false>), dim3(cnt_vec_), dim3(kBlock), 0, st_, st, (double *)nullptr, p, q, r, rn, xo, xn,
-                               minv, d_flags_, d_part_, vec_nt_, n_);
+        const int64_t g = ((n >> 1) + kVecBlock - 1) / kVecBlock;
+        return (int)std::max<int64_t>(1, std::min<int64_t>(g, n_cu_));      // one workgroup per CU at most: co-resident
+    }
+    bool vec_fused_available() const override { return vec_fused_ok_; }
+    bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rn, const double *xo,
+                    double *xn, const double *minv, double *p_next) override
+    {
+        const bool fused = p_next != nullptr;
+        if (fused && !vec_fused_ok_) throw std::runtime_error("vec_update: the fused form is not available on this device");
+        cnt_vec_ = vec_blocks(n_);
+        VecArgs a{};
+        a.st = st; a.mirror = mirror_of(st);
+        a.p = p; a.q = q; a.r = r; a.rn = rn; a.xo = xo; a.xn = xn; a.minv = minv; a.flags = d_flags_;
+        a.p_next = p_next; a.partials = d_part_;
+        if (pq_src == 2) {
+            if (ebe_) { a.pa = d_part_ebe_; a.count_a = cnt_ebe_; }
+            else { a.pa = d_part_spmv_; a.count_a = cnt_spmv_; }
+            a.pb = cnt_fix_ ? d_part_fix_ : nullptr; a.count_b = cnt_fix_;
+        }
+        a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_;
+        if (fused) {
+            a.seq = ++vec_seq_;
+            hipLaunchKernelGGL((k_vec<true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+        } else {
+            hipLaunchKernelGGL((k_vec<false>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+        }
         HIP_CHECK(hipGetLastError());
+        return fused;
     }
     void reduce_update(double *red5) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(5), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red5,
-                           mirror_of(red5), 0);
+                           mirror_of(red5));
         HIP_CHECK(hipGetLastError());
     }
     void residual(const double *b, const double *ax, double *r, const double *minv) override
@@ -2301,7 +791,7 @@ public:
     void reduce_residual(double *red3) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(3), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red3,
-                           mirror_of(red3), 0);
+                           mirror_of(red3));
         HIP_CHECK(hipGetLastError());
     }
     void dot_w(const double *a, const double *b) override
@@ -2313,7 +803,7 @@ public:
     void reduce_dotw(double *red1) override
     {
         hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st_, d_part_, cnt_vec_, kMaxPartials, (const double *)nullptr, 0, red1,
-                           mirror_of(red1), 0);
+                           mirror_of(red1));
         HIP_CHECK(hipGetLastError());
     }
     void copy_diag(double *d) override { d2d(d, d_diag_, sizeof(double) * (size_t)n_); }
@@ -2365,13 +855,7 @@ public:
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         for (int k = -3; k < reps; ++k) {
             HIP_CHECK(hipEventRecord(e0, st_));
-            const int W = 28;                                              // steps per region (even; a 27-wide slice + 1)
-            const int64_t n_regions = (int64_t)(bytes / ((size_t)W * 4608));
             if (mode == 1) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(kBlock), 0, st_, a, b, n2);
-            else if (mode == 2) hipLaunchKernelGGL((k_stream_slices<0>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out, n_regions, W);
-            else if (mode == 3) hipLaunchKernelGGL((k_stream_slices<1>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out, n_regions, W);
-            else if (mode == 4) hipLaunchKernelGGL((k_stream_slices<2>), dim3(grid), dim3(kBlock), 0, st_, (const double *)a, out,
-                                                   n_regions / ((int64_t)grid * kWavesPerBlock) * ((int64_t)grid * kWavesPerBlock), W);
             else hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(kBlock), 0, st_, a, out, n2);
             HIP_CHECK(hipEventRecord(e1, st_));
             HIP_CHECK(hipEventSynchronize(e1));
@@ -2400,92 +884,19 @@ public:
         }
         const int grid = spmv_grid(n_slices_);
         const bool dot = bench_dot_;
-        // PCG_BENCH_SPMV_CTX (development, tools/spmv_state.py): what a launch finds when it is NOT repeated back to back -
-        // bit 0: x rewritten by a copy kernel right before the launch (as k_update_p does in the loop); bit 1: 1 GiB of
-        // unrelated data streamed through the caches before the launch; bit 2: no host wait between launches.
-        int ctx = 0;
-        if (const char *e = getenv("PCG_BENCH_SPMV_CTX")) ctx = atoi(e);
-        if (ctx == 8) {            // placement probe: the same x in differently placed buffers (stderr)
-            const size_t nb = sizeof(double) * (size_t)n_;
-            char *slab = (char *)alloc(nb * 2 + (64u << 20));
-            std::vector<std::pair<const char *, double *>> cand;
-            cand.push_back({"x as given", const_cast<double *>(x)});
-            for (int k = 0; k < 4; ++k) cand.push_back({"fresh hipMalloc", (double *)alloc(nb)});
-            cand.push_back({"slab + 0", (double *)slab});
-            cand.push_back({"slab + 4 KiB", (double *)(slab + 4096)});
-            cand.push_back({"slab + 64 KiB", (double *)(slab + 65536)});
-            cand.push_back({"slab + 1 MiB", (double *)(slab + (1u << 20))});
-            cand.push_back({"slab + 2 MiB rounded up", (double *)(((uintptr_t)slab + (2u << 20) - 1) / (2u << 20) * (2u << 20))});
-            hipEvent_t a, b;
-            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            for (auto &c : cand) {
-                if (c.second != x) HIP_CHECK(hipMemcpyAsync(c.second, x, nb, hipMemcpyDeviceToDevice, st_));
-                std::vector<float> t;
-                for (int k = -3; k < 30; ++k) {
-                    HIP_CHECK(hipEventRecord(a, st_));
-                    if (C_ == 64) launch_spmv<1>(c.second, y, 0, n_slices_, dot, grid); else launch_spmv<2>(c.second, y, 0, n_slices_, dot, grid);
-                    HIP_CHECK(hipEventRecord(b, st_));
-                    HIP_CHECK(hipEventSynchronize(b));
-                    float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-                    if (k >= 0) t.push_back(ms);
-                }
-                std::sort(t.begin(), t.end());
-                fprintf(stderr, "placement %-26s x=%p (mod 2 MiB = %7zu)  y=%p vals=%p  median %.4f ms\n", c.first, (void *)c.second,
-                        (size_t)((uintptr_t)c.second % (2u << 20)), (void *)y, (void *)d_vals_, t[t.size() / 2]);
-            }
-            // and y placed in the slab
-            {
-                double *y2 = (double *)(((uintptr_t)slab + nb + (4u << 20)) / (2u << 20) * (2u << 20));
-                std::vector<float> t;
-                for (int k = -3; k < 30; ++k) {
-                    HIP_CHECK(hipEventRecord(a, st_));
-                    if (C_ == 64) launch_spmv<1>(x, y2, 0, n_slices_, dot, grid); else launch_spmv<2>(x, y2, 0, n_slices_, dot, grid);
-                    HIP_CHECK(hipEventRecord(b, st_));
-                    HIP_CHECK(hipEventSynchronize(b));
-                    float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-                    if (k >= 0) t.push_back(ms);
-                }
-                std::sort(t.begin(), t.end());
-                fprintf(stderr, "placement y in slab (2 MiB aligned) y=%p median %.4f ms\n", (void *)y2, t[t.size() / 2]);
-            }
-            HIP_CHECK(hipEventDestroy(a)); HIP_CHECK(hipEventDestroy(b));
-            for (size_t k = 1; k <= 4; ++k) release(cand[k].second);
-            release(slab);
-            ctx = 0;
-        }
-        double *x2 = (ctx & 1) ? (double *)alloc(sizeof(double) * (size_t)n_) : nullptr;
-        const int64_t fl2 = (int64_t)(1 << 30) / 16;
-        double2 *fl = (ctx & 2) ? (double2 *)alloc((size_t)fl2 * 16) : nullptr;
-        if (fl) HIP_CHECK(hipMemsetAsync(fl, 0x3c, (size_t)fl2 * 16, st_));
-        auto pre = [&]() {
-            const double2 *xa = reinterpret_cast<const double2 *>(x);
-            double2 *xb = reinterpret_cast<double2 *>(x2);
-            if (x2 && (ctx & 64)) hipLaunchKernelGGL((k_stream_copy_sc<0>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
-            else if (x2 && (ctx & 128)) hipLaunchKernelGGL((k_stream_copy_sc<1>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
-            else if (x2 && (ctx & 256)) hipLaunchKernelGGL((k_stream_copy_sc<2>), dim3(n_cu_ * 4), dim3(kBlock), 0, st_, xa, xb, n_ / 2);
-            else if (x2 && (ctx & 16)) hipLaunchKernelGGL(k_stream_copy_nt, dim3(n_cu_ * 4), dim3(kBlock), 0, st_, reinterpret_cast<const double2 *>(x),
-                                                     reinterpret_cast<double2 *>(x2), n_ / 2);
-            else if (x2) hipLaunchKernelGGL(k_stream_copy, dim3(n_cu_ * 4), dim3(kBlock), 0, st_, reinterpret_cast<const double2 *>(x),
-                                            reinterpret_cast<double2 *>(x2), n_ / 2);
-            if (fl && (ctx & 32)) hipLaunchKernelGGL(k_stream_read_plain, dim3(n_cu_ * 32), dim3(kBlock), 0, st_, (const double2 *)fl, y, fl2);
-            else if (fl) hipLaunchKernelGGL(k_stream_read, dim3(n_cu_ * 32), dim3(kBlock), 0, st_, (const double2 *)fl, y, fl2);
-        };
-        const double *xs = x2 ? x2 : x;
-        for (int k = 0; k < warmup; ++k) { pre(); if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid); }
+        const double *xs = x;
+        for (int k = 0; k < warmup; ++k) { if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid); }
         std::vector<hipEvent_t> ev((size_t)2 * reps);
         for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
         for (int k = 0; k < reps; ++k) {
-            pre();
             HIP_CHECK(hipEventRecord(ev[2 * k], st_));
             if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid);
             HIP_CHECK(hipEventRecord(ev[2 * k + 1], st_));
-            if (!(ctx & 4)) HIP_CHECK(hipEventSynchronize(ev[2 * k + 1]));
+            HIP_CHECK(hipEventSynchronize(ev[2 * k + 1]));
         }
         HIP_CHECK(hipStreamSynchronize(st_));
         for (int k = 0; k < reps; ++k) HIP_CHECK(hipEventElapsedTime(&ms_each[k], ev[2 * k], ev[2 * k + 1]));
         for (auto &e : ev) HIP_CHECK(hipEventDestroy(e));
-        if (x2) release(x2);
-        if (fl) release(fl);
         return 0;
     }
 };

@@ -1,0 +1,522 @@
+// Matrix-free (element-by-element) operator kernels (reference: pcg_solver.py:277-280 + :300).
+#pragma once
+#include "hip_common.hpp"
+
+namespace pcg {
+
+// ------------------------------------------------------------------------------------------------
+// Matrix-free operator (the reference's element-by-element form, pcg_solver.py:277-280 + :300).
+// One thread per element of ONE colour (no two elements of a launch share a node -> plain
+// read-modify-write of y, no atomics, summation order = colour order).  All lanes of a wave work on
+// the same pattern type, so Ke[a][b] is wave-uniform: it is fetched with scalar loads into SGPRs and
+// used as the scalar operand of v_fma_f64 - no LDS, no per-lane copy of the 24x24 matrix.  Four
+// output rows are accumulated at a time (independent FMA chains).
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, const unsigned *__restrict__ sgn,
+                                                const double *__restrict__ ck, const double *__restrict__ ke,
+                                                const double *__restrict__ x, double *__restrict__ y, int64_t ne,
+                                                int64_t e_lo, int64_t e_hi)
+{
+    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (e >= e_hi) return;
+    int d[ND];
+    double u[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a) d[a] = __builtin_nontemporal_load(dof + (size_t)a * ne + e);
+    const unsigned sg = __builtin_nontemporal_load(sgn + e);
+    const double c = __builtin_nontemporal_load(ck + e);
+#pragma unroll
+    for (int b = 0; b < ND; ++b) {
+        double v = x[d[b]];                                  // :277 gather
+        if ((sg >> b) & 1u) v = -v;                          // :278
+        u[b] = c * v;                                        // :279 Ck * U
+    }
+    static_assert(ND % 4 == 0, "ND must be a multiple of 4");
+#pragma unroll
+    for (int a0 = 0; a0 < ND; a0 += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fma(ke[(a0 + i) * ND + b], u[b], acc[i]);   // :279 Ke @ (.)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double o = acc[i];
+            if ((sg >> (a0 + i)) & 1u) o = -o;               // :280
+            y[d[a0 + i]] += o;                               // :300 (conflict-free inside a colour)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hex8 chunks, second form (k_ebe_hex).  Same algorithm, same summation order per node and the same host-side chunk
+// structures as k_ebe_chunk; what changes is how a workgroup gets to its arithmetic and back:
+//   * per-LAUNCH tables (HexTab): block b finds its header, node list (padded to MAXN entries, -1 = none) and element
+//     slots at fixed strides of b - no chunk-id list, no header -> offsets dependency: the node ids, the element data
+//     and the header are three independent loads issued together, the x gather is the only dependent round trip
+//     (k_ebe_chunk: chunk id -> header -> node ids -> x);
+//   * element slot of thread t, copy j: ((t >> 6) * EPT + j) * 64 + (t & 63): a wave owns EPT consecutive 64-slot runs,
+//     so slot order = (wave, j) order, and the LDS accumulation runs wave after wave (each wave its sub-colours in
+//     ascending order, LDS operations of one wave are ordered) with ONE block barrier per wave instead of one per
+//     sub-colour: 4 instead of 8-10 per chunk, same order of additions;
+//   * a sign is an XOR of the sign bit (shift, and, xor) instead of compare + select + two moves.
+// EPT / NPT (tile nodes per thread) / LB (blocks per CU asked of the register allocator) are template parameters so that
+// the occupancy trade-off can be measured (PCG_EBE_HEX, tools/ebe_lab.py).
+// ------------------------------------------------------------------------------------------------
+struct HexTab {
+    const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, any sign bit set
+    const int *nodes;             // [n][MAXN]  node id, -1 = padding
+    const int *dst;               // [n][MAXN]  >= 0: y offset (exclusive node); < 0: -(boundary slot + 1)
+    const unsigned short *tslot;  // [n][MAXN]  bits 0..9 slot in the LDS tile; bits 12..14: dof 0..2 of the node is owned and free
+                                  //            (the weight of the fused p.Ap, patched in by upload_masks: no flag loads in the kernel)
+    const unsigned short *lid;    // [n][8][CE]
+    const double *ck;             // [n][CE]
+    const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
+};
+
+__device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
+{
+    const unsigned long long m = (unsigned long long)((sg >> b) & 1u) << 63;
+    return __longlong_as_double(__double_as_longlong(v) ^ (long long)m);
+}
+
+// ACCM: how a lane adds its 24 outputs into the LDS y tile.  0: read - add - write in two batches of 12 (the signs are
+// applied beforehand, outside the serial part, and the wave whose turn it is runs at raised priority: its few VALU adds
+// must not queue behind the other workgroups' FMA streams while three waves wait at the barrier).  1: ds_add_f64 - the
+// LDS unit adds in place, the serial part of a wave is 24 * EPT LDS instructions and no VALU work at all.  The order of
+// additions per node is the same in both modes (wave after wave, sub-colour after sub-colour): bit-reproducible.
+template <int EPT, int NPT, int LB, bool DOT, int ACCM>
+__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                               double *__restrict__ y, double *__restrict__ buf,
+                                                               const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                               long long dot_lo)
+{
+    constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int4 h = T.hdr[b];
+    // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
+    unsigned sg[EPT];
+    double c[EPT];
+    int l3[EPT][8];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const size_t slot = (size_t)b * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63);
+        sg[j] = ntload(T.sgn + slot);
+        c[j] = ntload(T.ck + slot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            l3[j][k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + (wave * EPT + j) * 64 + (threadIdx.x & 63));
+    }
+    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+        g[j] = ntload(T.nodes + n);
+        dst[j] = ntload(T.dst + n);
+        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
+        sl3[j] = 3 * (ts & 0x3ff);
+        wmask[j] = ts >> 12;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            const double *xp = x + 3 * (size_t)g[j];
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    __syncthreads();
+    const double *K = ke_col + (size_t)h.z * ND * ND;
+    double acc[EPT][ND];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[j][a] = 0.0;
+    // h.w: some element of this chunk has a sign bit set (ElemList_SignVector, :278,:280); chunks without any - every chunk
+    // of a mesh whose patterns are in reference orientation - skip the two sign passes (block-uniform branch)
+    auto contract = [&](auto with_signs) {
+        constexpr bool SIG = decltype(with_signs)::value;
+#pragma unroll
+        for (int bb = 0; bb < ND; ++bb) {
+            double u[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const double xv = xs[l3[j][bb / 3] + bb % 3];                                            // :277 gather
+                u[j] = c[j] * (SIG ? flip_sign(xv, sg[j], bb) : xv);                                     // :278-279 sign, Ck
+            }
+            {
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                    const double k = K[bb * ND + a];                                                     // wave-uniform -> SGPR pair
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) acc[j][a] = fma(k, u[j], acc[j][a]);                   // :279 Ke @ (.)
+                }
+            }
+        }
+        if constexpr (SIG) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[j][a] = flip_sign(acc[j][a], sg[j], a);                 // :280 (every wave at once)
+        }
+    };
+    if (h.w) contract(std::true_type());
+    else contract(std::false_type());
+    // ---- LDS-staged partial sums, wave after wave (slot order = sub-colour order) ----------------------------------
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave == w) {
+            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
+            for (int s = 0; s < h.y; ++s) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j)
+                    if ((int)(sg[j] >> 24) == s) {
+                        if constexpr (ACCM == 1) {
+#pragma unroll
+                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
+                                __hip_atomic_fetch_add(&ys[l3[j][a / 3] + a % 3], acc[j][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+#pragma unroll
+                            for (int q0 = 0; q0 < ND; q0 += 12) {
+                                double old[12];
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[l3[j][a / 3] + a % 3]; }
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[l3[j][a / 3] + a % 3] = old[q] + acc[j][a]; }   // :300
+                            }
+                        }
+                    }
+            }
+            if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
+                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
+                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// hex8 chunks of 512 elements in TWO sequential passes of 256 (k_ebe_hexs).  The geometry of the 512-element chunk (an
+// 8x8x8 cell: 729 tile nodes, 386 of them shared with other chunks = 0.75 boundary slots per element, against 1.0 for
+// the 8x8x4 cells of the 256-element chunks) with the register footprint of one element per thread (96 VGPRs): the two
+// halves of the cell are contracted and accumulated one after the other into the SAME LDS y tile, so the plane between
+// them never leaves the workgroup and the tile is staged / written out once.  Why bytes matter here: at 10 M dof an apply
+// moves ~0.65 GB with 256-element chunks (0.49 GB with 512), of which a third is the boundary-slot round trip; the
+// element kernel + shared-node sums run within 1.4x of what that traffic costs at the stream rate.
+// Slot of thread t in pass p: p * 256 + t, i.e. slot order = (pass, wave) order = sub-colour order: same sums as k_ebe_hex.
+// ------------------------------------------------------------------------------------------------
+template <int LB, bool DOT, int ACCM>
+__global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const double *__restrict__ ke_col, const double *__restrict__ x,
+                                                                double *__restrict__ y, double *__restrict__ buf,
+                                                                const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                                long long dot_lo)
+{
+    constexpr int SEQ = 2, NPT = 3, CE = kChunkThreads * SEQ, MAXN = kChunkThreads * NPT, ND = 24;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int4 h = T.hdr[b];
+    unsigned sg;
+    double c;
+    int l3[8];
+    auto load_elem = [&](int ps) {
+        const size_t slot = (size_t)b * CE + ps * kChunkThreads + threadIdx.x;
+        sg = ntload(T.sgn + slot);
+        c = ntload(T.ck + slot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + ps * kChunkThreads + threadIdx.x);
+    };
+    load_elem(0);
+    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+        g[j] = ntload(T.nodes + n);
+        dst[j] = ntload(T.dst + n);
+        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
+        sl3[j] = 3 * (ts & 0x3ff);
+        wmask[j] = ts >> 12;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            const double *xp = x + 3 * (size_t)g[j];
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    __syncthreads();
+    const double *K = ke_col + (size_t)h.z * ND * ND;
+#pragma unroll
+    for (int ps = 0; ps < SEQ; ++ps) {
+        double acc[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[a] = 0.0;
+        auto contract = [&](auto with_signs) {
+            constexpr bool SIG = decltype(with_signs)::value;
+#pragma unroll
+            for (int bb = 0; bb < ND; ++bb) {
+                const double xv = xs[l3[bb / 3] + bb % 3];                                               // :277 gather
+                const double u = c * (SIG ? flip_sign(xv, sg, bb) : xv);                                 // :278-279 sign, Ck
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = fma(K[bb * ND + a], u, acc[a]);                    // :279 Ke @ (.)
+            }
+            if constexpr (SIG) {
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = flip_sign(acc[a], sg, a);                          // :280
+            }
+        };
+        if (h.w) contract(std::true_type());
+        else contract(std::false_type());
+        const unsigned my_colour = sg >> 24;
+        const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
+        if (ps + 1 < SEQ) load_elem(ps + 1);                 // the other half's slots arrive under this accumulation
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (wave == w) {
+                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
+                for (int s = 0; s < h.y; ++s)
+                    if ((int)my_colour == s) {
+                        if constexpr (ACCM == 1) {
+#pragma unroll
+                            for (int a = 0; a < ND; ++a)                                                 // :300, added by the LDS unit
+                                __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+#pragma unroll
+                            for (int q0 = 0; q0 < ND; q0 += 12) {
+                                double old[12];
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; old[q] = ys[a0[a / 3] + a % 3]; }
+#pragma unroll
+                                for (int q = 0; q < 12; ++q) { const int a = q0 + q; ys[a0[a / 3] + a % 3] = old[q] + acc[a]; }
+                            }
+                        }
+                    }
+                if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
+                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
+                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Pattern types other than the full hex8 class (hanging-node octree patterns with up to 32 nodes, and patterns with fewer
+// than 8): k_ebe_rows.  A chunk is 64 elements - ONE per lane - and the four waves of the workgroup each contract a
+// quarter of the output rows (whole local nodes: NDP/4 = 6 / 12 / 18 / 24 rows) of the same 64 elements:
+//   * a lane carries NDP/4 accumulators instead of NDP (12 instead of 48 for the 13-node transition cells): 5-8 waves
+//     per SIMD instead of 2, and a workgroup's critical path is a quarter of the element's contraction;
+//   * four times as many workgroups for the same elements.  On the two-level octree mesh of bench.py (4 608 transition
+//     cells among 1.1 M hex8 cells) the round-1 kernel ran 18 workgroups for 47.6 us - more than the 33 us the 1.1 M
+//     hex8 cells took - because each of them streamed a 48 x 48 Ke through one wave per SIMD with nothing to hide the
+//     scalar-load waits behind;
+//   * Ke is laid out per wave (ke_rows: wave, column, row-in-wave), so a wave's slice of a column is one contiguous
+//     scalar load; the wave index is read with readfirstlane so the loads stay scalar.
+// Gather, signs, Ck, LDS accumulation (wave after wave, sub-colour after sub-colour, ds_add_f64) and the exclusive /
+// shared write-out are those of k_ebe_hex; every wave gathers all NDP inputs (the tile is in LDS, the redundancy is 4 LDS
+// reads instead of 1 per input).
+// ------------------------------------------------------------------------------------------------
+template <int NNP, bool DOT>
+__global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
+    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
+    const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
+    const double *__restrict__ ke_rows, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ buf,
+    const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo)
+{
+    constexpr int NPT = kChunkMaxNodes / kChunkThreads;      // tile nodes per thread (3)
+    constexpr int CE = 64, NDP = 3 * NNP, RPW = NDP / 4, NPW = NNP / 4, W = NDP / 32 + 1;
+    static_assert(RPW % 3 == 0, "a wave owns whole local nodes");
+    __shared__ double xs[3 * kChunkMaxNodes];
+    __shared__ double ys[3 * kChunkMaxNodes];
+    const int chunk = chunk_list[blockIdx.x];
+    const int4 h = hdr[2 * chunk];                           // node_off, n_nodes, n_sub, ke index in class
+    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, -
+    const int kci = h2.x, nd = h2.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // element `lane` of the chunk (every wave loads it: same cache lines)
+    unsigned sg[W];
+    int l3[NNP], lown[NPW];
+#pragma unroll
+    for (int w = 0; w < W; ++w) sg[w] = ntload(sgn + ((size_t)kci * W + w) * CE + lane);
+    const double c = ntload(ck + (size_t)kci * CE + lane);
+#pragma unroll
+    for (int k = 0; k < NNP; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + k) * CE + lane);
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) lown[k] = 3 * (int)__builtin_nontemporal_load(lid + ((size_t)kci * NNP + wave * NPW + k) * CE + lane);
+    int dst[NPT], sl3[NPT];
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        int g = -1;
+        dst[j] = 0;
+        sl3[j] = 0;
+        if (n < h.y) {
+            g = ntload(nodes + h.x + n); dst[j] = ntload(dstl + h.x + n);
+            sl3[j] = 3 * (int)__builtin_nontemporal_load(tslot + h.x + n);
+        }
+        if (g >= 0) {
+            const double *xp = x + 3 * (size_t)g;
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    }
+    __syncthreads();
+    const double *K = ke_rows + ((size_t)h.w * 4 + wave) * NDP * RPW;       // this wave's rows: [column b][row a]
+    double acc[RPW];
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) acc[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NDP; ++b) {
+        if (b < nd) {                                        // nd is block-uniform: scalar compare, loops stay unrolled
+            const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);                   // :277-279
+#pragma unroll
+            for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                       // :279 Ke @ (.)
+        }
+    }
+    const int row0 = wave * RPW;                             // global row of acc[0]
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) {                          // :280 (dynamic bit position: the wave index is not a constant)
+        const int r = row0 + a;
+        acc[a] = flip_sign(acc[a], sg[W == 1 ? 0 : (r >> 5)], r & 31);
+    }
+    const int my_colour = (int)(sg[W - 1] >> 24);
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave == w)
+            for (int s = 0; s < h.z; ++s)
+                if (my_colour == s) {
+#pragma unroll
+                    for (int a = 0; a < RPW; ++a)
+                        if (row0 + a < nd)                   // padded rows alias local node 0: never add them
+                            __hip_atomic_fetch_add(&ys[lown[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int n = threadIdx.x + j * kChunkThreads;
+        if (n < h.y) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {    // fused p.Ap.w (:487) on the dofs this chunk finalises
+                const uint8_t *fp = flags + dst[j];
+                if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
+                if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
+                if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
+                                                       int slot0, const double *__restrict__ buf,
+                                                       double *__restrict__ y, int count, const double *__restrict__ x,
+                                                       const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                       long long dot_lo)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int k = t / 3, d = t - 3 * k;
+    double dot = 0.0;
+    if (k < count) {
+        const int q0 = sh_ptr[k], cnt = sh_ptr[k + 1] - q0;
+        const double *b = buf + 3 * (size_t)(slot0 + q0) + d;
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = q < cnt ? ntload(b + 3 * q) : 0.0;
+        double s = v[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            if (q < cnt) s += v[q];
+        for (int q = 8; q < cnt; ++q) s += ntload(b + 3 * q);      // more than 8 chunks at one node: irregular meshes only
+        const size_t dof = 3 * (size_t)sh_node[k] + d;
+        y[dof] = s;
+        if (DOT && (long long)dof >= dot_lo && (flags[dof] & 3) == 3) dot += x[dof] * s;
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// any nd (hanging-node patterns): same algorithm, x re-gathered per block of 4 output rows
+__global__ __launch_bounds__(kBlock) void k_ebe_generic(const int *__restrict__ dof, const uint8_t *__restrict__ sgn,
+                                                        const double *__restrict__ ck, const double *__restrict__ ke,
+                                                        const double *__restrict__ x, double *__restrict__ y, int nd,
+                                                        int64_t ne, int64_t e_lo, int64_t e_hi)
+{
+    const int64_t e = e_lo + blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (e >= e_hi) return;
+    const double c = ck[e];
+    for (int a0 = 0; a0 < nd; a0 += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < nd; ++b) {
+            double v = x[dof[(size_t)b * ne + e]];
+            if (sgn[(size_t)b * ne + e]) v = -v;
+            v = c * v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (a0 + i < nd) acc[i] = fma(ke[(size_t)(a0 + i) * nd + b], v, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (a0 + i < nd) {
+                double o = acc[i];
+                if (sgn[(size_t)(a0 + i) * ne + e]) o = -o;
+                y[dof[(size_t)(a0 + i) * ne + e]] += o;
+            }
+    }
+}
+
+}  // namespace pcg

@@ -1,0 +1,240 @@
+// SpMV kernels of the assembled operator (reference: calcMatVecProd, src/solver/pcg_solver.py:265-300, + the fused
+// p.Ap.w of :487): k_spmv (SELL over 3x3 blocks), k_spmv_dict (value dictionary), k_spmv_scalar (literal CSR volume).
+#pragma once
+#include "hip_common.hpp"
+
+namespace pcg {
+
+// ------------------------------------------------------------------------------------------------
+// SpMV over the SELL-C 3x3-block matrix.  One wave per slice at a time; RPL rows per lane
+// (RPL=1: C=64, 8-B lane loads; RPL=2: C=128, 16-B lane loads).
+// ------------------------------------------------------------------------------------------------
+// COL16: the block columns of a slice are stored as 16-bit offsets from the slice's smallest column (colbase[s]) -
+// 74 instead of 76 bytes per stored block; chosen at upload when every slice spans fewer than 65536 block columns
+// (node numberings with a bandwidth below 32 k nodes, e.g. the 10 M-dof brick: 22 651).  Same columns, same order,
+// same arithmetic: results are bit-identical to the 32-bit form.
+template <int RPL, bool DOT, bool COL16>
+__global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
+                                                 const int *__restrict__ colbase,
+                                                 const double *__restrict__ vals, const double *__restrict__ x,
+                                                 double *__restrict__ y, const uint8_t *__restrict__ flags,
+                                                 double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
+                                                 int64_t n_nodes, int xcd_aware)
+{
+    constexpr int C = 64 * RPL;
+    using DV = typename VecT<RPL>::d;
+    using IV = typename VecT<RPL>::i;
+    using CV = typename std::conditional<COL16, typename std::conditional<RPL == 1, unsigned short, ushort2>::type, IV>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // Slice -> wave mapping.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
+    // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
+    // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
+    const int64_t S = slice_hi - slice_lo;
+    const bool xa = (xcd_aware & 1) != 0;                    // bit 1 of the argument: non-temporal y stores
+    const int xcd = xa ? (blockIdx.x & 7) : 0;
+    const int64_t lb = xa ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t blocks_per_xcd = xa ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
+    const int64_t c_lo = xa ? slice_lo + (S * xcd) / 8 : slice_lo;
+    const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
+    const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
+    double dot = 0.0;
+    for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const DV *vp = reinterpret_cast<const DV *>(vals + (size_t)base * 9 * C) + lane;
+        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
+        int cb = 0;
+        if constexpr (COL16) cb = colbase[s];
+        double acc[RPL][3];
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.0;
+#pragma unroll 3
+        for (int k = 0; k < w; ++k) {
+            IV jv = ntload(cp + (size_t)k * 64);
+            if constexpr (COL16) {
+                if constexpr (RPL == 1) jv += cb; else { jv.x += cb; jv.y += cb; }
+            }
+            DV v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
+            if constexpr (RPL == 1) {
+                const double *xp = x + 3 * (size_t)jv;
+                const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    acc[0][a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[0][a])));
+            } else {
+                const double *xa = x + 3 * (size_t)jv.x, *xb = x + 3 * (size_t)jv.y;
+                const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
+                const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    acc[0][a] = fma(v[3 * a + 2].x, a2, fma(v[3 * a + 1].x, a1, fma(v[3 * a].x, a0, acc[0][a])));
+                    acc[1][a] = fma(v[3 * a + 2].y, b2, fma(v[3 * a + 1].y, b1, fma(v[3 * a].y, b0, acc[1][a])));
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+            const int64_t row = s * C + (int64_t)lane * RPL + h;
+            if (row < n_nodes) {
+                double *yp = y + 3 * row;
+                if (xcd_aware & 2) {
+                    __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
+                    __builtin_nontemporal_store(acc[h][2], yp + 2);
+                } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
+                if constexpr (DOT) {
+                    const uint8_t *fp = flags + 3 * row;
+                    const double *xp = x + 3 * row;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if ((fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
+                }
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// Dictionary variant (SellHost::bidx / dict, sell.cpp compress_blocks; PCG_FORMAT_DICTIONARY): a stored block is a column and a
+// 16-bit index into the table of the matrix's DISTINCT 3x3 blocks, 4-6 bytes instead of 74-76.  The same lanes multiply the
+// same values in the same order as k_spmv: results are bit-identical, only where the values come from differs.  LDSD: the
+// table (72 B per entry) is copied into LDS once per workgroup - the workgroups are persistent, each wave walks many
+// slices - and the lanes of a wave read their blocks from there (same index = one broadcast read; the kernel is bound by the
+// LDS read rate and the x gathers, not by HBM: 0.5 GB instead of 6.9 GB per launch at 10 M dof).  !LDSD: tables beyond the LDS
+// budget are read through L1/L2.
+// MIXED (with LDSD): the table is larger than LDS; its n_lds most frequent entries (the host orders the table by descending
+// frequency) are the LDS copy, a lane whose block is one of the others reads it through L1/L2 - a divergent branch that
+// costs nothing when no lane of the wave needs it.
+template <bool DOT, bool COL16, bool LDSD, int BLK, bool MIXED = false>
+__global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
+                                                      const int *__restrict__ colbase, const unsigned short *__restrict__ bidx,
+                                                      const double *__restrict__ dict, int n_lds,
+                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                      int64_t slice_lo, int64_t slice_hi, int64_t n_nodes)
+{
+    // LDS copy of the table: entries padded to 80 B (16-B aligned) so that a block is four ds_read_b128 + one ds_read_b64 -
+    // 256 B/clk per CU; the 72-B layout compiles to ds_read2_b64 pairs, which run at half that rate (MI355X_MICROARCH.md, LDS)
+    extern __shared__ __align__(16) double sdict[];
+    using CV = typename std::conditional<COL16, unsigned short, int>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int WPB = BLK / 64;                              // waves per workgroup: they share one copy of the table
+    if constexpr (LDSD) {
+        for (int i = threadIdx.x; i < 9 * n_lds; i += BLK) sdict[10 * (i / 9) + i % 9] = dict[i];
+        __syncthreads();
+    }
+    const int64_t wstride = (int64_t)gridDim.x * WPB;
+    double dot = 0.0;
+    for (int64_t s = slice_lo + (int64_t)blockIdx.x * WPB + wid; s < slice_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
+        const unsigned short *ip = bidx + (size_t)base * 64 + lane;
+        int cb = 0;
+        if constexpr (COL16) cb = colbase[s];
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 3
+        for (int k = 0; k < w; ++k) {
+            int j = ntload(cp + (size_t)k * 64);
+            if constexpr (COL16) j += cb;
+            const int id = ntload(ip + (size_t)k * 64);
+            double v[9];
+            if (LDSD && (!MIXED || id < n_lds)) {
+                const double2 *e2 = reinterpret_cast<const double2 *>(sdict + 10 * id);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const double2 t = e2[c]; v[2 * c] = t.x; v[2 * c + 1] = t.y; }
+                v[8] = sdict[10 * id + 8];
+            } else {
+                const double *b = dict + 9 * (size_t)id;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = b[c];
+            }
+            const double *xp = x + 3 * (size_t)j;
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+        }
+        const int64_t row = s * 64 + lane;
+        if (row < n_nodes) {
+            double *yp = y + 3 * row;
+            yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+            if constexpr (DOT) {
+                const uint8_t *fp = flags + 3 * row;
+                const double *xr = x + 3 * row;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
+            }
+        }
+    }
+    if constexpr (DOT) {                                       // fixed order: lanes (shuffle tree), then the waves in turn
+        __shared__ double lds[WPB];
+        const double ws = wave_sum(dot);
+        if (lane == 0) lds[wid] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = lds[0];
+#pragma unroll
+            for (int q = 1; q < WPB; ++q) t += lds[q];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
+// Scalar-row variant (SellHost::bs == 1): one lane per matrix ROW, one f64 value + one i32 column per stored
+// entry - the literal CSR data volume (12 B per non-zero), in the same slice layout, so a wave's loads of a
+// slice column are one 512 B + one 256 B coalesced line.  Used by pcg_create_csr(block = 1): systems whose
+// rows are not 3-dof node blocks, and the "CSR-format" point of the measurement table.
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_scalar(const int64_t *__restrict__ slice_ptr, const int *__restrict__ cols,
+                                                        const double *__restrict__ vals, const double *__restrict__ x,
+                                                        double *__restrict__ y, const uint8_t *__restrict__ flags,
+                                                        double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
+                                                        int64_t n_rows)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
+    double dot = 0.0;
+    for (int64_t s = slice_lo + (int64_t)blockIdx.x * kWavesPerBlock + wid; s < slice_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const double *vp = vals + (size_t)base * 64 + lane;
+        const int *cp = cols + (size_t)base * 64 + lane;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        int k = 0;
+        for (; k + 9 <= w; k += 9) {                            // 9 independent gathers in flight per lane
+            int j[9];
+            double v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { j[c] = ntload(cp + (size_t)(k + c) * 64); v[c] = ntload(vp + (size_t)(k + c) * 64); }
+#pragma unroll
+            for (int c = 0; c < 9; c += 3) {
+                a0 = fma(v[c], x[j[c]], a0);
+                a1 = fma(v[c + 1], x[j[c + 1]], a1);
+                a2 = fma(v[c + 2], x[j[c + 2]], a2);
+            }
+        }
+        for (; k < w; ++k) a0 = fma(ntload(vp + (size_t)k * 64), x[ntload(cp + (size_t)k * 64)], a0);
+        const int64_t row = s * 64 + lane;
+        if (row < n_rows) {
+            const double r = (a0 + a1) + a2;
+            y[row] = r;
+            if constexpr (DOT)
+                if ((flags[row] & 3) == 3) dot += x[row] * r;
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+}  // namespace pcg

@@ -1,0 +1,397 @@
+// Vector-phase, interface and reduction kernels of the PCG iteration (reference: pcg_solver.py:447-516, :307-334).
+#pragma once
+#include "hip_common.hpp"
+
+namespace pcg {
+
+// Sum of count_a values at pa (+ count_b values at pb when pb != null) by the FIRST 256 threads of the workgroup, in one
+// fixed order whatever the workgroup size: thread t < 256 keeps 4 independent partial sums over pa[t], pa[t + 256], ...
+// (loads in flight), the values of pb go into the second one, (s0 + s1) + (s2 + s3), a wave shuffle tree, the four waves in
+// turn.  Every thread of the workgroup gets the total.  No float atomics anywhere: bit-reproducible run to run, and a sum
+// formed by k_reduce equals the sum the fused vector kernel forms for itself from the same partials.
+// SC1: the partials were published inside this launch by other workgroups (agent-scope stores): agent-scope loads.
+template <bool SC1>
+__device__ __forceinline__ double reduce_fixed_256(const double *pa, int count_a, const double *pb, int count_b, double *lds /* 5 */)
+{
+    auto ld = [](const double *q) -> double {
+        if constexpr (SC1) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *q;
+    };
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = tid;
+        for (; b + 3 * 256 < count_a; b += 4 * 256) {
+            s0 += ld(pa + b); s1 += ld(pa + b + 256); s2 += ld(pa + b + 2 * 256); s3 += ld(pa + b + 3 * 256);
+        }
+        for (; b < count_a; b += 256) s0 += ld(pa + b);
+        if (pb)
+            for (int c = tid; c < count_b; c += 256) s1 += ld(pb + c);
+        const double w = wave_sum((s0 + s1) + (s2 + s3));
+        if ((tid & 63) == 0) lds[tid >> 6] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t = lds[0];
+        t += lds[1]; t += lds[2]; t += lds[3];
+        lds[4] = t;
+    }
+    __syncthreads();
+    const double r = lds[4];
+    __syncthreads();                                    // lds may be reused by the caller
+    return r;
+}
+
+// out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x: one block per value.
+// mirror (may be null): host-visible copy of the words written, so the host needs no device->host copy.
+__global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
+                                                   const double *__restrict__ pb, int count_b, double *out, double *mirror)
+{
+    __shared__ double lds[5];
+    const int k = blockIdx.x;
+    const double v = reduce_fixed_256<false>(pa + (size_t)k * stride, count_a, pb, count_b, lds);
+    if (threadIdx.x == 0) {
+        out[k] = v;
+        if (mirror) mirror[k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// interface kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__ y, const int *__restrict__ idx,
+                                                      double *__restrict__ send, int64_t count)
+{
+    for (int64_t m = blockIdx.x * (int64_t)kBlock + threadIdx.x; m < count; m += (int64_t)gridDim.x * kBlock)
+        send[m] = y[idx[m]];
+}
+
+// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
+                                                  const int *__restrict__ fptr, const int *__restrict__ fpos,
+                                                  const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
+                                                  int64_t nb, double *__restrict__ partials)
+{
+    double dot = 0.0;
+    for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
+        double v = y[d];
+        const int q0 = fptr[d], q1 = fptr[d + 1];
+        for (int q = q0; q < q1; ++q) v += recv[fpos[q]];
+        if (q1 > q0) y[d] = v;
+        if constexpr (DOT)
+            if ((flags[d] & 3) == 3) dot += xdot[d] * v;
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector kernels (grid-stride, 16 B per lane, scalar tail)
+// ------------------------------------------------------------------------------------------------
+// beta = rho / rho_prev (:475) with rho = st[RHO_NEXT] read on the device: the host need not know rho yet when it
+// enqueues this kernel (look-ahead), and divides the same two doubles later for its own Flag-4 test (:476-478).
+__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, const double *__restrict__ pi,
+                                                     const double *__restrict__ r, const double *__restrict__ minv,
+                                                     const double *__restrict__ st, double rho_prev, int first, int nt, int64_t n)
+{
+    const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
+    const int64_t n2 = n >> 1;
+    const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
+    double2 *po2 = reinterpret_cast<double2 *>(po);
+    const double2 *pi2 = reinterpret_cast<const double2 *>(pi);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *m2 = reinterpret_cast<const double2 *>(minv);
+    for (int64_t t = t0; t < n2; t += ts) {
+        const double2 rr = (nt & 4) ? ntload(r2 + t) : r2[t], mm = (nt & 4) ? ntload(m2 + t) : m2[t];
+        double2 z = make_double2(mm.x * rr.x, mm.y * rr.y);        // :447
+        if (!first) { const double2 pp = (nt & 4) ? ntload(pi2 + t) : pi2[t]; z.x = z.x + beta * pp.x; z.y = z.y + beta * pp.y; }   // :479
+        if (nt & 1) ntstore(po2 + t, z); else po2[t] = z;
+    }
+    if ((n & 1) && t0 == 0) {
+        const int64_t i = n - 1;
+        double z = minv[i] * r[i];
+        if (!first) z = z + beta * pi[i];
+        po[i] = z;
+    }
+}
+
+// whole status block -> host-visible ring slot (multi-GPU: the all-reduce rewrote the block in place)
+__global__ void k_publish(const double *__restrict__ st, double *__restrict__ mirror)
+{
+    if (threadIdx.x < ST_COUNT) mirror[threadIdx.x] = st[threadIdx.x];
+}
+
+struct Up { double sqp, sqx, sqr, rho, ninf; };
+
+// -> z = M^-1 r' (:447 of the next iteration)
+__device__ __forceinline__ double update_one(double alpha, double p, double q, double &r, double xo, double &xn, double m,
+                                             uint8_t f, Up &u)
+{
+    const bool w = (f & 3) == 3;
+    if (w) { u.sqp += p * p; u.sqx += xo * xo; }                  // :504-505 (x BEFORE the update)
+    const double rn = r - alpha * q;                               // :501
+    r = rn;
+    xn = xo + alpha * p;                                           // :516
+    const double z = m * rn;                                       // :447 of the next iteration
+    if ((f & 2) && isinf(z)) u.ninf += 1.0;                        // :448
+    if (w) { u.sqr += rn * rn; u.rho += z * rn; }                  // :506, :462
+    return z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_vec: the vector phase of one iteration in ONE launch (pcg_solver.py:487-516 and :447-479 of the next iteration).
+//
+//   [alpha]   pq = p.Ap: pq_src 2 = every workgroup sums the operator's dot partials itself (fixed order, so all get the
+//             same bits; no reduce launch), 1 = st[PQ] (all-reduced, multi-GPU), 0 = alpha given in st[ALPHA] (tests);
+//             alpha = rho / pq and the Flag-4 tests of :492-498 (sticky stop flag: a frozen launch updates nothing)
+//   [update]  sums of p^2 w and x^2 w, r' = r - alpha q, x' = x + alpha p, z = M^-1 r', sums of r'^2 w, z r' w, #inf(z)
+//   FUSED (single part):
+//   [reduce]  the workgroups publish their five partial sums with agent-scope stores and meet at a grid barrier (XCD-sharded
+//             arrival counters, one lane polls); every workgroup then sums the partials of rho' in the same fixed order ->
+//             beta = rho' / rho (:475), workgroup 0 writes the five sums to the status block (and its host mirror)
+//   [p]       p' = z + beta p (:479) with z still in REGISTERS (kVecKreg x 16 B per thread): r' and M^-1 are not read
+//             again; beyond that (more than 2 * kVecKreg * threads dofs) z is recomputed from r', M^-1 - the same product.
+//   !FUSED    the partial sums go to `partials` for k_reduce (then the all-reduce, then k_update_p), multi-GPU loop.
+//
+// One workgroup of 1024 threads per CU: the grid barrier needs every workgroup resident (checked at start-up with the
+// occupancy query; 16 waves per CU at <= 128 VGPRs) and costs ~4 us at 256 workgroups (MI355X_MICROARCH.md barrier-xcd);
+// it replaces two reduce launches, one vector kernel launch and 16 B per dof of re-reads.  Thread t of the grid owns the
+// 16-byte chunks t, t + T, t + 2T, ... in both forms and the reductions share reduce_fixed_256, so the fused and the
+// split form produce identical bits (tests/test_gpu_parity.py::test_fused_vector_phase_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int kVecBlock = 1024;
+constexpr int kVecWaves = kVecBlock / 64;
+constexpr int kVecKreg = 20;              // 10.1 M dof on 256 CUs: 19.3 chunks per thread
+constexpr int kVecSyncWords = 16 * 9;     // 8 shard counters + the top counter, 128 B apart
+
+struct VecArgs {
+    double *st, *mirror;
+    const double *p, *q, *r;
+    double *rn;
+    const double *xo;
+    double *xn;
+    const double *minv;
+    const uint8_t *flags;
+    double *p_next;                       // FUSED
+    double *partials;                     // 5 x kMaxPartials
+    const double *pa, *pb;                // pq_src 2: the operator's dot partials (interior launches; boundary fix-up)
+    int count_a, count_b;
+    unsigned long long *sync;             // FUSED: monotonic arrival counters
+    unsigned long long seq;               // FUSED: number of this launch (1, 2, ...): targets = arrivals per launch x seq
+    int pq_src, nt;
+    int64_t n;
+};
+
+template <int NV, int NW>
+__device__ __forceinline__ void block_sum_w(double (&v)[NV], double *lds /* NV * NW */)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) lds[k * NW + wid] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = lds[k * NW];
+            for (int w = 1; w < NW; ++w) s += lds[k * NW + w];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
+{
+    __shared__ double lds[5 * kVecWaves + 8];
+    const int tid = threadIdx.x;
+    double stop = a.st[ST_STOP], alpha = a.st[ST_ALPHA];
+    const double rho = a.st[ST_RHO_NEXT];
+    if (a.pq_src) {                                                // :487-498
+        const double pq = a.pq_src == 2 ? reduce_fixed_256<false>(a.pa, a.count_a, a.pb, a.count_b, lds) : a.st[ST_PQ];
+        if (pq <= 0.0 || isinf(pq)) stop = 1.0;                    // the sticky stop flag only ever goes 0 -> 1
+        else { alpha = rho / pq; if (isinf(alpha)) stop = 1.0; }
+        if (blockIdx.x == 0 && tid == 0) {
+            a.st[ST_RHO] = rho; a.st[ST_PQ] = pq; a.st[ST_ALPHA] = alpha; a.st[ST_STOP] = stop;
+            if (a.mirror) { a.mirror[ST_RHO] = rho; a.mirror[ST_PQ] = pq; a.mirror[ST_ALPHA] = alpha; a.mirror[ST_STOP] = stop; }
+        }
+    }
+    const bool ntl = (a.nt & 4) != 0, nts = (a.nt & 1) != 0;
+    const int64_t n2 = a.n >> 1, T = (int64_t)gridDim.x * kVecBlock, t0 = (int64_t)blockIdx.x * kVecBlock + tid;
+    const double2 *p2 = reinterpret_cast<const double2 *>(a.p), *q2 = reinterpret_cast<const double2 *>(a.q);
+    const double2 *x2 = reinterpret_cast<const double2 *>(a.xo), *m2 = reinterpret_cast<const double2 *>(a.minv);
+    const double2 *r2 = reinterpret_cast<const double2 *>(a.r);
+    double2 *rn2 = reinterpret_cast<double2 *>(a.rn), *xn2 = reinterpret_cast<double2 *>(a.xn);
+    const uchar2 *f2 = reinterpret_cast<const uchar2 *>(a.flags);
+    Up u = {0, 0, 0, 0, 0};
+    double2 z[FUSED ? kVecKreg : 1];
+    double z_tail = 0.0;
+    auto chunk = [&](int64_t t) -> double2 {
+        const double2 pp = ntl ? ntload(p2 + t) : p2[t], qq = ntl ? ntload(q2 + t) : q2[t], xx = ntl ? ntload(x2 + t) : x2[t],
+                      mm = ntl ? ntload(m2 + t) : m2[t];
+        double2 rr = ntl ? ntload(r2 + t) : r2[t], xo2, zz;
+        const uchar2 ff = f2[t];
+        zz.x = update_one(alpha, pp.x, qq.x, rr.x, xx.x, xo2.x, mm.x, ff.x, u);
+        zz.y = update_one(alpha, pp.y, qq.y, rr.y, xx.y, xo2.y, mm.y, ff.y, u);
+        if (nts) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
+        else { rn2[t] = rr; xn2[t] = xo2; }
+        return zz;
+    };
+    if (stop == 0.0) {                                             // frozen when pq / alpha broke down (:492-498)
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int k = 0; k < kVecKreg; ++k) {
+                const int64_t t = t0 + k * T;
+                if (t < n2) z[k] = chunk(t);
+            }
+            for (int64_t t = t0 + kVecKreg * T; t < n2; t += T) (void)chunk(t);
+        } else {
+            for (int64_t t = t0; t < n2; t += T) (void)chunk(t);
+        }
+        if ((a.n & 1) && t0 == 0) {
+            const int64_t i = a.n - 1;
+            double rr = a.r[i], xnew;
+            z_tail = update_one(alpha, a.p[i], a.q[i], rr, a.xo[i], xnew, a.minv[i], a.flags[i], u);
+            a.rn[i] = rr;
+            a.xn[i] = xnew;
+        }
+    }
+    double v[5] = {u.sqp, u.sqx, u.sqr, u.rho, u.ninf};
+    block_sum_w<5, kVecWaves>(v, lds);                             // valid in thread 0
+    if constexpr (!FUSED) {
+        if (tid == 0)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a.partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+    } else {
+        // ---- grid barrier.  Arrivals are counted even by a frozen launch: the counters are monotonic over the launches
+        // of an engine (target = arrivals per launch x launch number), nothing is reset between launches.
+        const int G = gridDim.x, ns = G < 8 ? G : 8, shard = blockIdx.x % ns;
+        if (tid == 0) {
+            if (stop == 0.0)
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    __hip_atomic_store(a.partials + (size_t)k * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partials are out before the arrival is counted
+            const unsigned long long members = (unsigned long long)((G - shard + ns - 1) / ns);
+            const unsigned long long old = __hip_atomic_fetch_add(a.sync + 16 * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == members * a.seq) __hip_atomic_fetch_add(a.sync + 16 * 8, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double ok = 1.0;
+            if (stop == 0.0) {
+                const unsigned long long target = (unsigned long long)ns * a.seq;
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.sync + 16 * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { ok = 0.0; break; }  // seconds: a workgroup of the grid is not resident
+                }
+            }
+            lds[5 * kVecWaves] = ok;
+        }
+        __syncthreads();
+        const bool ok = lds[5 * kVecWaves] != 0.0;
+        __syncthreads();
+        if (stop != 0.0 || !ok) {                                  // uniform over the grid (frozen) or reported (time-out)
+            if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { a.st[ST_SQP + k] = 0.0; if (a.mirror) a.mirror[ST_SQP + k] = 0.0; }
+                if (!ok) { a.st[ST_ERR] = 1.0; if (a.mirror) a.mirror[ST_ERR] = 1.0; }
+            }
+            return;
+        }
+        // ---- every workgroup: rho' from the G partials, same order everywhere -> same beta everywhere (:462, :475)
+        const double rho_next = reduce_fixed_256<true>(a.partials + (size_t)3 * kMaxPartials, G, nullptr, 0, lds);
+        if (blockIdx.x == 0) {
+            double s[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                s[k] = k == 3 ? rho_next : reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, G, nullptr, 0, lds);
+            if (tid == 0)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { a.st[ST_SQP + k] = s[k]; if (a.mirror) a.mirror[ST_SQP + k] = s[k]; }
+        }
+        const double beta = rho_next / rho;
+        const double2 *pc2 = reinterpret_cast<const double2 *>(a.p);
+        double2 *pn2 = reinterpret_cast<double2 *>(a.p_next);
+#pragma unroll
+        for (int k = 0; k < kVecKreg; ++k) {
+            const int64_t t = t0 + k * T;
+            if (t < n2) {
+                const double2 pp = pc2[t];
+                const double2 o = make_double2(z[k].x + beta * pp.x, z[k].y + beta * pp.y);      // :479
+                if (nts) ntstore(pn2 + t, o); else pn2[t] = o;
+            }
+        }
+        for (int64_t t = t0 + kVecKreg * T; t < n2; t += T) {      // beyond the register-resident part: z again from r', M^-1
+            const double2 rr = rn2[t], mm = m2[t], pp = pc2[t];
+            const double2 o = make_double2(mm.x * rr.x + beta * pp.x, mm.y * rr.y + beta * pp.y);
+            if (nts) ntstore(pn2 + t, o); else pn2[t] = o;
+        }
+        if ((a.n & 1) && t0 == 0) a.p_next[a.n - 1] = z_tail + beta * a.p[a.n - 1];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_residual(const double *__restrict__ b, const double *__restrict__ ax,
+                                                     double *__restrict__ r, const double *__restrict__ minv,
+                                                     const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
+{
+    __shared__ double lds[3 * kWavesPerBlock];
+    double sqr = 0, rho = 0, ninf = 0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double rn = b[i] - ax[i];                            // :414, :531
+        r[i] = rn;
+        const double z = minv[i] * rn;
+        const uint8_t f = flags[i];
+        if ((f & 2) && isinf(z)) ninf += 1.0;
+        if ((f & 3) == 3) { sqr += rn * rn; rho += z * rn; }       // :415, :462
+    }
+    double v[3] = {sqr, rho, ninf};
+    block_sum<3>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_dot_w(const double *__restrict__ a, const double *__restrict__ b,
+                                                  const uint8_t *__restrict__ flags, double *__restrict__ partials, int64_t n)
+{
+    __shared__ double lds[kWavesPerBlock];
+    double s = 0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if ((flags[i] & 3) == 3) s += a[i] * b[i];
+    double v[1] = {s};
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert_free(double *__restrict__ minv, const double *__restrict__ d,
+                                                        const uint8_t *__restrict__ flags, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        minv[i] = (flags[i] & 2) ? 1.0 / d[i] : 0.0;               // :351-352
+}
+
+__global__ __launch_bounds__(kBlock) void k_axpby(double *__restrict__ o, double a, const double *__restrict__ x, double b,
+                                                  const double *__restrict__ y, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        o[i] = a * x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale(double *__restrict__ o, double a, const double *__restrict__ x, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) o[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_free(double *__restrict__ x, const uint8_t *__restrict__ flags, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (!(flags[i] & 2)) x[i] = 0.0;
+}
+
+}  // namespace pcg

@@ -7,8 +7,10 @@
 //   * vectors keep the part's full local length n; fixed dofs are masked (w=0, M^-1=0) instead of
 //     restricted through LocDofEff (:377-378,:482-484) - the extra terms are exact zeros;
 //   * z = M^-1 r, rho = z.r.w and the inf test of the NEXT iteration (:447-463) are produced by
-//     the same kernel that updates r (or recomputes the true residual), so an iteration is three
-//     vector-length kernels (update_p, SpMV+dot, fused_update) and two all-reduces (pq; 5 values);
+//     the same kernel that updates r (or recomputes the true residual); on a single part that
+//     kernel also reduces its five sums grid-wide and forms the next search direction, so an
+//     iteration is the operator + ONE vector launch (Backend::vec_update with p_next); with a
+//     communicator it is update_p, operator + dot, vec_update and two all-reduces (pq; 5 values);
 //   * the alpha/flag-4 tests on pq (:492-498) run on the device and freeze the update kernel, the
 //     host sees them in the one status read-back per iteration;
 //   * XMin (:555-558) is tracked by rotating three x buffers instead of copying.
@@ -74,10 +76,12 @@ struct pcg_engine {
 
     double *d_send = nullptr, *d_recv = nullptr, *d_st = nullptr;
     double *v_b = nullptr, *v_q = nullptr, *v_minv = nullptr, *v_minv_user = nullptr;
-    // Every vector an iteration UPDATES is written to a different buffer than it is read from (r, p: ping-pong;
-    // x: 4 rotating buffers, one of them protects XMin :555-558), so an iteration enqueued ahead of the host's
-    // decision on its predecessor can simply be dropped: nothing it read was overwritten.
-    double *v_r[2] = {nullptr, nullptr}, *v_p[2] = {nullptr, nullptr};
+    // Every vector an iteration UPDATES is written to a different buffer than it is read from (r: ping-pong; p: a ring
+    // of 3 - iteration i reads p_i, and on a single part its vector launch already writes p_{i+1}, so the look-ahead
+    // iteration i+1 writes p_{i+2} into a THIRD buffer and p_i survives a dropped look-ahead; x: 4 rotating buffers, one
+    // of them protects XMin :555-558), so an iteration enqueued ahead of the host's decision on its predecessor can
+    // simply be dropped: nothing it read was overwritten.
+    double *v_r[2] = {nullptr, nullptr}, *v_p[3] = {nullptr, nullptr, nullptr};
     double *v_x[4] = {nullptr, nullptr, nullptr, nullptr};
     double *scr[4] = {nullptr, nullptr, nullptr, nullptr};
     double h_st[ST_COUNT];
@@ -100,6 +104,8 @@ struct pcg_engine {
         int cur = 0, min_idx = 0;
         bool min_live = true;
         int rcur = 0, pcur = 0;   // buffers holding the current residual / the last search direction
+        bool p_ready = false;     // v_p[(pcur + 1) % 3] already holds the search direction of iteration `i` (formed by the
+                                  // vector launch of iteration i - 1 from the recurrence residual; void once r is replaced)
         bool ahead = false;       // iteration `i` is already enqueued (look-ahead from the previous pass)
         int ahead_nx = -1;        // ... writing its new x into this buffer
         int64_t n_enqueued = 0;   // iterations whose device work was enqueued (those not consumed were look-aheads dropped)
@@ -110,7 +116,7 @@ struct pcg_engine {
     ~pcg_engine()
     {
         if (!be) return;
-        for (double *p : {d_send, d_recv, d_st, v_b, v_r[0], v_r[1], v_p[0], v_p[1], v_q, v_minv, v_minv_user, v_x[0], v_x[1],
+        for (double *p : {d_send, d_recv, d_st, v_b, v_r[0], v_r[1], v_p[0], v_p[1], v_p[2], v_q, v_minv, v_minv_user, v_x[0], v_x[1],
                           v_x[2], v_x[3], scr[0], scr[1], scr[2], scr[3]})
             if (p) be->release(p);
     }
@@ -242,24 +248,30 @@ struct pcg_engine {
         return -1;
     }
 
-    // The device work of one iteration (:447-516 without the host's tests): p, q = A p, alpha, the fused update and
-    // its five sums, published in status slot `slot`.  rho of the iteration is st[RHO_NEXT] on the device.
-    void enqueue_iteration(bool first, double rho_prev, const double *p_in, double *p_out, const double *r_in, double *r_out,
-                           const double *x_in, double *x_out, int slot)
+    // single part, every dof finalised by the operator's own launches: one vector launch per iteration (vec_update with
+    // p_next); read per solve so that a test / a tool can A/B it with PCG_VEC_FUSED
+    bool fused_vec() const { return !multi() && be->vec_fused_available(); }
+
+    // The device work of one iteration (:447-516 without the host's tests): p (unless the previous iteration's vector
+    // launch already formed it), q = A p, alpha, the update and its five sums, published in status slot `slot`.  rho of the
+    // iteration is st[RHO_NEXT] on the device.  p_next != null (fused_vec()): the same launch leaves p of iteration i + 1 there.
+    void enqueue_iteration(bool first, double rho_prev, bool p_ready, const double *p_prev, double *p_cur, double *p_next,
+                           const double *r_in, double *r_out, const double *x_in, double *x_out, int slot)
     {
         s.n_enqueued++;
         be->set_status_slot(slot);
-        be->update_p(p_out, p_in, r_in, s.minv, d_st, rho_prev, first);     // :447, :472-479
-        apply(p_out, v_q, true);                                            // :482-484
-        bool alpha_in_update = false;
-        if (!multi() && !(kind == 1 && !ebe_dot_fused)) {
-            be->reduce_dot_alpha(d_st);                                     // :487-498, one launch (no all-reduce in between)
-        } else {
+        if (!p_ready) be->update_p(p_cur, p_prev, r_in, s.minv, d_st, rho_prev, first);   // :447, :472-479
+        apply(p_cur, v_q, true);                                            // :482-484
+        int pq_src = 2;                                                     // :487-498 inside the vector launch
+        if (multi() || (kind == 1 && !ebe_dot_fused)) {
             reduce_apply_dot(d_st + ST_PQ);                                 // :487
             allreduce(d_st + ST_PQ, 1);                                     // :488
-            alpha_in_update = true;                                         // :492-498 inside the update kernel
+            pq_src = 1;
         }
-        be->fused_update(d_st, p_out, v_q, r_in, r_out, x_in, x_out, s.minv, alpha_in_update);   // :501-516 (+ :447-462 of i+1)
+        if (be->vec_update(d_st, pq_src, p_cur, v_q, r_in, r_out, x_in, x_out, s.minv, p_next)) {   // :501-516 (+ :447-479 of i+1)
+            be->publish_status(false);                                      // the sums are already in the block and its mirror
+            return;
+        }
         be->reduce_update(d_st + ST_SQP);
         allreduce(d_st + ST_SQP, 5);                                        // :507 (+ next rho, inf count)
         be->publish_status(multi());
@@ -272,7 +284,8 @@ void ensure_solver_buffers(pcg_engine *e)
 {
     if (e->v_b) return;
     e->v_b = e->vec(); e->v_q = e->vec();
-    for (int k = 0; k < 2; ++k) { e->v_r[k] = e->vec(); e->v_p[k] = e->vec(); }
+    for (int k = 0; k < 2; ++k) e->v_r[k] = e->vec();
+    for (int k = 0; k < 3; ++k) e->v_p[k] = e->vec();
     for (int k = 0; k < 4; ++k) e->v_x[k] = e->vec();
 }
 
@@ -306,21 +319,26 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     const int slot = (int)(i % kStatusSlots);
     const int nx = in_flight ? flight_nx : e->pick_new_x();
     double *r_in = e->v_r[s.rcur], *r_out = e->v_r[s.rcur ^ 1];
-    double *p_in = e->v_p[s.pcur], *p_out = e->v_p[s.pcur ^ 1];
+    double *p_prev = e->v_p[s.pcur], *p_cur = e->v_p[(s.pcur + 1) % 3], *p_next = e->v_p[(s.pcur + 2) % 3];
+    const bool fused = e->fused_vec();
     if (!in_flight)                                            // else: the look-ahead of the previous pass IS iteration i
-        e->enqueue_iteration(i == 0, rho_1, p_in, p_out, r_in, r_out, e->v_x[s.cur], e->v_x[nx], slot);
+        e->enqueue_iteration(i == 0, rho_1, s.p_ready, p_prev, p_cur, fused ? p_next : nullptr, r_in, r_out, e->v_x[s.cur],
+                             e->v_x[nx], slot);
     s.n_matvec++;
     // ---- look ahead: iteration i+1 from the state iteration i leaves when it ends the ordinary way --------------
     if (may_look_ahead && s.more == 0 && i + 1 < s.max_iter) {
         const int nx2 = e->pick_new_x(nx);                     // not x_i (a frozen iteration i keeps it), not x_{i+1}, not XMin
-        if (nx2 >= 0) {
-            e->enqueue_iteration(false, s.rho, p_out, p_in, r_out, r_in, e->v_x[nx], e->v_x[nx2], (int)((i + 1) % kStatusSlots));
+        if (nx2 >= 0) {                                        // p_{i+2} goes to the buffer of p_{i-1}: p_i survives a drop
+            e->enqueue_iteration(false, s.rho, fused, p_cur, p_next, fused ? p_prev : nullptr, r_out, r_in, e->v_x[nx], e->v_x[nx2],
+                                 (int)((i + 1) % kStatusSlots));
             s.ahead = true;
             s.ahead_nx = nx2;
         }
     }
     e->be->wait_status(slot, e->h_st);
     const double *st = e->h_st;
+    if (st[ST_ERR] != 0) throw std::runtime_error("the fused vector kernel's grid barrier timed out (a workgroup of its grid was "
+                                                  "not resident - another kernel on the device?); PCG_VEC_FUSED=0 selects the split form");
     if (st[ST_STOP] != 0) { s.flag = 4; return true; }         // pq<=0 / inf / alpha inf: nothing was updated
     const double alpha = st[ST_ALPHA];
     const double normp = std::sqrt(st[ST_SQP]), normx = std::sqrt(st[ST_SQX]);
@@ -332,7 +350,8 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     else s.stag = 0;
     s.cur = nx;                                                // :516
     s.rcur ^= 1;
-    s.pcur ^= 1;
+    s.pcur = (s.pcur + 1) % 3;
+    s.p_ready = fused;                                         // the vector launch left p of iteration i + 1 behind
     s.normr_act = normr;                                       // :518
     s.i = i + 1;
     if (normr <= s.tolb || s.stag >= 3 || s.more > 0) {        // :527
@@ -344,6 +363,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
             e->be->zero(e->d_st + ST_STOP, sizeof(double));
             s.ahead = false;
         }
+        s.p_ready = false;                                     // p_{i+1} = M^-1 r + beta p_i has to be formed from the NEW r
         e->true_residual(e->v_x[s.cur]);                       // :528-533 (R is REPLACED, :531)
         s.normr_act = std::sqrt(e->h_st[ST_SQR]);
         s.rho_next = e->h_st[ST_RHO_NEXT];
@@ -1025,7 +1045,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
 int pcg_bench_hbm(pcg_engine *e, int64_t bytes, int32_t mode, int32_t reps, float *ms_each)
 {
     return guarded("pcg_bench_hbm", e, [&]() -> int {
-        if (!e || bytes < 16 || reps < 1 || !ms_each || mode < 0 || mode > 4) return set_error("pcg_bench_hbm: bad argument");
+        if (!e || bytes < 16 || reps < 1 || !ms_each || mode < 0 || mode > 1) return set_error("pcg_bench_hbm: bad argument");
         return e->be->bench_hbm((size_t)bytes, mode, reps, ms_each);
     });
 }
@@ -1105,12 +1125,45 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         e->be->h2d(e->d_st, st, sizeof(st));
-        e->be->fused_update(e->d_st, dp, dq, dr, drn, dxo, dxn, dm);
+        (void)e->be->vec_update(e->d_st, 0, dp, dq, dr, drn, dxo, dxn, dm, nullptr);
         e->be->reduce_update(e->d_st + ST_SQP);
         e->read_status();
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
         e->be->d2h(r, drn, bytes);
         e->be->d2h(x_new, dxn, bytes);
+        return 0;
+    });
+}
+
+// The whole vector phase of one iteration on given vectors (:501-516 and :447-479 of the next iteration): r, x updated, the
+// five sums, p_next = M^-1 r' + (rho' / rho) p.  fused != 0: the single launch of the solve loop (k_vec with its grid-wide
+// reduction; an error when the device does not admit it); fused == 0: the split form (update, reduce, k_update_p).
+int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p, const double *q, double *r, const double *x_old,
+                        double *x_new, const double *inv_diag, double *p_next, double *sums5, int32_t fused)
+{
+    return guarded("pcg_k_vec_iteration", e, [&]() -> int {
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        ensure_solver_buffers(e);
+        if (fused && !e->be->vec_fused_available()) return set_error("pcg_k_vec_iteration: the fused form is not available");
+        double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
+        double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2], *dpn = e->v_x[3];
+        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
+        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
+        double st[ST_COUNT] = {0};
+        st[ST_ALPHA] = alpha;
+        st[ST_RHO_NEXT] = rho;
+        e->be->h2d(e->d_st, st, sizeof(st));
+        e->be->set_status_slot(0);
+        if (!e->be->vec_update(e->d_st, 0, dp, dq, dr, drn, dxo, dxn, dm, fused ? dpn : nullptr)) {
+            e->be->reduce_update(e->d_st + ST_SQP);
+            e->be->update_p(dpn, dp, drn, dm, e->d_st, rho, false);
+        }
+        e->read_status();
+        if (e->h_st[ST_ERR] != 0) return set_error("pcg_k_vec_iteration: the grid barrier timed out");
+        for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
+        e->be->d2h(r, drn, bytes);
+        e->be->d2h(x_new, dxn, bytes);
+        e->be->d2h(p_next, dpn, bytes);
         return 0;
     });
 }

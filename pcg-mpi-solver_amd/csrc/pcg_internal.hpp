@@ -166,7 +166,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups, 
 //
 // All `double*` below are buffers obtained from alloc() ("device" pointers).
 enum { ST_RHO = 0, ST_PQ = 1, ST_ALPHA = 2, ST_STOP = 3, ST_SQP = 4, ST_SQX = 5, ST_SQR = 6,
-       ST_RHO_NEXT = 7, ST_NINF = 8, ST_COUNT = 16 };
+       ST_RHO_NEXT = 7, ST_NINF = 8, ST_ERR = 9 /* the fused vector kernel's grid barrier timed out */, ST_COUNT = 16 };
 constexpr int kStatusSlots = 4;          // status ring of the solve loop's look-ahead (2 would do; 4 keeps slots apart)
 
 struct HaloHost {
@@ -224,11 +224,6 @@ public:
     virtual void begin_dot() = 0;
     // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
     virtual void reduce_dot(double *red) = 0;
-    // rho = st[RHO_NEXT] (left there by the previous update / residual reduction, device side) ;
-    // st[RHO] = rho ; st[ALPHA] = rho / st[PQ] ; st[STOP] per pcg_solver.py:492-498
-    virtual void scalar_alpha(double *st) = 0;
-    // single part (no all-reduce between the two): reduce_dot(st + ST_PQ) and scalar_alpha(st) in one launch
-    virtual void reduce_dot_alpha(double *st) = 0;
     // Status block: `st` is the device block the reduce/scalar kernels write into.  A back end may mirror
     // those writes into host-visible memory so that read_status() is a stream sync instead of a copy;
     // it returns false when it has no mirror (the caller then copies).
@@ -245,12 +240,18 @@ public:
     // two doubles the host divides for its Flag-4 test)                     (:447,:472-479)
     virtual void update_p(double *p_out, const double *p_in, const double *r, const double *minv, const double *st,
                           double rho_prev, bool first) = 0;
-    // if st[STOP]==0: sums of p^2 w, x_old^2 w ; r_new = r_old - alpha q ; sum r^2 w ; x_new = x_old + alpha p ;
-    // z = M^-1 r ; sum z r w ; count of inf in z.  Partials -> reduce_update().   (:501-516,:447-462)
-    // with_alpha: alpha / stop are formed here from st[PQ] (already all-reduced) and st[RHO_NEXT] exactly like
-    // scalar_alpha(), by every block for itself; the separate one-thread launch disappears from the multi-GPU loop.
-    virtual void fused_update(double *st, const double *p, const double *q, const double *r_old, double *r_new,
-                              const double *x_old, double *x_new, const double *minv, bool with_alpha = false) = 0;
+    // The vector phase of an iteration (:487-516, and :447-479 of the next one).
+    //   alpha: pq_src 2 = p.Ap is the fixed-order sum of the dot partials of the operator launches since begin_dot() (single
+    //          part: no reduce launch), 1 = st[PQ] (already all-reduced), 0 = alpha is given in st[ALPHA];
+    //          st[RHO] = rho = st[RHO_NEXT], st[ALPHA] = rho / pq, st[STOP] per :492-498 (sticky; a frozen call updates nothing)
+    //   sums of p^2 w, x_old^2 w ; r_new = r_old - alpha q ; sum r^2 w ; x_new = x_old + alpha p ; z = M^-1 r_new ;
+    //   sum z r w ; count of inf in z
+    //   p_next == null: the partial sums are left for reduce_update().  Returns false.
+    //   p_next != null (single part only, ask vec_fused_available() first): ONE launch also reduces the five sums into
+    //          st[SQP..NINF] and forms the next search direction p_next = z + (rho' / rho) p (:475-479); returns true.
+    virtual bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r_old, double *r_new,
+                            const double *x_old, double *x_new, const double *minv, double *p_next) = 0;
+    virtual bool vec_fused_available() const { return false; }
     virtual void reduce_update(double *red5) = 0;
     // r = b - ax ; sums r^2 w, (M^-1 r) r w, inf count                      (:413-416,:530-533)
     virtual void residual(const double *b, const double *ax, double *r, const double *minv) = 0;

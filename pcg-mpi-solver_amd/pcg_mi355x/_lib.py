@@ -119,6 +119,7 @@ _SIGS = {
     "pcg_matrix_dictionary": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pcg_k_update_p": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32]),
     "pcg_k_fused_update": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P, _P]),
+    "pcg_k_vec_iteration": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32]),
     "pcg_k_residual": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "pcg_k_spmv_local": (C.c_int, [_P, _P, _P, _P]),
 }

@@ -193,7 +193,7 @@ public:
     int64_t n_pq_ = 0;
     const int64_t neg_pq_at_ = std::getenv("PCG_TEST_NEG_PQ_AT") ? std::atoll(std::getenv("PCG_TEST_NEG_PQ_AT")) : -1;
     void reduce_dot(double *red) override { red[0] = (++n_pq_ == neg_pq_at_) ? -1.0 : dot_spmv_ + dot_fix_; }
-    void scalar_alpha(double *st) override
+    void scalar_alpha(double *st)
     {
         const double pq = st[ST_PQ], rho = st[ST_RHO_NEXT];
         st[ST_RHO] = rho;
@@ -201,7 +201,6 @@ public:
         st[ST_ALPHA] = rho / pq;
         if (std::isinf(st[ST_ALPHA])) st[ST_STOP] = 1;
     }
-    void reduce_dot_alpha(double *st) override { reduce_dot(st + ST_PQ); scalar_alpha(st); }
     // status ring: every "kernel" here runs at once, so a look-ahead iteration has ALREADY overwritten the block
     // when the host asks for its predecessor's sums - the most adversarial order a GPU could produce
     void set_status_block(double *st) override { st_ = st; }
@@ -221,12 +220,20 @@ public:
             po[i] = first ? z : z + beta * pi[i];
         }
     }
-    void fused_update(double *st, const double *p, const double *q, const double *r, double *rnew, const double *xo,
-                      double *xn, const double *minv, bool with_alpha) override
+    // PCG_VEC_FUSED=0 keeps the driver on the split form, like the product
+    bool vec_fused_available() const override { const char *e = std::getenv("PCG_VEC_FUSED"); return !(e && std::atoi(e) == 0); }
+    bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rnew, const double *xo,
+                    double *xn, const double *minv, double *p_next) override
     {
-        if (with_alpha) scalar_alpha(st);
+        const double rho = st[ST_RHO_NEXT];
+        if (pq_src == 2) reduce_dot(st + ST_PQ);
+        if (pq_src) scalar_alpha(st);
         for (double &v : up_) v = 0;
-        if (st[ST_STOP] != 0) return;
+        const bool fused = p_next != nullptr;
+        if (st[ST_STOP] != 0) {
+            if (fused) for (int k = 0; k < 5; ++k) st[ST_SQP + k] = 0.0;
+            return fused;
+        }
         const double alpha = st[ST_ALPHA];
         for (int64_t i = 0; i < n_; ++i) {
             const bool w = own_free(i);
@@ -238,6 +245,11 @@ public:
             if (is_free(i) && std::isinf(z)) up_[4] += 1;
             if (w) { up_[2] += rn * rn; up_[3] += z * rn; }
         }
+        if (!fused) return false;
+        for (int k = 0; k < 5; ++k) st[ST_SQP + k] = up_[k];
+        const double beta = up_[3] / rho;                                // :475
+        for (int64_t i = 0; i < n_; ++i) p_next[i] = minv[i] * rnew[i] + beta * p[i];   // :447, :479
+        return true;
     }
     void reduce_update(double *red5) override { for (int k = 0; k < 5; ++k) red5[k] = up_[k]; }
     void residual(const double *b, const double *ax, double *r, const double *minv) override

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run a few stand-alone operator applies (for rocprofv3 PMC passes).  usage: prof_op.py [sell|ebe] [N] [reps]"""
+"""Run a few stand-alone operator applies (for rocprofv3 PMC passes).  usage: prof_op.py [sell|dict|ebe[,...]] [N] [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -24,6 +24,8 @@ if os.environ.get("PROF_OCTREE"):          # two-level octree mesh with hanging-
     print("octree mesh", m.n_dof, "dof", {k: len(v) for k, v in m.cells.items()})
 else:
     P = make_parts(Brick(N))[0]
-op = from_refmeshpart(P, kind=kind, ebe_chunked=os.environ.get("PROF_EBE_CHUNKED", "1") == "1")
-ms = op.bench_spmv(3, reps)
-print(kind, N, op.operator_info(), "median ms", float(np.median(ms)), "min", float(ms.min()))
+for kd in kind.split(","):                  # several operators in one process (one rocprofv3 pass covers them all)
+    op = from_refmeshpart(P, kind=kd, ebe_chunked=os.environ.get("PROF_EBE_CHUNKED", "1") == "1")
+    ms = op.bench_spmv(3, reps)
+    print(kd, N, op.operator_info(), "median ms", float(np.median(ms)), "min", float(ms.min()), flush=True)
+    op.close()
