@@ -75,6 +75,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ranks", type=int, default=0, help="processes of the multi-core CPU baseline (0 = min(cores, 64))")
     ap.add_argument("--no-finish", action="store_true", help="do not run the solve to convergence after the timed window")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the SpMV launch on this box (N = 1; they run "
+                         "by default when rocprofv3 is on PATH and this process is not itself being profiled)")
     ap.add_argument("--pmc-traffic", action="store_true",
                     help="N = 1: measure the HBM traffic of the SpMV launch on THIS box with two extra rocprofv3 --pmc passes of a short "
                          "run of this script (FETCH_SIZE, WRITE_SIZE; +1-2 min) instead of quoting profiles/pmc_traffic.json")
@@ -188,6 +191,60 @@ def scipy_csr_spmv_point(n_side=70):
             "n": int(b.n_dof), "nnz": int(A.nnz), "ms": ms, "GBps_algorithmic": (12.0 * A.nnz + 20.0 * b.n_dof) / (ms * 1e-3) / 1e9}
 
 
+def numpy_reference_point(part, budget_s=12.0):
+    """The reference's OWN arithmetic path on one host core: the NumPy restatement of calcMatVecProd / PCG (pcg_oracle with
+    use_c=False - bit-identical to the unmodified pcg_solver.py on every fixture, oracle/make_golden.py), single-threaded BLAS
+    like the reference sets it (pcg_solver.py:10-15).  Bounded sample; a part above 4 M dof is replaced by the 1 M-dof brick."""
+    import copy
+    import numpy as np
+    import pcg_oracle
+    note = "the bench's own part"
+    if part["NDOF"] > 4_000_000:
+        from pcg_mi355x.brick import Brick, make_parts
+        part = make_parts(Brick(70, seed=0))[0]
+        note = "1 M-dof brick (N = 70) of the same generator: the bench's system is too large for a bounded NumPy sample"
+    P = {k: v for k, v in part.items() if not k.startswith("_pcg_mi355x")}
+    P["GlobData"] = copy.deepcopy(part["GlobData"])
+    P["Un"] = np.zeros(P["NDOF"])
+    t0 = time.perf_counter()
+    pcg_oracle.update_bc([P], use_c=False)
+    t_mv = time.perf_counter() - t0
+    pcg_oracle.update_preconditioner([P])
+    m = int(max(3, min(50, budget_s / max(t_mv * 1.3, 1e-3))))
+    P["GlobData"]["MaxIter"] = m
+    t0 = time.perf_counter()
+    pcg_oracle.pcg([P], use_c=False, record=False)
+    t = time.perf_counter() - t0
+    return {"value": m / t, "unit": "iterations/s", "cores": 1, "kind": "reference arithmetic (NumPy restatement, bit-identical to pcg_solver.py)",
+            "dofs": int(P["NDOF"]), "matvec_ms": t_mv * 1e3, "sample": f"first {m} PCG iterations, 1 process x 1 thread; {note}"}
+
+
+def scalar_csr_point(dev, n_side=100):
+    """SURVEY 8(d)'s literal "CSR SpMV": the assembled operator of a brick as SCALAR CSR (one f64 value + one i32 column per
+    non-zero, pcg_create_csr(block = 1), k_spmv_scalar) - 20 back-to-back launches, GB/s in the formula's own bytes 12 nnz + 20 n,
+    which is what this kernel really moves.  N = 100 (3 M dof, 238 M non-zeros): the scalar CSR arrays of the 10 M-dof system
+    would be 10 GB of host memory for an informational point."""
+    import numpy as np
+    import scipy.sparse as sp
+    from pcg_mi355x.brick import Brick, make_parts
+    from pcg_mi355x.operator import assemble_bsr3, Operator
+    b = Brick(n_side, seed=0)
+    P = make_parts(b)[0]
+    rp, c, v = assemble_bsr3(P["SubDomainData"]["StrucDataList"], b.n_node)
+    A = sp.bsr_matrix((v, c, rp), shape=(b.n_dof, b.n_dof)).tocsr()
+    del rp, c, v
+    op = Operator.from_csr(A.indptr, A.indices, A.data, device=dev, block=1)
+    nnz, n = int(A.nnz), int(b.n_dof)
+    del A
+    ms = op.bench_spmv(5, 20)
+    by, _ = op.operator_cost()
+    op.close()
+    t = float(np.median(ms)) * 1e-3
+    return {"kernel": "k_spmv_scalar (SELL-64 over scalar rows: f64 value + i32 column per stored non-zero)", "n": n, "nnz": nnz,
+            "median_launch_ms": t * 1e3, "launches": 20, "bytes_12nnz_20n": 12.0 * nnz + 20.0 * n, "stored_bytes": by,
+            "GBps_12nnz_20n": (12.0 * nnz + 20.0 * n) / t / 1e9, "frac_of_peak": (12.0 * nnz + 20.0 * n) / t / 1e9 / HBM_PEAK_GBS}
+
+
 def cpu_baseline(part, N, ranks=0, workload="brick"):
     """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core."""
     import mp_baseline
@@ -195,6 +252,10 @@ def cpu_baseline(part, N, ranks=0, workload="brick"):
     single = cpu_baseline_single(part)
     out = {"kind": "port", "unit": "iterations/s", "host_cpu": _cpu_model(), "host_cores_available": avail,
            "single_core": single}
+    try:
+        out["numpy_reference_path"] = numpy_reference_point(part)
+    except Exception as ex:      # noqa: BLE001 - the line must survive
+        log(f"NumPy reference-path point failed: {ex!r}")
     try:
         out["scipy_csr_spmv"] = scipy_csr_spmv_point()
     except Exception as ex:      # noqa: BLE001 - informational only
@@ -231,7 +292,7 @@ def pmc_traffic_live(args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pcg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "20", "--warmup", "3", "--operator", "sell", "--no-cpu-baseline", "--no-finish",
+               "--steps", "20", "--warmup", "3", "--operator", "sell", "--no-cpu-baseline", "--no-finish", "--no-pmc-traffic",
                "--nodes-per-side", str(args.nodes_per_side), "--rows-per-lane", str(args.rows_per_lane)]
         subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
         db = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
@@ -380,6 +441,19 @@ def main():
             f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
         op_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
         n_op = int(r.spmv_count)
+        vec = None
+        if r.vec_count > 0:                           # the vector phase (k_vec): HIP events around its launches in the timed window
+            fused = world == 1 and os.environ.get("PCG_VEC_FUSED", "1") != "0"
+            vb = (73.0 if fused else 57.0) * op.n       # p, q, r, x, M^-1 in + flags + r', x' out (57 B/dof) [+ p in, p' out: 16 B/dof]
+            vms = r.vec_ms_sum / r.vec_count
+            vec = {"kernel": "k_vec<fused>: alpha, r/x update + five sums, grid-wide reduction, beta, p' - ONE launch per iteration" if fused else
+                             "k_vec<split>: alpha, r/x update + partial sums (then k_reduce, the all-reduce and k_update_p)",
+                   "avg_launch_ms": vms, "launches_timed": int(r.vec_count), "bytes_per_launch": vb,
+                   "bytes_definition": ("73 B/dof: p, q, r, x, M^-1 read + 1 flag byte + r', x' written (57), then p read and p' written (16); "
+                                        "z = M^-1 r' stays in registers across the grid barrier" if fused else
+                                        "57 B/dof: p, q, r, x, M^-1 read + 1 flag byte + r', x' written"),
+                   "bound": "hbm", "achieved": vb / (vms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         op.set_profiling(False)
         elapsed, per_rank = gather_max(elapsed_local)
         comm_info = None
@@ -414,7 +488,7 @@ def main():
             ms = op.bench_spmv(10, 100)
             standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
         return {"op": op, "elapsed": elapsed, "per_rank_s": per_rank, "op_ms": op_ms, "n_op": n_op, "final": final,
-                "standalone": standalone, "t_setup": t_setup, "comm": comm_info}
+                "standalone": standalone, "t_setup": t_setup, "comm": comm_info, "vec": vec}
 
     box = box_identity(dev) if rank == 0 else None
     stream = None
@@ -428,9 +502,7 @@ def main():
         sell_bytes, sell_flops = op.operator_cost()
         if rank == 0:                                # what THIS box's HBM delivers to a plain stream kernel on the engine's stream
             stream = {"read_GBps": op.bench_hbm(8 << 30, "read", 10), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
-                      "slice_read_GBps": op.bench_hbm(6 << 30, 2, 10),
-                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy); slice_read = one wave per contiguous 126 KB region in 4608-B steps, 8 B per lane - the shape in which "
-                              "k_spmv streams a slice's values, without columns, gathers or arithmetic: the ceiling of that access pattern on this box"}
+                      "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy)"}
         if rank == 0:
             if brick.nnz is None:
                 brick.nnz = op.nnz if world == 1 else None
@@ -453,7 +525,7 @@ def main():
                           "distinct_blocks": nu, "table": d["op"].matrix_dictionary_info(),
                           "value": args.steps / d["elapsed"], "unit": "iterations/s",
                           "ms_per_step": d["elapsed"] / args.steps * 1e3, "operator_avg_ms": d["op_ms"], "operator_launches_timed": d["n_op"],
-                          "standalone_spmv": d["standalone"], "solve": d["final"], "comm": d["comm"],
+                          "standalone_spmv": d["standalone"], "solve": d["final"], "comm": d["comm"], "vector_phase": d["vec"],
                           "roofline": {"kernel": "k_spmv_dict (SELL-64, 16-bit block index + column per stored block, table in LDS)",
                                        "avg_launch_ms": d["op_ms"], "bytes_per_launch": db, "achieved_GBps": db / t_op / 1e9,
                                        "peak_GBps": HBM_PEAK_GBS, "frac_hbm": db / t_op / 1e9 / HBM_PEAK_GBS,
@@ -485,7 +557,7 @@ def main():
         matrix_free = {"note": "SURVEY 8(f)-1: the reference's element-by-element operator kept matrix-free; same PCG driver, same inputs",
                        "value": args.steps / e["elapsed"], "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3,
                        "operator_avg_ms": e["op_ms"], "operator_launches_timed": e["n_op"], "n_elem": oi["n_elem"], "n_chunks": oi["n_chunks"],
-                       "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"],
+                       "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"], "vector_phase": e["vec"],
                        "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (hex8 class; k_ebe_rows for the other node-count classes) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
                                     "flops_per_apply": ef, "achieved_TFLOPs": ef / t_op / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                                     "frac_flops": ef / t_op / 1e12 / F64_PEAK_TFLOPS,
@@ -495,8 +567,7 @@ def main():
         if m is None:
             n_loc = e["op"].n
             if rank == 0:
-                stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy"),
-                          "slice_read_GBps": e["op"].bench_hbm(6 << 30, 2, 10)}
+                stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
         e["op"].close()
 
     def shutdown():
@@ -547,11 +618,16 @@ def main():
             "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 passes of their own; the committed passes for this kernel are under "
                             "profiles/ (DESIGN.md section 8) - traffic / bytes_per_launch = 1.03",
             "hbm_stream_this_box": stream, "frac_of_stream_read": achieved / stream["read_GBps"] if stream else None,
-            "frac_of_slice_read": achieved / stream["slice_read_GBps"] if stream else None,
             "csr_equivalent_bytes": alg_bytes, "csr_equivalent_GBps": alg_bytes / t_k / 1e9,
             "csr_equivalent_note": "SURVEY 8(d) formula 12 nnz + 20 n: a scalar-CSR kernel's traffic for the same product; NOT what this "
                                    "kernel moves (it can exceed the HBM peak) - kept for comparison with CSR codes only",
             "standalone_spmv": m["standalone"]}
+        out["roofline_vector_phase"] = m["vec"]
+        if world == 1 and args.workload == "brick" and not args.no_finish:
+            try:
+                out["roofline"]["scalar_csr_same_run"] = scalar_csr_point(dev)
+            except Exception as ex:      # noqa: BLE001 - informational
+                log(f"scalar-CSR point failed: {ex!r}")
         try:        # PMC traffic of an identical launch, collected by separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}" + ("_col16" if col_bytes == 2 else ""))
             if pmc and world == 1:
@@ -560,7 +636,9 @@ def main():
                                                    "(gfx950-corrected), collected on another box in another session - not a measurement of this run")
         except OSError:
             pass
-        if args.pmc_traffic and world == 1:
+        import shutil
+        profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ)       # already under a profiler: no nested passes
+        if world == 1 and not args.no_pmc_traffic and args.workload == "brick" and (args.pmc_traffic or (shutil.which("rocprofv3") and not profiled)):
             try:
                 live = pmc_traffic_live(args)
                 out["roofline"]["traffic"] = live["bytes"]

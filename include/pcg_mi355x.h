@@ -203,6 +203,8 @@ typedef struct {
     int64_t spmv_count;
     int64_t iters_enqueued; /* iterations whose device work was enqueued: iters_done + look-ahead iterations that
                               were dropped because their predecessor ended the loop or replaced r (:527-549)  */
+    double vec_ms_sum;     /* HIP-event time of the vector-phase launches (k_vec) when profiling is on      */
+    int64_t vec_count;
 } pcg_result;
 
 /* inv_diag may be NULL: use the Jacobi vector built by pcg_build_jacobi().

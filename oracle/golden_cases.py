@@ -26,6 +26,9 @@ CASES = {
     "oct_p1":       dict(octree=(8, 8, 4, 3), parts=1, axis=0, sign_seed=3, tol=1e-7, max_iter=10000),
     "oct_p3":       dict(octree=(8, 6, 3, 2), parts=3, axis=0, sign_seed=5, tol=1e-7, max_iter=10000),
     "oct_p2_z":     dict(octree=(6, 6, 4, 2), parts=2, axis=2, sign_seed=None, tol=1e-7, max_iter=10000),   # interface = the transition layer
+    # multi-level 2:1-balanced octree mesh around a sphere (round 3): 3 cell sizes, dozens of pattern types with 9-20 nodes
+    "goct_p1":      dict(graded=((3, 3, 3), 2, 1.2), parts=1, sign_seed=None, tol=1e-7, max_iter=10000),
+    "goct_p4":      dict(graded=((3, 3, 3), 2, 1.2), parts=4, sign_seed=9, tol=1e-7, max_iter=10000),      # recursive bisection
     "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
     "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
 }
@@ -40,6 +43,12 @@ def build_case(name, golden_dir=None):
         from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
         mesh = TwoLevelMesh(*c["octree"], seed=0)
         return mesh, make_octree_parts(mesh, c["parts"], c["axis"], c["tol"], c["max_iter"], c["sign_seed"])
+    if "graded" in c:
+        from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
+        roots, levels, band = c["graded"]
+        mesh = GradedOctreeMesh(roots, levels, band=band, seed=0)
+        ep = bisect_elements(mesh, c["parts"]) if c["parts"] > 1 else None
+        return mesh, make_octree_parts(mesh, c["parts"], 0, c["tol"], c["max_iter"], c["sign_seed"], elem_part=ep)
     b = Brick(c["N"], seed=0, n_types=c["n_types"])
     parts = make_parts(b, block_partition(b, *c["grid"]), tol=c["tol"], max_iter=c["max_iter"])
     for p in parts:

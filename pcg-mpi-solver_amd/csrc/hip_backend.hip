@@ -98,8 +98,8 @@ class HipBackend : public Backend {
     // profiling
     bool prof_ = false;
     static constexpr int kMaxEv = 8192;
-    std::vector<hipEvent_t> ev0_, ev1_;
-    int ev_used_ = 0;
+    std::vector<hipEvent_t> ev0_, ev1_, evv0_, evv1_;   // operator launches / vector-phase launches
+    int ev_used_ = 0, evv_used_ = 0;
     int64_t ev_applies_ = 0;
 
     int vec_grid(int64_t n) const
@@ -198,6 +198,8 @@ public:
         for (void *p : hex_allocs_) (void)hipFree(p);
         for (auto e : ev0_) (void)hipEventDestroy(e);
         for (auto e : ev1_) (void)hipEventDestroy(e);
+        for (auto e : evv0_) (void)hipEventDestroy(e);
+        for (auto e : evv1_) (void)hipEventDestroy(e);
         if (h_mirror_) {
             (void)hipHostFree(h_mirror_);
             for (auto e : ev_slot_) (void)hipEventDestroy(e);
@@ -719,6 +721,8 @@ public:
         vec_nt_ = 5;
         if (const char *e = getenv("PCG_VEC_NT")) vec_nt_ = atoi(e);          // bit 0: p / r' / x' stores, bit 1: SpMV y stores, bit 2: vector loads
         vec_fused_ok_ = vec_fused_hw_;
+        vec_kreg_ = kVecKreg;
+        if (const char *e = getenv("PCG_VEC_KREG")) vec_kreg_ = std::max(0, std::min(kVecKreg, atoi(e)));
         if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_hw_ && atoi(e) != 0;
     }
     void publish_status(bool copy_block) override
@@ -744,6 +748,7 @@ public:
     // ---- vector phase (k_vec) --------------------------------------------------------------------------------------
     unsigned long long *d_vec_sync_ = nullptr;     // arrival counters of the fused form's grid barrier (monotonic)
     unsigned long long vec_seq_ = 0;               // fused launches so far
+    int vec_kreg_ = kVecKreg;
     bool vec_fused_hw_ = false, vec_fused_ok_ = false;   // the device admits the grid / and PCG_VEC_FUSED does not say 0
     int vec_blocks(int64_t n) const
     {
@@ -766,7 +771,9 @@ public:
             else { a.pa = d_part_spmv_; a.count_a = cnt_spmv_; }
             a.pb = cnt_fix_ ? d_part_fix_ : nullptr; a.count_b = cnt_fix_;
         }
-        a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_;
+        a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_;
+        const bool rec = prof_ && evv_used_ < kMaxEv;
+        if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {
             a.seq = ++vec_seq_;
             hipLaunchKernelGGL((k_vec<true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
@@ -774,6 +781,7 @@ public:
             hipLaunchKernelGGL((k_vec<false>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
         }
         HIP_CHECK(hipGetLastError());
+        if (rec) { HIP_CHECK(hipEventRecord(evv1_[evv_used_], st_)); ++evv_used_; }
         return fused;
     }
     void reduce_update(double *red5) override
@@ -831,10 +839,13 @@ public:
     {
         prof_ = on;
         if (on && ev0_.empty()) {
-            ev0_.resize(kMaxEv); ev1_.resize(kMaxEv);
-            for (int k = 0; k < kMaxEv; ++k) { HIP_CHECK(hipEventCreate(&ev0_[k])); HIP_CHECK(hipEventCreate(&ev1_[k])); }
+            ev0_.resize(kMaxEv); ev1_.resize(kMaxEv); evv0_.resize(kMaxEv); evv1_.resize(kMaxEv);
+            for (int k = 0; k < kMaxEv; ++k) {
+                HIP_CHECK(hipEventCreate(&ev0_[k])); HIP_CHECK(hipEventCreate(&ev1_[k]));
+                HIP_CHECK(hipEventCreate(&evv0_[k])); HIP_CHECK(hipEventCreate(&evv1_[k]));
+            }
         }
-        ev_used_ = 0; ev_applies_ = 0;
+        ev_used_ = 0; ev_applies_ = 0; evv_used_ = 0;
     }
     void collect_profile(double *ms_sum, int64_t *count) override
     {
@@ -842,6 +853,13 @@ public:
         double s = 0;
         for (int k = 0; k < ev_used_; ++k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0_[k], ev1_[k])); s += ms; }
         *ms_sum = s; *count = ev_applies_;
+    }
+    void collect_profile_vec(double *ms_sum, int64_t *count) override
+    {
+        HIP_CHECK(hipStreamSynchronize(st_));
+        double s = 0;
+        for (int k = 0; k < evv_used_; ++k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, evv0_[k], evv1_[k])); s += ms; }
+        *ms_sum = s; *count = evv_used_;
     }
     int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) override
     {

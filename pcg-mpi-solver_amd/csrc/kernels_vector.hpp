@@ -183,6 +183,7 @@ struct VecArgs {
     unsigned long long *sync;             // FUSED: monotonic arrival counters
     unsigned long long seq;               // FUSED: number of this launch (1, 2, ...): targets = arrivals per launch x seq
     int pq_src, nt;
+    int kreg;                             // FUSED: chunks of z kept in registers, <= kVecKreg (tests lower it: PCG_VEC_KREG)
     int64_t n;
 };
 
@@ -249,9 +250,9 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 #pragma unroll
             for (int k = 0; k < kVecKreg; ++k) {
                 const int64_t t = t0 + k * T;
-                if (t < n2) z[k] = chunk(t);
+                if (k < a.kreg && t < n2) z[k] = chunk(t);
             }
-            for (int64_t t = t0 + kVecKreg * T; t < n2; t += T) (void)chunk(t);
+            for (int64_t t = t0 + a.kreg * T; t < n2; t += T) (void)chunk(t);
         } else {
             for (int64_t t = t0; t < n2; t += T) (void)chunk(t);
         }
@@ -321,13 +322,13 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 #pragma unroll
         for (int k = 0; k < kVecKreg; ++k) {
             const int64_t t = t0 + k * T;
-            if (t < n2) {
+            if (k < a.kreg && t < n2) {
                 const double2 pp = pc2[t];
                 const double2 o = make_double2(z[k].x + beta * pp.x, z[k].y + beta * pp.y);      // :479
                 if (nts) ntstore(pn2 + t, o); else pn2[t] = o;
             }
         }
-        for (int64_t t = t0 + kVecKreg * T; t < n2; t += T) {      // beyond the register-resident part: z again from r', M^-1
+        for (int64_t t = t0 + a.kreg * T; t < n2; t += T) {        // beyond the register-resident part: z again from r', M^-1
             const double2 rr = rn2[t], mm = m2[t], pp = pc2[t];
             const double2 o = make_double2(mm.x * rr.x + beta * pp.x, mm.y * rr.y + beta * pp.y);
             if (nts) ntstore(pn2 + t, o); else pn2[t] = o;

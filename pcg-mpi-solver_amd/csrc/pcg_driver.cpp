@@ -416,6 +416,7 @@ void fill_result(pcg_engine *e, pcg_result *res)
     if (e->profiling) e->be->collect_profile(&ms, &cnt);
     res->spmv_ms_sum = ms;
     res->spmv_count = cnt;
+    if (e->profiling) e->be->collect_profile_vec(&res->vec_ms_sum, &res->vec_count);
     res->iters_enqueued = s.n_enqueued;
 }
 

@@ -266,6 +266,7 @@ public:
     // profiling of the SpMV launches with events on the stream
     virtual void set_profiling(bool on) = 0;
     virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
+    virtual void collect_profile_vec(double *ms_sum, int64_t *count) { *ms_sum = 0; *count = 0; }   // the vec_update launches
     virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;
     // stream microbenchmark over `bytes` of device memory: mode 0 read-only, 1 copy (read + write); ms per repetition
     virtual int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) = 0;

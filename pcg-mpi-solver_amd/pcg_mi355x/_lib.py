@@ -44,7 +44,8 @@ class Result(C.Structure):
     _fields_ = [("flag", C.c_int32), ("status", C.c_int32), ("iter", C.c_int64), ("iters_done", C.c_int64),
                 ("n_matvec", C.c_int64), ("relres", C.c_double), ("norm_b", C.c_double),
                 ("normr_act", C.c_double), ("t_total_s", C.c_double), ("t_comm_s", C.c_double),
-                ("spmv_ms_sum", C.c_double), ("spmv_count", C.c_int64), ("iters_enqueued", C.c_int64)]
+                ("spmv_ms_sum", C.c_double), ("spmv_count", C.c_int64), ("iters_enqueued", C.c_int64),
+                ("vec_ms_sum", C.c_double), ("vec_count", C.c_int64)]
 
 
 class CommStats(C.Structure):

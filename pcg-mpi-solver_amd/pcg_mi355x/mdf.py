@@ -91,15 +91,15 @@ def model_from_brick(brick):
 
 
 def model_from_octree(mesh, sign_seed=None):
-    """octree.TwoLevelMesh (hex8 cells of two sizes + 13-node transition patterns) as a global MDF model."""
+    """octree.TwoLevelMesh (hex8 cells of two sizes + 13-node transition patterns) or octree.GradedOctreeMesh (multi-level, many
+    pattern types) as a global MDF model."""
     flips = [np.zeros(3 * g.shape[1], bool) for g in mesh.group_nodes]
     if sign_seed is not None:
         r = np.random.default_rng(sign_seed)
         flips = [r.random(3 * g.shape[1]) < 0.4 for g in mesh.group_nodes]
     node_flat, node_off, dof_flat, dof_off = _ragged(mesh.group_nodes)
     sign = np.concatenate([np.tile(f, len(g)) for f, g in zip(flips, mesh.group_nodes)])
-    n_fine = len(mesh.cells["fine"])
-    level = np.concatenate([np.ones(n_fine), 2.0 * np.ones(len(mesh.group_nodes[0]) - n_fine), 2.0 * np.ones(len(mesh.group_nodes[1]))])
+    level = np.concatenate(mesh.group_level)                                    # cell edge length per element
     ke = []
     for k, f in zip(mesh.group_ke, flips):
         d = np.where(f, -1.0, 1.0)

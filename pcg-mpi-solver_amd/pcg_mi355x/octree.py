@@ -26,7 +26,7 @@ import numpy as np
 
 from .brick import hex8_stiffness, glob_settings
 
-__all__ = ["transition_stiffness", "TwoLevelMesh", "make_octree_parts"]
+__all__ = ["transition_stiffness", "TwoLevelMesh", "make_octree_parts", "pattern_stiffness", "GradedOctreeMesh", "HANG_POS"]
 
 
 def _sub27():
@@ -108,6 +108,8 @@ class TwoLevelMesh:
         self.group_ck = [np.concatenate([mat(len(self.cells["fine"])), 2.0 * mat(len(self.cells["coarse"]))]),
                          mat(len(self.cells["trans"]))]
         self.group_ke = [hex8_stiffness(), transition_stiffness()]
+        nf = len(self.cells["fine"])
+        self.group_level = [np.concatenate([np.ones(nf), 2.0 * np.ones(len(self.cells["coarse"]))]), 2.0 * np.ones(len(self.cells["trans"]))]
         # element centroids (for geometric partitioning)
         self.group_centroid = [self.coords[g].mean(axis=1) for g in self.group_nodes]
         self.fixed_nodes = np.flatnonzero(self.coords[:, 2] == 0)
@@ -119,14 +121,26 @@ class TwoLevelMesh:
         return F
 
 
-def make_octree_parts(mesh: TwoLevelMesh, n_parts=1, axis=0, tol=1e-7, max_iter=10000, sign_seed=None):
-    """RefMeshPart dicts (same keys as brick.make_parts) for `n_parts` slabs along `axis` (by element centroid).
-    sign_seed: give every pattern a random sign frame (Ke_t = D Ke D, mask undone per element, like brick.py)."""
+def bisect_elements(mesh, n_parts):
+    """Element -> part id by recursive coordinate bisection of the element centroids (the stand-in for METIS,
+    partition.geometric_partition; elements in group order), as a list of arrays per pattern group."""
+    from .partition import geometric_partition
+    part = geometric_partition({"sctrs": np.concatenate(mesh.group_centroid)}, n_parts)
+    cuts = np.cumsum([len(c) for c in mesh.group_centroid])[:-1]
+    return np.split(part, cuts)
+
+
+def make_octree_parts(mesh, n_parts=1, axis=0, tol=1e-7, max_iter=10000, sign_seed=None, elem_part=None):
+    """RefMeshPart dicts (same keys as brick.make_parts) for `n_parts` slabs along `axis` (by element centroid), or for the
+    element -> part map `elem_part` (list of arrays per pattern group, e.g. bisect_elements()).  mesh: TwoLevelMesh or
+    GradedOctreeMesh.  sign_seed: give every pattern a random sign frame (Ke_t = D Ke D, mask undone per element)."""
     F = mesh.load_vector()
     fixed = np.zeros(mesh.n_dof, bool)
     fixed[(3 * mesh.fixed_nodes[:, None] + np.arange(3)).ravel()] = True
     ext = mesh.coords[:, axis].max()
     part_of = [np.minimum((c[:, axis] / ext * n_parts).astype(int), n_parts - 1) for c in mesh.group_centroid]
+    if elem_part is not None:
+        part_of = [np.asarray(v, np.int64) for v in elem_part]
     flips = [np.zeros(3 * g.shape[1], bool) for g in mesh.group_nodes]
     if sign_seed is not None:
         r = np.random.default_rng(sign_seed)
@@ -192,3 +206,218 @@ def make_octree_parts(mesh: TwoLevelMesh, n_parts=1, axis=0, tol=1e-7, max_iter=
         p["Un"] = np.zeros(p["NDOF"])
         p["DofWeightVector_Eff"] = p["DofWeightVector"][p["LocDofEff"]]
     return parts
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Multi-level, 2:1-balanced octree mesh (round 3).  The reference's meshes are octree cells of many
+# sizes whose hanging nodes make PATTERN TYPES (partition_mesh.py:443-491 groups the elements by `Type`, :576-581 reads one
+# Ke per type, NNodes = nd / 3; up to 144 types, :1074).  This generator builds such a mesh around a spherical surface:
+# cells are refined towards the surface over `levels` levels, the tree is balanced across faces, edges AND corners, and
+# every coarse cell keeps exactly those of its 18 candidate hanging positions (12 edge mid-points, 6 face centres) at which
+# a finer neighbour has a corner.  A pattern type = one 18-bit mask of kept positions: 9 to 26 nodes, nd = 27 ... 78.
+# ---------------------------------------------------------------------------------------------------------------------
+# the 18 candidate hanging positions of a cell in half-edge units, ascending position index a + 3 b + 9 c
+HANG_POS = [(a, b, c) for c in range(3) for b in range(3) for a in range(3) if (a == 1) + (b == 1) + (c == 1) in (1, 2)]
+_CORNERS = [(2 * (a & 1), 2 * ((a >> 1) & 1), 2 * ((a >> 2) & 1)) for a in range(8)]
+
+
+def pattern_stiffness(mask):
+    """Element matrix of the pattern with hanging positions `mask` (bit q = HANG_POS[q] is a node), for a cell of edge 2:
+    the cell is split into its 8 unit sub-cells (27 lattice points, trilinear hex8 each) and every lattice point that is NOT a
+    node follows hierarchically from the nodes - an edge mid-point is the mean of its two corners, a face centre the mean of
+    its four edge mid-points, the cell centre the mean of the six face centres (K = C^T K27 C).  The rule for a face uses
+    data of that face only, so two cells that share a face (or an edge) interpolate it identically: conforming across every
+    2:1 transition; symmetric positive semi-definite with exactly the six rigid-body modes (linear fields are reproduced).
+    Node order: the 8 corners (a = dx + 2 dy + 4 dz), then the kept positions in ascending HANG_POS order."""
+    Ke = hex8_stiffness()
+    K27 = np.zeros((81, 81))
+    for nodes in _sub27():
+        idx = np.array([3 * n + d for n in nodes for d in range(3)])
+        K27[np.ix_(idx, idx)] += Ke
+    kept = list(_CORNERS) + [HANG_POS[q] for q in range(18) if (mask >> q) & 1]
+    col = {pt: k for k, pt in enumerate(kept)}
+    rows = {}
+
+    def row(pt):
+        if pt in rows:
+            return rows[pt]
+        r = np.zeros(len(kept))
+        if pt in col:
+            r[col[pt]] = 1.0
+        else:
+            ones = [d for d in range(3) if pt[d] == 1]
+            if len(ones) == 1:                                  # edge mid-point: its two corners
+                d = ones[0]
+                for v in (0, 2):
+                    q = list(pt); q[d] = v
+                    r += 0.5 * row(tuple(q))
+            elif len(ones) == 2:                                # face centre: the four edge mid-points of the face
+                for d in ones:
+                    for v in (0, 2):
+                        q = list(pt); q[d] = v
+                        r += 0.25 * row(tuple(q))
+            else:                                               # cell centre: the six face centres
+                for d in range(3):
+                    for v in (0, 2):
+                        q = list(pt); q[d] = v
+                        r += row(tuple(q)) / 6.0
+        rows[pt] = r
+        return r
+    Cn = np.stack([row((x, y, z)) for z in range(3) for y in range(3) for x in range(3)])      # (27, n_kept), lattice index x + 3y + 9z
+    C = np.kron(Cn, np.eye(3))
+    K = C.T @ K27 @ C
+    return 0.5 * (K + K.T)
+
+
+class GradedOctreeMesh:
+    """`roots` = (Rx, Ry, Rz) root cells of edge 2**levels lattice units, refined over `levels` levels towards the sphere
+    |x - centre| = radius: a cell of edge s is split when its centre lies within band * s of the surface; then balanced 2:1
+    over the full 26-neighbourhood.  Same attribute set as TwoLevelMesh (group_nodes / group_ck / group_ke / group_centroid /
+    group_level, coords, fixed_nodes, top_nodes, load_vector) - make_octree_parts, mdf.model_from_octree and
+    partition.partition_model take either.  Host-side set-up only (whole-array NumPy)."""
+
+    def __init__(self, roots=(4, 4, 4), levels=3, centre=None, radius=None, band=1.0, seed=0, two_phase=True):
+        L = int(levels)
+        R = np.array(roots, np.int64)
+        S0 = 1 << L
+        dims = R * S0                                            # lattice extent (cells of edge 1)
+        self.roots, self.levels, self.band = tuple(int(r) for r in R), L, float(band)
+        c = np.array(centre if centre is not None else dims / 2.0, float)
+        rho = float(radius if radius is not None else 0.3 * dims.min())
+        self.centre, self.radius = c, rho
+
+        def nx(l):
+            return R << l                                        # cells per axis at level l
+
+        def key(l, i, j, k):
+            n = nx(l)
+            return (k * n[1] + j) * n[0] + i
+
+        def unkey(l, q):
+            n = nx(l)
+            return q % n[0], (q // n[0]) % n[1], q // (n[0] * n[1])
+
+        def children(l, q):                                      # keys at level l + 1
+            i, j, k = unkey(l, q)
+            out = [key(l + 1, 2 * i + (a & 1), 2 * j + ((a >> 1) & 1), 2 * k + ((a >> 2) & 1)) for a in range(8)]
+            return np.stack(out, 1).ravel()
+
+        def parents(l, q):                                       # keys at level l - 1
+            i, j, k = unkey(l, q)
+            return np.unique(key(l - 1, i // 2, j // 2, k // 2))
+
+        def n26(l, q):
+            i, j, k = unkey(l, q)
+            n = nx(l)
+            out = []
+            for dk in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    for di in (-1, 0, 1):
+                        if di == dj == dk == 0:
+                            continue
+                        ii, jj, kk = i + di, j + dj, k + dk
+                        ok = (ii >= 0) & (ii < n[0]) & (jj >= 0) & (jj < n[1]) & (kk >= 0) & (kk < n[2])
+                        out.append(key(l, ii[ok], jj[ok], kk[ok]))
+            return np.unique(np.concatenate(out)) if out else np.zeros(0, np.int64)
+
+        # 1. refinement towards the surface, top down
+        I = []                                                   # internal (split) cells per level 0 .. L-1
+        cand = np.arange(int(np.prod(R)), dtype=np.int64)
+        for l in range(L):
+            s = S0 >> l
+            i, j, k = unkey(l, cand)
+            ctr = (np.stack([i, j, k], 1) + 0.5) * s
+            d = np.abs(np.linalg.norm(ctr - c, axis=1) - rho)
+            split = cand[d < band * s]
+            I.append(np.unique(split))
+            cand = children(l, I[l])
+        # 2. 2:1 balance over faces, edges and corners, one sweep from the finest level down: every neighbour of a split
+        #    cell exists at that cell's level, i.e. its parent is split too
+        for l in range(L - 1, 0, -1):
+            need = np.union1d(n26(l, I[l]), I[l])
+            I[l - 1] = np.union1d(I[l - 1], parents(l, need))
+        # 3. leaves
+        leaves = []                                              # (level, keys)
+        exist = np.arange(int(np.prod(R)), dtype=np.int64)
+        for l in range(L + 1):
+            if l < L:
+                leaves.append(np.setdiff1d(exist, I[l], assume_unique=True))
+                exist = np.sort(children(l, I[l]))
+            else:
+                leaves.append(exist)
+        self.leaves_per_level = [len(v) for v in leaves]
+        # 4. nodes = the corners of all leaves, on the finest lattice
+        X, Y, Z = (int(v) + 1 for v in dims)
+        self.dims = (X, Y, Z)
+
+        def lat(x, y, z):
+            return (z * Y + y) * X + x
+        org, size = [], []
+        for l, q in enumerate(leaves):
+            s = S0 >> l
+            i, j, k = unkey(l, q)
+            org.append(np.stack([i, j, k], 1) * s)
+            size.append(np.full(len(q), s, np.int64))
+        org = np.concatenate(org)
+        size = np.concatenate(size)
+        corners = np.stack([lat(org[:, 0] + size * (a & 1), org[:, 1] + size * ((a >> 1) & 1), org[:, 2] + size * ((a >> 2) & 1))
+                            for a in range(8)], 1)
+        used = np.unique(corners)
+        self.lattice_of_node = used
+        self.n_node = len(used)
+        self.n_dof = 3 * self.n_node
+        self.n_elem = len(org)
+        # 5. pattern of every leaf: which of its 18 hanging positions are nodes
+        h = size // 2
+        mask = np.zeros(len(org), np.int64)
+        hang_ids = np.zeros((len(org), 18), np.int64)
+        big = size >= 2
+        for q, (a, b, cc) in enumerate(HANG_POS):
+            pid = lat(org[:, 0] + a * h, org[:, 1] + b * h, org[:, 2] + cc * h)
+            pos = np.searchsorted(used, pid)
+            pos[pos >= len(used)] = 0
+            is_node = big & (used[pos] == pid)
+            mask |= is_node.astype(np.int64) << q
+            hang_ids[:, q] = pos
+        cn = np.searchsorted(used, corners)                      # (E, 8) node ids
+        rng = np.random.default_rng(seed)
+        mat = np.where(rng.random(len(org)) < 0.5, 1.0, 3.0) if two_phase else np.ones(len(org))    # two-phase scaling like brick.py
+        ctr = org + size[:, None] / 2.0
+        self.pattern_masks = [0] + sorted(int(m) for m in np.unique(mask) if m != 0)
+        self.group_nodes, self.group_ck, self.group_ke, self.group_centroid, self.group_level = [], [], [], [], []
+        for m in self.pattern_masks:
+            sel = np.flatnonzero(mask == m)
+            if m == 0:
+                nodes = cn[sel]
+                ck = size[sel] * mat[sel]                        # 3-D elasticity: K ~ edge length
+                ke = hex8_stiffness()
+            else:
+                bits = [q for q in range(18) if (m >> q) & 1]
+                nodes = np.concatenate([cn[sel], hang_ids[sel][:, bits]], 1)
+                ck = (size[sel] / 2.0) * mat[sel]                # pattern_stiffness is the matrix of a cell of edge 2
+                ke = pattern_stiffness(m)
+            self.group_nodes.append(np.ascontiguousarray(nodes))
+            self.group_ck.append(ck)
+            self.group_ke.append(ke)
+            self.group_centroid.append(ctr[sel])
+            self.group_level.append(size[sel].astype(float))
+        self.coords = np.stack([used % X, (used // X) % Y, used // (X * Y)], 1).astype(float)
+        self.fixed_nodes = np.flatnonzero(self.coords[:, 2] == 0)
+        self.top_nodes = np.flatnonzero(self.coords[:, 2] == self.coords[:, 2].max())
+        self.nnz = None
+
+    def load_vector(self):
+        F = np.zeros(self.n_dof)
+        F[3 * self.top_nodes + 2] = -1.0
+        return F
+
+    def summary(self):
+        """What the mesh looks like to the operators: leaves per level, pattern types with node and element counts."""
+        return {"dofs": int(self.n_dof), "elements": int(self.n_elem), "levels": self.levels + 1,
+                "leaves_per_level_coarse_to_fine": [int(v) for v in self.leaves_per_level],
+                "pattern_types": len(self.pattern_masks),
+                "nodes_per_element_max": int(max(g.shape[1] for g in self.group_nodes)),
+                "elements_hex8": int(len(self.group_nodes[0])),
+                "elements_with_hanging_nodes": int(self.n_elem - len(self.group_nodes[0])),
+                "elements_by_node_count": {str(nn): int(sum(len(g) for g in self.group_nodes if g.shape[1] == nn))
+                                           for nn in sorted({g.shape[1] for g in self.group_nodes})}}

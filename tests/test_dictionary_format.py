@@ -206,7 +206,7 @@ def test_dictionary_from_a_scalar_csr_matrix(hostops):
         op.close(); ref.close()
 
 
-@pytest.mark.parametrize("case", ["n9_p1", "n9_flag4", "n9_maxiter", "oct_p1", "n17_p1"])
+@pytest.mark.parametrize("case", ["n9_p1", "n9_flag4", "n9_maxiter", "oct_p1", "n17_p1", "goct_p1"])
 def test_dictionary_solve_matches_reference_fixture(hostops, case):
     import pcg_mi355x as pm
     _, parts = golden_cases.build_case(case)

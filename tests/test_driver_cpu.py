@@ -135,17 +135,44 @@ def _solve_both_ways(monkeypatch, case, kind="sell"):
     return out
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 @pytest.mark.parametrize("case", ["n9_p1", "n9_maxiter", "n9_stagnate", "n9_flag4", "n9_flag2", "oct_p1"])
-def test_look_ahead_changes_nothing(hostops, monkeypatch, case, kind):
+def test_look_ahead_changes_nothing(hostops, monkeypatch, case, kind, fused):
     """Iteration i+1 is enqueued before the host has seen the sums of iteration i; every exit path (converged,
-    MaxIter, stagnation, breakdown, inf) must give bit-identical results with the look-ahead on and off."""
+    MaxIter, stagnation, breakdown, inf) must give bit-identical results with the look-ahead on and off - with the
+    single vector launch per iteration (fused: it already writes p of iteration i+1, so a dropped look-ahead must not
+    have overwritten p of iteration i: ring of three) and with the split form of the multi-GPU loop."""
+    monkeypatch.setenv("PCG_VEC_FUSED", fused)
     on, off = _solve_both_ways(monkeypatch, case, kind)
     assert np.array_equal(on[0], off[0])
     assert on[1:5] == off[1:5] and on[6] == off[6]
     assert np.array_equal(on[7], off[7])
     assert 0 <= off[5] - off[4] <= 1                              # off: the consumed iterations (+ the one a breakdown froze)
     assert 0 <= on[5] - off[5] <= 2                               # on: plus the dropped look-aheads of a break / the :527 branch
+
+
+@pytest.mark.parametrize("la", ["1", "0"])
+@pytest.mark.parametrize("case", ["n9_p1", "n9_maxiter", "n9_stagnate", "n9_flag4", "n9_flag2", "oct_p1", "n17_p1", "n9_raise"])
+def test_fused_vector_launch_changes_nothing(hostops, monkeypatch, case, la):
+    """The single-part loop forms p of iteration i+1 inside the vector launch of iteration i (Backend::vec_update with
+    p_next) and skips update_p; the true-residual branch (:527-549) voids that p and falls back to update_p.  Same bits
+    as the split form on every exit path."""
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_LOOK_AHEAD", la)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PCG_VEC_FUSED", fused)
+        _, parts = golden_cases.build_case(case)
+        P = parts[0]
+        op = from_refmeshpart(P)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"],
+                                P["GlobData"]["GlobNDofEff"], history=True)
+        out.append((x, (res.flag, res.iter, res.relres, res.iters_done, res.n_matvec), hist))
+        op.close()
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
 
 
 def test_dropped_look_ahead_leaves_no_stop_flag_behind(hostops, monkeypatch):

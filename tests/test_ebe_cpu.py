@@ -11,7 +11,7 @@ import pcg_oracle
 import pcg_mi355x as pm
 from util import golden, relerr, check_solution_against_golden, run_dist, make_super_part
 
-SINGLE = ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_zero_rhs", "oct_p1"]
+SINGLE = ["n9_p1", "n17_p1", "n9_maxiter", "n9_raise", "n9_zero_rhs", "oct_p1", "goct_p1"]
 
 
 @pytest.fixture(autouse=True)
@@ -83,7 +83,7 @@ def test_patterns_with_nd_36_and_mixed_groups(hostops, kind, N):
     assert relerr(P["Un"], R["Un"]) < 1e-8
 
 
-@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622), ("oct_p3", 3, 29623)])
+@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622), ("oct_p3", 3, 29623), ("goct_p4", 4, 29624)])
 def test_ebe_multi_rank(tmp_path, case, nproc, port):
     import conftest
     conftest.build_hostops()

@@ -7,9 +7,13 @@ solve of the 1 M-dof brick (BASELINE configs[1]) and hands the vectors of every 
 
     p_i  = k_update_p(r_i, p_{i-1}, beta_i)                      must EQUAL the oracle's P bit for bit   (:447,:472-479)
     q_i  = operator(p_i) with the fused p.Ap                     <= 1e-13 relative                       (:482-488)
-    r', x', [|p|^2,|x|^2,|r'|^2, rho_{i+1}] = k_fused_update     r', x' bit-equal; sums <= 1e-13         (:501-516,:462)
+    r', x', [|p|^2,|x|^2,|r'|^2, rho_{i+1}], p_{i+1} = k_vec     r', x' bit-equal; sums <= 1e-13;        (:501-516,:462,
+                                                                 p_{i+1} == M^-1 r' + (rho_{i+1} / rho_i) p_i bit for bit   :475-479)
 
-so the late-iteration behaviour of every kernel is pinned at the per-kernel tolerance, for both operators.
+(k_vec = the single vector launch of the single-part loop, round 3: update, grid-wide reduction, beta, next search direction)
+so the late-iteration behaviour of every kernel is pinned at the per-kernel tolerance, for both operators.  The host's
+stagnation test (:512-513) is evaluated on the engine's sums and must take the oracle's decision at every iteration
+(`test_stagnation_exit_in_lock_step`: the Flag-3 fixture, whose free-running exit iteration is rounding-chaotic).
 """
 import copy
 import os
@@ -37,9 +41,37 @@ def test_lock_step_harness_on_the_cpu_double(hostops, oracle_c, kind):
     lock_step(kind, 13)
 
 
-def lock_step(kind, N):
-    b = Brick(N, seed=0)
-    P = make_parts(b)[0]
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_stagnation_exit_in_lock_step(gpu_lib, oracle_c, kind):
+    """n9_stagnate (Tol 1e-15; the reference ends with Flag 3 at iteration 177 via :560-562): the oracle walks the solve, the
+    engine's sums of EVERY iteration drive the host's stagnation test and it must decide like the oracle each time - so the
+    stagnation counter, and with it the exit, are pinned on the HIP kernels with identical inputs."""
+    st = lock_step(kind, 0, case="n9_stagnate", expect_flag=3)
+    assert st["stag_hits"] >= 3 and st["count"] >= 100
+
+
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_stagnation_exit_in_lock_step_on_the_cpu_double(hostops, oracle_c, kind):
+    lock_step(kind, 0, case="n9_stagnate", expect_flag=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("PCG_LOCKSTEP_10M"), reason="10 M-dof lock-step window: set PCG_LOCKSTEP_10M=<iterations> (minutes of CPU oracle time)")
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_lock_step_window_at_10m_dof(gpu_lib, oracle_c, kind):
+    """The metric's size (brick N = 150): the first PCG_LOCKSTEP_10M iterations in lock-step."""
+    lock_step(kind, 150, max_iter=int(os.environ["PCG_LOCKSTEP_10M"]), expect_flag=1)
+
+
+def lock_step(kind, N, case=None, max_iter=None, expect_flag=0):
+    if case is not None:
+        import golden_cases
+        b, parts = golden_cases.build_case(case)
+        P = parts[0]
+    else:
+        b = Brick(N, seed=0)
+        P = make_parts(b)[0] if max_iter is None else make_parts(b, max_iter=max_iter)[0]
     R = copy.deepcopy(P)
     op = from_refmeshpart(P, kind=kind)
     n = b.n_dof
@@ -49,7 +81,9 @@ def lock_step(kind, N):
     minv = np.zeros(n); minv[eff] = R["InvDiagPreCondVector0"]
     minv_e = op.to_engine(minv)
     worst = {"q": 0.0, "pq": 0.0, "sums": 0.0, "rho_next": 0.0}
-    state = {"p_prev": np.zeros(n), "rho_next_engine": None, "count": 0}
+    state = {"p_prev": np.zeros(n), "rho_next_engine": None, "count": 0, "stag_hits": 0}
+    EPS = np.finfo(float).eps
+    fused = 1 if L_fused_available(op) else 0
     L, h = op._L, op._h
 
     def full(v):
@@ -60,7 +94,7 @@ def lock_step(kind, N):
         i = o["i"]
         r0, x0, p_o, q_o, r1, x1 = (full(o[k][0]) for k in ("R_before", "X_before", "P", "Q", "R_after", "X_after"))
         # -- rho of THIS iteration was produced by the previous fused update (engine: st[RHO_NEXT]) -------------------
-        if state["rho_next_engine"] is not None:
+        if state["rho_next_engine"] is not None and np.array_equal(r0, state["r_after_prev"]):   # (not after :527-531 replaced R)
             d = abs(state["rho_next_engine"] - o["rho"]) / abs(o["rho"])
             worst["rho_next"] = max(worst["rho_next"], d)
             assert d < 1e-13, (i, d)
@@ -79,19 +113,39 @@ def lock_step(kind, N):
         worst["q"], worst["pq"] = max(worst["q"], dq), max(worst["pq"], dpq)
         assert dq < 1e-13 and dpq < 1e-13, (i, dq, dpq)
         # -- residual / solution update and the five sums ----------------------------------------------------------------
-        rr = r0e.copy(); xn = np.empty(n); sums = np.zeros(5)
-        check(L.pcg_k_fused_update(h, float(o["alpha"]), pe.ctypes.data, qe.ctypes.data, rr.ctypes.data,
-                                   x0e.ctypes.data, xn.ctypes.data, minv_e.ctypes.data, sums.ctypes.data))
+        rr = r0e.copy(); xn = np.empty(n); pn = np.empty(n); sums = np.zeros(5)
+        check(L.pcg_k_vec_iteration(h, float(o["alpha"]), float(o["rho"]), pe.ctypes.data, qe.ctypes.data, rr.ctypes.data,
+                                    x0e.ctypes.data, xn.ctypes.data, minv_e.ctypes.data, pn.ctypes.data, sums.ctypes.data, fused))
         assert np.array_equal(op.from_engine(rr)[eff], r1[eff]) and np.array_equal(op.from_engine(xn)[eff], x1[eff]), i
+        assert np.array_equal(pn, minv_e * rr + (sums[3] / float(o["rho"])) * pe), i               # :447, :475, :479
         ds = max(abs(a - c) / c if c > 0 else abs(a) for a, c in zip(sums[:3], o["sq"]))      # |x|^2 = 0 before the first update
         worst["sums"] = max(worst["sums"], ds)
         assert ds < 1e-13 and sums[4] == 0.0, (i, ds)
+        # -- the host's stagnation test (:512-513) on the ENGINE's sums takes the oracle's decision ------------------------
+        stag_e = np.sqrt(sums[0]) * abs(o["alpha"]) < EPS * np.sqrt(sums[1])
+        stag_o = np.sqrt(o["sq"][0]) * abs(o["alpha"]) < EPS * np.sqrt(o["sq"][1])
+        assert stag_e == stag_o, (i, sums[:2], o["sq"][:2])
+        state["stag_hits"] += int(stag_o)
         state["rho_next_engine"] = sums[3]
+        state["r_after_prev"] = r1.copy()
         state["p_prev"] = p_o
         state["count"] += 1
 
     out = pcg_oracle.pcg([R], use_c=True, record=False, observer=observer)
     op.close()
-    assert out["flag"] == 0 and state["count"] == out["iter"]          # every iteration of the converged solve was compared
-    assert state["count"] > (600 if N >= 70 else 50)
-    print(f"lock-step {kind}: {state['count']} iterations of {n} dof, worst relative deviations {worst}")
+    assert out["flag"] == expect_flag, out["flag"]
+    if expect_flag == 0:
+        assert state["count"] == out["iter"]                           # every iteration of the converged solve was compared
+        assert state["count"] > (600 if N >= 70 else 50)
+    print(f"lock-step {kind}{' ' + case if case else ''}: {state['count']} iterations of {n} dof (fused vector launch: {bool(fused)}), "
+          f"stagnation test true {state['stag_hits']} times, worst relative deviations {worst}")
+    return state
+
+
+def L_fused_available(op):
+    """Whether the engine runs the single vector launch (one probe call on zero vectors)."""
+    n = op.n
+    z = np.zeros(n); o = np.ones(n); s5 = np.zeros(5); pn = np.empty(n); xn = np.empty(n); rr = np.zeros(n)
+    rc = op._L.pcg_k_vec_iteration(op._h, 0.0, 1.0, z.ctypes.data, z.ctypes.data, rr.ctypes.data, z.ctypes.data, xn.ctypes.data,
+                                   o.ctypes.data, pn.ctypes.data, s5.ctypes.data, 1)
+    return rc == 0

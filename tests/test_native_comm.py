@@ -103,7 +103,7 @@ def test_real_rccl_send_recv_group_on_one_gpu(gpu_lib, tmp_path):
             assert relerr(got, want) < 1e-13                        # (the exchange-free operator numbers its rows differently)
 
 
-@pytest.mark.parametrize("cases", ["n9_p2,n9_p8", "n9_p2_flag4,n9_p2_maxiter", "oct_p3,oct_p2_z,n13_t3_p4_ud"])
+@pytest.mark.parametrize("cases", ["n9_p2,n9_p8", "n9_p2_flag4,n9_p2_maxiter", "oct_p3,oct_p2_z,n13_t3_p4_ud", "goct_p4"])
 def test_parts_as_threads_on_one_gpu(gpu_lib, tmp_path, cases):
     r = subprocess.run([sys.executable, WORKER, "threads", cases, "sell,ebe", str(tmp_path)], env=_env(True),
                        capture_output=True, text=True, timeout=900)

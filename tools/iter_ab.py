@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Per-iteration time of the PCG loop, same process / same operator A/B over environment switches the engine re-reads at
+solve_begin (PCG_VEC_FUSED, PCG_VEC_NT, PCG_VEC_KREG, PCG_LOOK_AHEAD is read at creation).
+usage: python tools/iter_ab.py N[,N..] kind[,kind..] [steps] [VAR=a|b ...]      e.g.  iter_ab.py 75,150 ebe,dict 200 PCG_VEC_FUSED=1|0"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
+import numpy as np
+import torch
+from pcg_mi355x.brick import Brick, make_parts
+from pcg_mi355x.operator import from_refmeshpart
+Ns = [int(a) for a in sys.argv[1].split(",")]
+kinds = sys.argv[2].split(",")
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+switches = [a.split("=", 1) for a in sys.argv[4:]] or [["PCG_VEC_FUSED", "1|0"]]
+out = []
+for N in Ns:
+    P = make_parts(Brick(N))[0]
+    for kind in kinds:
+        op = from_refmeshpart(P, kind=kind)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        inv = op.build_jacobi()
+        for var, vals in switches:
+            for rep in range(2):
+                for v in vals.split("|"):
+                    os.environ[var] = v
+                    op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
+                    op.solve_run(20)
+                    op.set_profiling(True)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    r = op.solve_run(steps)
+                    torch.cuda.synchronize(); t = time.perf_counter() - t0
+                    op.set_profiling(False)
+                    op.solve_end()
+                    rec = {"N": N, "dof": op.n, "kind": kind, var: v, "rep": rep, "us_per_iter": t / steps * 1e6, "it_per_s": steps / t,
+                           "operator_us": r.spmv_ms_sum / max(1, r.spmv_count) * 1e3, "vec_us": r.vec_ms_sum / max(1, r.vec_count) * 1e3}
+                    out.append(rec); print(rec, file=sys.stderr, flush=True)
+            os.environ.pop(var, None)
+        op.close()
+print(json.dumps(out))
