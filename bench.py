@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=["brick", "octree"], default="brick",
                     help="brick = SURVEY 8(d) uniform brick (the metric's configuration); octree = two-level 2:1 graded mesh with "
                          "hanging-node transition patterns, ~1.2 M dof (BASELINE configs[1] names an octree mesh)")
+    ap.add_argument("--octree-size", choices=["1m", "10m"], default="1m", help="--workload octree: 1 M dof (BASELINE configs[1]) or 10 M dof")
+    ap.add_argument("--no-octree", action="store_true", help="brick workload, N = 1: skip the `octree` object (the 1 M-dof graded octree mesh on all three operators)")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("PCG_ROWS_PER_LANE", "0")))
     ap.add_argument("--operator", choices=["sell", "ebe", "dict", "both"], default="both",
                     help="sell = assembled SELL-BSR3 matrix (the headline value/roofline); both = also time the same matrix in the "
@@ -303,6 +305,40 @@ def pmc_traffic_live(args):
             "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1]}
 
 
+def octree_object(measure, log):
+    """BASELINE configs[1] names "a synthetic 3D elasticity octree mesh, 1M DOFs": the multi-level graded octree mesh of
+    pcg_mi355x.octree.GradedOctreeMesh (5 cell sizes, 2:1 balanced over faces / edges / corners, ~95 pattern types with 9-20
+    nodes besides hex8) on all three operators - iterations/s, operator time, what the formats make of it."""
+    import numpy as np
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    t0 = time.perf_counter()
+    mesh = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0)
+    opart = make_octree_parts(mesh, 1)[0]
+    obj = {"workload": "multi-level 2:1-balanced octree mesh around a sphere (GradedOctreeMesh((12,12,12), levels=4, band=1.2)), Jacobi-PCG Tol 1e-7, 1 part",
+           "mesh": mesh.summary(), "mesh_setup_s": time.perf_counter() - t0, "steps": 200, "warmup": 20}
+    for kind in ("sell", "dict", "ebe"):
+        mm = measure(kind, opart, steps=200, warmup=20, standalone_reps=30)
+        op = mm["op"]
+        e = {"value": 200 / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / 200 * 1e3, "operator_avg_ms": mm["op_ms"],
+             "standalone_operator": mm["standalone"], "solve": mm["final"], "setup_s": mm["t_setup"],
+             "vector_phase_ms": mm["vec"]["avg_launch_ms"] if mm["vec"] else None}
+        by, fl = op.operator_cost()
+        e["operator_bytes"], e["operator_flops"] = by, fl
+        if kind in ("sell", "dict"):
+            info = op.matrix_info()
+            e["sell_padding"] = info["stored_blocks"] / max(1, info["nnzb"]) - 1
+            e["nnz"] = op.nnz
+        if kind == "dict":
+            e["table"] = op.matrix_dictionary_info()        # distinct blocks, how many sit in LDS, the share of stored blocks those cover
+        if kind == "ebe":
+            e["operator_info"] = op.operator_info()
+        obj[{"sell": "assembled", "dict": "assembled_dictionary", "ebe": "matrix_free"}[kind]] = e
+        op.close()
+        log(f"[octree {kind}] {e['value']:.0f} it/s, operator {e['operator_avg_ms']:.4f} ms, solve {e['solve']}")
+    opart.pop("_pcg_mi355x_operator", None)
+    return obj
+
+
 def box_identity(dev):
     """What distinguishes one MI355X box from another for a bandwidth-bound kernel."""
     import torch
@@ -383,12 +419,15 @@ def main():
     N = args.nodes_per_side
     t0 = time.perf_counter()
     if args.workload == "octree":
-        from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
-        brick = TwoLevelMesh(96, 96, 40, 8, seed=0)                 # .n_dof like a Brick; nnz filled in after assembly
+        from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
+        roots = {"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size]
+        brick = GradedOctreeMesh(roots, 4, band=1.2, seed=0)        # .n_dof like a Brick; nnz filled in after assembly
         grid = (world, 1, 1)
-        part = make_octree_parts(brick, world, axis=0)[rank]
+        part = make_octree_parts(brick, world, elem_part=bisect_elements(brick, world) if world > 1 else None)[rank]
         brick.nnz = None
-        wl_name = f"two-level octree mesh 96x96x(40 fine + 8 coarse), hanging-node transition patterns (nd=39), {brick.n_dof} dof"
+        sm = brick.summary()
+        wl_name = (f"multi-level 2:1-balanced octree mesh around a sphere, {sm['levels']} cell sizes, {sm['pattern_types']} pattern types "
+                   f"(up to {sm['nodes_per_element_max']} nodes per element), {brick.n_dof} dof, parts by recursive bisection")
     else:
         brick = Brick(N, seed=0)
         grid = default_grid(world)
@@ -409,7 +448,7 @@ def main():
         dist.all_gather_object(box, float(x))
         return max(box), box
 
-    def measure(kind):
+    def measure(kind, part=part, steps=args.steps, warmup=args.warmup, standalone_reps=100):
         """Set up the operator of `kind`, run W warm-up + K timed PCG iterations, finish the solve."""
         part.pop("_pcg_mi355x_operator", None)
         pm.configure(comm=comm, device=dev, rows_per_lane=args.rows_per_lane, operator=kind)
@@ -426,18 +465,18 @@ def main():
         gd = part["GlobData"]
         eff = np.asarray(part["LocDofEff"], np.int64)
         inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
-        extra = args.steps if world > 1 else 0       # N > 1: a second window with the communication timers on
-        max_iter = max(int(gd["MaxIter"]), args.warmup + args.steps + extra + 1)
+        extra = steps if world > 1 else 0       # N > 1: a second window with the communication timers on
+        max_iter = max(int(gd["MaxIter"]), warmup + steps + extra + 1)
         op.solve_begin(part["Fext"], np.zeros(op.n), inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
-        r = op.solve_run(args.warmup)
-        assert r.status == 4 and r.iters_done == args.warmup, "solve ended inside the warm-up window"
+        r = op.solve_run(warmup)
+        assert r.status == 4 and r.iters_done == warmup, "solve ended inside the warm-up window"
         op.set_profiling(True)                        # HIP events around every operator launch from here on
         fence()
         t0 = time.perf_counter()
-        r = op.solve_run(args.steps)                  # exactly K PCG iterations
+        r = op.solve_run(steps)                  # exactly K PCG iterations
         fence()
         elapsed_local = time.perf_counter() - t0
-        assert r.iters_done == args.warmup + args.steps and r.status == 4, \
+        assert r.iters_done == warmup + steps and r.status == 4, \
             f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
         op_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
         n_op = int(r.spmv_count)
@@ -462,13 +501,13 @@ def main():
             comm.set_timing(True)
             fence()
             t0 = time.perf_counter()
-            r2 = op.solve_run(args.steps)
+            r2 = op.solve_run(steps)
             fence()
             t_win = time.perf_counter() - t0
             comm.set_timing(False)
             s1 = comm.stats()
             if r2.status == 4:
-                k = max(1, args.steps)
+                k = max(1, steps)
                 comm_info = {"halo_wait_ms_per_iter": (s1["halo_wait_ms"] - s0["halo_wait_ms"]) / k,
                              "allreduce_ms_per_iter": (s1["allreduce_ms"] - s0["allreduce_ms"]) / k,
                              "exchanges_per_iter": (s1["n_halo"] - s0["n_halo"]) / k,
@@ -485,7 +524,7 @@ def main():
             op.solve_end()
         standalone = None
         if world == 1:
-            ms = op.bench_spmv(10, 100)
+            ms = op.bench_spmv(10, standalone_reps)
             standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
         return {"op": op, "elapsed": elapsed, "per_rank_s": per_rank, "op_ms": op_ms, "n_op": n_op, "final": final,
                 "standalone": standalone, "t_setup": t_setup, "comm": comm_info, "vec": vec}
@@ -652,6 +691,12 @@ def main():
         out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]]}
         if head["comm"]:
             out["comm"].update(head["comm"])
+    if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:
+        try:
+            out["octree"] = octree_object(measure, log)
+        except Exception as ex:          # noqa: BLE001 - the headline line must survive
+            log(f"octree object failed: {ex!r}")
+            out["octree"] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:
         log("timing the CPU baseline (oracle port: 1 core, then R processes x 1 thread) ...")
         out["cpu_baseline"] = cpu_baseline(part, N, args.cpu_ranks, args.workload)

@@ -121,12 +121,18 @@ int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const 
  * communicator below, which needs no callbacks.  All buffers are DEVICE pointers, `stream` is the
  * engine's hipStream_t.  halo_begin is called once the send buffer has been packed on `stream`;
  * halo_end must make `stream` wait until the receive buffer is complete.  allreduce sums
- * `count` doubles in place across ranks.  NULL hooks = single part. */
+ * `count` doubles in place across ranks.  NULL hooks = single part.
+ * collective_exchange: 0 = the exchange is point-to-point between neighbours (like the reference's Isend / Recv,
+ * pcg_solver.py:318-328): a part WITHOUT neighbours never sees halo_begin / halo_end.  Non-zero = halo_begin / halo_end are a
+ * group-wide collective that EVERY rank must enter (torch all_to_all_single, a barrier-based test communicator): a part
+ * without neighbours then also calls halo_begin(ctx, NULL, NULL, 0, stream) + halo_end once per operator apply / interface
+ * sum.  (Round 2 made those calls unconditionally; round 3 made them opt-in.) */
 typedef struct {
     void *ctx;
     int (*halo_begin)(void *ctx, double *dev_send, double *dev_recv, int64_t count, void *stream);
     int (*halo_end)(void *ctx, void *stream);
     int (*allreduce)(void *ctx, double *dev_buf, int32_t count, void *stream);
+    int32_t collective_exchange;
 } pcg_comm_hooks;
 int pcg_set_comm(pcg_engine *e, const pcg_comm_hooks *hooks);
 void *pcg_stream(pcg_engine *e);

@@ -11,6 +11,8 @@
 // all-reduced sums of every iteration (pcg_solver.py:507-562), so the members' loops have to advance side by side.
 // One persistent host thread per member (created here, bound to the member's device by the engine's entry points)
 // does that; the caller sees one thread and plain blocking calls.
+#include <algorithm>
+#include <cstdlib>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -143,6 +145,17 @@ int pcg_group_create(int32_t n_dev, const int32_t *dev_ids, pcg_group **out)
         for (int k = 0; k < n_dev; ++k)
             if (dev_ids[k] < 0 || (have > 0 && dev_ids[k] >= have))
                 return set_error("pcg_group_create: device id " + std::to_string(dev_ids[k]) + " out of range (" + std::to_string(have) + " visible)");
+        // RCCL refuses two ranks of one communicator on the same device ("Duplicate GPU detected"), and a member that fails
+        // inside the collective ncclCommInitRank can leave the others waiting: reject duplicates before any thread starts.
+        // Only the tests' shared-GPU stand-in for librccl (PCG_RCCL_LIB) and the CPU test double (no devices) take them.
+        if (have > 0 && !std::getenv("PCG_RCCL_LIB")) {
+            std::vector<int32_t> seen(dev_ids, dev_ids + n_dev);
+            std::sort(seen.begin(), seen.end());
+            for (int k = 1; k < n_dev; ++k)
+                if (seen[k] == seen[k - 1])
+                    return set_error("pcg_group_create: device " + std::to_string(seen[k]) + " is listed twice - one member per GPU (" +
+                                     std::to_string(n_dev) + " members, " + std::to_string(have) + " devices visible)");
+        }
         g->comm.assign(n_dev, nullptr);
         g->eng.assign(n_dev, nullptr);
         unsigned char ids[PCG_RCCL_ID_BYTES];

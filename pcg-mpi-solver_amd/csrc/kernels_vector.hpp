@@ -66,17 +66,19 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
         send[m] = y[idx[m]];
 }
 
-// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
+// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs.
+// nbn > 0: direction-major vectors (kernels_spmv.hpp SOA): boundary dof t = dir * nbn + node lives at dir * n_nodes + node.
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
                                                   const int *__restrict__ fptr, const int *__restrict__ fpos,
                                                   const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
-                                                  int64_t nb, double *__restrict__ partials)
+                                                  int64_t nb, int64_t nbn, int64_t n_nodes, double *__restrict__ partials)
 {
     double dot = 0.0;
-    for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
+    for (int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x; t < nb; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t d = nbn ? (t / nbn) * n_nodes + t % nbn : t;
         double v = y[d];
-        const int q0 = fptr[d], q1 = fptr[d + 1];
+        const int q0 = fptr[t], q1 = fptr[t + 1];
         for (int q = q0; q < q1; ++q) v += recv[fpos[q]];
         if (q1 > q0) y[d] = v;
         if constexpr (DOT)
@@ -88,6 +90,19 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
         block_sum<1>(v, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
     }
+}
+
+// node-major (3 node + dir, the C ABI's numbering) <-> direction-major (dir * n_nodes + node) copies of a whole vector:
+// only at the boundary of the engine (pcg_apply, pcg_solve_begin / _end, ...), never inside the iteration
+__global__ __launch_bounds__(kBlock) void k_to_soa(double *__restrict__ dst, const double *__restrict__ src, int64_t n_nodes)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < 3 * n_nodes; i += (int64_t)gridDim.x * kBlock)
+        dst[i] = src[3 * (i % n_nodes) + i / n_nodes];
+}
+__global__ __launch_bounds__(kBlock) void k_from_soa(double *__restrict__ dst, const double *__restrict__ src, int64_t n_nodes)
+{
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < 3 * n_nodes; i += (int64_t)gridDim.x * kBlock)
+        dst[i] = src[(i % 3) * n_nodes + i / 3];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -150,9 +165,9 @@ __device__ __forceinline__ double update_one(double alpha, double p, double q, d
 //             alpha = rho / pq and the Flag-4 tests of :492-498 (sticky stop flag: a frozen launch updates nothing)
 //   [update]  sums of p^2 w and x^2 w, r' = r - alpha q, x' = x + alpha p, z = M^-1 r', sums of r'^2 w, z r' w, #inf(z)
 //   FUSED (single part):
-//   [reduce]  the workgroups publish their five partial sums with agent-scope stores and meet at a grid barrier (XCD-sharded
-//             arrival counters, one lane polls); every workgroup then sums the partials of rho' in the same fixed order ->
-//             beta = rho' / rho (:475), workgroup 0 writes the five sums to the status block (and its host mirror)
+//   [reduce]  the workgroups publish their five partial sums with agent-scope stores and meet at a grid barrier (8 sharded
+//             arrival counters, eight lanes poll); every workgroup then sums the partials of rho' in the same fixed order ->
+//             beta = rho' / rho (:475), workgroups 0..4 write one of the five sums each to the status block (and its mirror)
 //   [p]       p' = z + beta p (:479) with z still in REGISTERS (kVecKreg x 16 B per thread): r' and M^-1 are not read
 //             again; beyond that (more than 2 * kVecKreg * threads dofs) z is recomputed from r', M^-1 - the same product.
 //   !FUSED    the partial sums go to `partials` for k_reduce (then the all-reduce, then k_update_p), multi-GPU loop.
@@ -166,7 +181,7 @@ __device__ __forceinline__ double update_one(double alpha, double p, double q, d
 constexpr int kVecBlock = 1024;
 constexpr int kVecWaves = kVecBlock / 64;
 constexpr int kVecKreg = 20;              // 10.1 M dof on 256 CUs: 19.3 chunks per thread
-constexpr int kVecSyncWords = 16 * 9;     // 8 shard counters + the top counter, 128 B apart
+constexpr int kVecSyncWords = 16 * 8;     // 8 shard counters, 128 B apart
 
 struct VecArgs {
     double *st, *mirror;
@@ -271,28 +286,33 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 #pragma unroll
             for (int k = 0; k < 5; ++k) a.partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
     } else {
-        // ---- grid barrier.  Arrivals are counted even by a frozen launch: the counters are monotonic over the launches
-        // of an engine (target = arrivals per launch x launch number), nothing is reset between launches.
+        // ---- grid barrier.  Every workgroup adds ONE non-returning agent-scope arrival to the counter of its shard (8 shards,
+        // blockIdx % 8: the arrivals of a launch spread over 8 words instead of queueing on one) after its partial sums are out;
+        // lanes 0..7 of its first wave then poll the 8 counters until each has all the arrivals of THIS launch.  The counters are
+        // monotonic over the launches of an engine (target = arrivals per launch x launch number; nothing is reset in between),
+        // so a frozen launch still counts its arrivals.
         const int G = gridDim.x, ns = G < 8 ? G : 8, shard = blockIdx.x % ns;
-        if (tid == 0) {
-            if (stop == 0.0)
+        if (tid < 64) {
+            if (tid == 0) {
+                if (stop == 0.0)
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    __hip_atomic_store(a.partials + (size_t)k * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partials are out before the arrival is counted
-            const unsigned long long members = (unsigned long long)((G - shard + ns - 1) / ns);
-            const unsigned long long old = __hip_atomic_fetch_add(a.sync + 16 * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1 == members * a.seq) __hip_atomic_fetch_add(a.sync + 16 * 8, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            double ok = 1.0;
+                    for (int k = 0; k < 5; ++k)
+                        __hip_atomic_store(a.partials + (size_t)k * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are out before the arrival is counted
+                (void)__hip_atomic_fetch_add(a.sync + 16 * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool ok = true;
             if (stop == 0.0) {
-                const unsigned long long target = (unsigned long long)ns * a.seq;
+                const unsigned long long want = tid < ns ? (unsigned long long)((G - tid + ns - 1) / ns) * a.seq : 0ull;
                 unsigned spins = 0;
-                while (__hip_atomic_load(a.sync + 16 * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                for (;;) {
+                    const unsigned long long got = tid < ns ? __hip_atomic_load(a.sync + 16 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    if (__all(got >= want)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { ok = 0.0; break; }  // seconds: a workgroup of the grid is not resident
+                    if (++spins > (1u << 22)) { ok = false; break; }   // seconds: a workgroup of the grid is not resident
                 }
             }
-            lds[5 * kVecWaves] = ok;
+            if (tid == 0) lds[5 * kVecWaves] = ok ? 1.0 : 0.0;
         }
         __syncthreads();
         const bool ok = lds[5 * kVecWaves] != 0.0;
@@ -305,9 +325,16 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
             }
             return;
         }
-        // ---- every workgroup: rho' from the G partials, same order everywhere -> same beta everywhere (:462, :475)
+        // ---- every workgroup: rho' from the G partials, same order everywhere -> same beta everywhere (:462, :475);
+        // the five sums of the status block are written by workgroups 0..4, one each (by workgroup 0 alone on a tiny grid)
         const double rho_next = reduce_fixed_256<true>(a.partials + (size_t)3 * kMaxPartials, G, nullptr, 0, lds);
-        if (blockIdx.x == 0) {
+        if (G >= 5) {
+            if (blockIdx.x < 5) {
+                const int k = blockIdx.x;
+                const double sk = k == 3 ? rho_next : reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, G, nullptr, 0, lds);
+                if (tid == 0) { a.st[ST_SQP + k] = sk; if (a.mirror) a.mirror[ST_SQP + k] = sk; }
+            }
+        } else if (blockIdx.x == 0) {
             double s[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k)

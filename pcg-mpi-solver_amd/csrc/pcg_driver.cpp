@@ -41,6 +41,7 @@ const double kEps = std::numeric_limits<double>::epsilon();   // np.finfo(float)
 struct pcg_comm {
     std::unique_ptr<Comm> impl;
     int32_t device = 0;
+    std::vector<pcg_engine *> attached;       // engines whose `comm` points at impl: detached when the communicator goes first
 };
 
 struct pcg_engine {
@@ -63,6 +64,7 @@ struct pcg_engine {
     pcg_comm_hooks hooks{};
     bool has_hooks = false;               // callbacks (the gloo / thread test seam, or torch.distributed)
     Comm *comm = nullptr;                 // native RCCL communicator (not owned; pcg_comm handle), takes precedence
+    pcg_comm *comm_handle = nullptr;      // ... its handle: either side may be destroyed first (detach())
     CommStats comm0;                      // its counters at pcg_solve_begin
     bool multi() const { return comm != nullptr || has_hooks; }
     bool jacobi_built = false;
@@ -113,8 +115,18 @@ struct pcg_engine {
         double t_total = 0.0, t_comm0 = 0.0;
     } s;
 
+    void detach_comm()
+    {
+        if (comm_handle) {
+            auto &v = comm_handle->attached;
+            v.erase(std::remove(v.begin(), v.end(), this), v.end());
+        }
+        comm_handle = nullptr;
+        comm = nullptr;
+    }
     ~pcg_engine()
     {
+        detach_comm();
         if (!be) return;
         for (double *p : {d_send, d_recv, d_st, v_b, v_r[0], v_r[1], v_p[0], v_p[1], v_p[2], v_q, v_minv, v_minv_user, v_x[0], v_x[1],
                           v_x[2], v_x[3], scr[0], scr[1], scr[2], scr[3]})
@@ -155,8 +167,12 @@ struct pcg_engine {
     }
     // A part without neighbours in a multi-part job: the native exchange is point-to-point (nothing to do, like the
     // reference's Isend/Recv loops over an empty NbrMPIdVector), but a callback communicator may implement the exchange
-    // as a group-wide collective (torch all_to_all_single) which EVERY rank has to enter.
-    bool lone_in_collective() const { return !has_halo && !comm && has_hooks && hooks.halo_begin && hooks.halo_end; }
+    // as a group-wide collective (torch all_to_all_single) which EVERY rank has to enter: pcg_comm_hooks.collective_exchange
+    // says which kind it is (0: point-to-point, a lone part makes no call at all).
+    bool lone_in_collective() const
+    {
+        return !has_halo && !comm && has_hooks && hooks.collective_exchange != 0 && hooks.halo_begin && hooks.halo_end;
+    }
     void empty_exchange()
     {
         if (!lone_in_collective()) return;
@@ -755,6 +771,7 @@ int pcg_part_interface(int32_t device, int64_t n_glob_nodes, int64_t n_elem, con
             if (elem_ptr[e + 1] < elem_ptr[e]) return set_error("pcg_part_interface: elem_ptr must be non-decreasing");
         for (int64_t k = elem_ptr[0]; k < elem_ptr[n_elem]; ++k)
             if (flat_nodes[k] < 0 || flat_nodes[k] >= n_glob_nodes) return set_error("pcg_part_interface: node id out of range");
+        if (n_elem == 0 || elem_ptr[n_elem] == elem_ptr[0]) { *n_pairs = 0; return 0; }     // nothing to launch
         *n_pairs = part_interface(device, n_glob_nodes, n_elem, elem_ptr, flat_nodes, ele_part, cap, pairs);
         return 0;
     });
@@ -794,7 +811,12 @@ int pcg_comm_create_rccl(int32_t device, int32_t rank, int32_t nranks, const voi
     });
 }
 
-void pcg_comm_destroy(pcg_comm *c) { delete c; }
+void pcg_comm_destroy(pcg_comm *c)
+{
+    if (!c) return;
+    for (pcg_engine *e : std::vector<pcg_engine *>(c->attached)) e->detach_comm();   // no engine keeps a dangling Comm*
+    delete c;
+}
 
 int pcg_comm_rank(const pcg_comm *c) { return c && c->impl ? c->impl->rank() : -1; }
 int pcg_comm_size(const pcg_comm *c) { return c && c->impl ? c->impl->size() : -1; }
@@ -802,7 +824,15 @@ int pcg_comm_size(const pcg_comm *c) { return c && c->impl ? c->impl->size() : -
 int pcg_set_comm_native(pcg_engine *e, pcg_comm *c)
 {
     if (!e) return set_error("pcg_set_comm_native: null engine");
-    e->comm = c ? c->impl.get() : nullptr;
+    if (c && e->be && c->device != e->be->device())
+        return set_error("pcg_set_comm_native: the communicator lives on device " + std::to_string(c->device) + ", the engine on device " +
+                         std::to_string(e->be->device()));
+    e->detach_comm();
+    if (c) {
+        e->comm = c->impl.get();
+        e->comm_handle = c;
+        c->attached.push_back(e);
+    }
     return 0;
 }
 
@@ -831,9 +861,9 @@ int pcg_apply(pcg_engine *e, const double *x, double *y)
 {
     return guarded("pcg_apply", e, [&]() -> int {
         double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->h2d(dx, x, sizeof(double) * e->n);
+        e->be->vec_in(dx, x, e->n);
         e->apply(dx, dy, false);
-        e->be->d2h(y, dy, sizeof(double) * e->n);
+        e->be->vec_out(y, dy, e->n);
         return 0;
     });
 }
@@ -844,7 +874,7 @@ int pcg_diag(pcg_engine *e, double *d)
         double *dd = e->scratch(0);
         e->be->copy_diag(dd);                   // :282-287 element diagonals, assembled
         e->halo_sum(dd);                        // :303-334
-        e->be->d2h(d, dd, sizeof(double) * e->n);
+        e->be->vec_out(d, dd, e->n);
         return 0;
     });
 }
@@ -857,7 +887,7 @@ int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out)
         e->halo_sum(dd);
         e->be->invert_free(e->v_minv, dd);      // :351-352
         e->jacobi_built = true;
-        if (inv_diag_out) e->be->d2h(inv_diag_out, e->v_minv, sizeof(double) * e->n);
+        if (inv_diag_out) e->be->vec_out(inv_diag_out, e->v_minv, e->n);
         return 0;
     });
 }
@@ -866,13 +896,13 @@ int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, doubl
 {
     return guarded("pcg_update_bc", e, [&]() -> int {
         double *dud = e->scratch(0), *dudi = e->scratch(1), *dfdi = e->scratch(2), *df = e->scratch(3);
-        e->be->h2d(dud, ud, sizeof(double) * e->n);
-        e->be->h2d(df, ref_load, sizeof(double) * e->n);
+        e->be->vec_in(dud, ud, e->n);
+        e->be->vec_in(df, ref_load, e->n);
         e->be->scale(dudi, delta, dud);                     // :234
         e->apply(dudi, dfdi, false);                        // :235
         e->be->axpby(df, delta, df, -1.0, dfdi);            // :236-237
-        if (fext_out) e->be->d2h(fext_out, df, sizeof(double) * e->n);
-        if (udi_out) e->be->d2h(udi_out, dudi, sizeof(double) * e->n);
+        if (fext_out) e->be->vec_out(fext_out, df, e->n);
+        if (udi_out) e->be->vec_out(udi_out, dudi, e->n);
         return 0;
     });
 }
@@ -881,8 +911,8 @@ int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out)
 {
     return guarded("pcg_dot_w", e, [&]() -> int {
         double *da = e->scratch(0), *db = e->scratch(1);
-        e->be->h2d(da, a, sizeof(double) * e->n);
-        e->be->h2d(db, b, sizeof(double) * e->n);
+        e->be->vec_in(da, a, e->n);
+        e->be->vec_in(db, b, e->n);
         e->be->dot_w(da, db);
         e->be->reduce_dotw(e->d_st + ST_SQR);
         e->allreduce(e->d_st + ST_SQR, 1);
@@ -923,13 +953,13 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         s.tol = tol;
         s.max_iter = max_iter;
         const size_t bytes = sizeof(double) * (size_t)e->n;
-        be.h2d(e->v_b, b, bytes);                                           // :377
-        if (x0) be.h2d(e->v_x[0], x0, bytes);                               // :378
+        be.vec_in(e->v_b, b, e->n);                                           // :377
+        if (x0) be.vec_in(e->v_x[0], x0, e->n);                               // :378
         else be.zero(e->v_x[0], bytes);
         be.mask_free(e->v_x[0]);                                            // :408,:411 (X_Unq is 0 on fixed dofs)
         if (inv_diag) {
             if (!e->v_minv_user) e->v_minv_user = e->vec();
-            be.h2d(e->v_minv_user, inv_diag, bytes);
+            be.vec_in(e->v_minv_user, inv_diag, e->n);
             be.mask_free(e->v_minv_user);
             s.minv = e->v_minv_user;
         } else {
@@ -1012,7 +1042,7 @@ int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res)
             s.iter += 1;                                                    // :584
             if (s.status == PCG_STATUS_RUNNING) s.status = PCG_STATUS_NORMAL;
         }
-        if (x_out) e->be->d2h(x_out, xf, sizeof(double) * (size_t)e->n);
+        if (x_out) e->be->vec_out(x_out, xf, e->n);
         e->be->sync();
         s.t_total += now_s() - t0;
         fill_result(e, res);
@@ -1038,7 +1068,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
         std::vector<double> hx((size_t)e->n);
         uint64_t sd = 0x9E3779B97F4A7C15ull;                 // random (not zero-filled) operand: DVFS-honest
         for (auto &v : hx) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5; }
-        e->be->h2d(dx, hx.data(), sizeof(double) * e->n);
+        e->be->vec_in(dx, hx.data(), e->n);
         return e->be->bench_spmv(dx, dy, warmup, reps, ms_each);
     });
 }
@@ -1103,12 +1133,12 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
         double *dpo = e->scratch(3);
-        e->be->h2d(dp, p, bytes); e->be->h2d(dr, r, bytes); e->be->h2d(dm, inv_diag, bytes);
+        e->be->vec_in(dp, p, e->n); e->be->vec_in(dr, r, e->n); e->be->vec_in(dm, inv_diag, e->n);
         double st[ST_COUNT] = {0};
         st[ST_RHO_NEXT] = beta;                               // beta = st[RHO_NEXT] / rho_prev with rho_prev = 1: exact
         e->be->h2d(e->d_st, st, sizeof(st));
         e->be->update_p(dpo, dp, dr, dm, e->d_st, 1.0, first != 0);
-        e->be->d2h(p, dpo, bytes);
+        e->be->vec_out(p, dpo, e->n);
         return 0;
     });
 }
@@ -1121,8 +1151,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         ensure_solver_buffers(e);
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2];
-        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
-        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
+        e->be->vec_in(dp, p, e->n); e->be->vec_in(dq, q, e->n); e->be->vec_in(dr, r, e->n);
+        e->be->vec_in(dm, inv_diag, e->n); e->be->vec_in(dxo, x_old, e->n);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         e->be->h2d(e->d_st, st, sizeof(st));
@@ -1130,8 +1160,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         e->be->reduce_update(e->d_st + ST_SQP);
         e->read_status();
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->d2h(r, drn, bytes);
-        e->be->d2h(x_new, dxn, bytes);
+        e->be->vec_out(r, drn, e->n);
+        e->be->vec_out(x_new, dxn, e->n);
         return 0;
     });
 }
@@ -1148,8 +1178,8 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         if (fused && !e->be->vec_fused_available()) return set_error("pcg_k_vec_iteration: the fused form is not available");
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2], *dpn = e->v_x[3];
-        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
-        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
+        e->be->vec_in(dp, p, e->n); e->be->vec_in(dq, q, e->n); e->be->vec_in(dr, r, e->n);
+        e->be->vec_in(dm, inv_diag, e->n); e->be->vec_in(dxo, x_old, e->n);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         st[ST_RHO_NEXT] = rho;
@@ -1162,9 +1192,9 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         e->read_status();
         if (e->h_st[ST_ERR] != 0) return set_error("pcg_k_vec_iteration: the grid barrier timed out");
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->d2h(r, drn, bytes);
-        e->be->d2h(x_new, dxn, bytes);
-        e->be->d2h(p_next, dpn, bytes);
+        e->be->vec_out(r, drn, e->n);
+        e->be->vec_out(x_new, dxn, e->n);
+        e->be->vec_out(p_next, dpn, e->n);
         return 0;
     });
 }
@@ -1174,12 +1204,12 @@ int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, 
     return guarded("pcg_k_residual", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *db = e->scratch(0), *da = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
-        e->be->h2d(db, b, bytes); e->be->h2d(da, ax, bytes); e->be->h2d(dm, inv_diag, bytes);
+        e->be->vec_in(db, b, e->n); e->be->vec_in(da, ax, e->n); e->be->vec_in(dm, inv_diag, e->n);
         e->be->residual(db, da, dr, dm);
         e->be->reduce_residual(e->d_st + ST_SQR);
         e->read_status();
         for (int k = 0; k < 3; ++k) sums3[k] = e->h_st[ST_SQR + k];
-        e->be->d2h(r, dr, bytes);
+        e->be->vec_out(r, dr, e->n);
         return 0;
     });
 }
@@ -1189,7 +1219,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
     return guarded("pcg_k_spmv_local", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->h2d(dx, x, bytes);
+        e->be->vec_in(dx, x, e->n);
         if (e->kind == 1) {
             if (pxy) e->be->begin_dot();
             e->ebe_dot_fused = e->be->ebe_apply(dx, dy, 0, 2, true, pxy != nullptr, 0) && pxy;
@@ -1203,7 +1233,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
             e->read_status();
             *pxy = e->h_st[ST_PQ];
         }
-        e->be->d2h(y, dy, bytes);
+        e->be->vec_out(y, dy, e->n);
         return 0;
     });
 }

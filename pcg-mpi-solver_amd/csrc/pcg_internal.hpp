@@ -194,6 +194,11 @@ public:
     virtual void h2d(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
     virtual void d2h(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
     virtual void d2d(void *dst, const void *src, size_t bytes) = 0;   // async on the stream
+    // Whole vectors of the engine (length n) between the C ABI's numbering (dof = 3 * node + dir) and the back end's own
+    // layout of a device vector (the HIP back end keeps the vectors of an assembled 3x3-block operator direction-major);
+    // host-synchronous like h2d / d2h.  Everything between them - the vector kernels - is layout-agnostic.
+    virtual void vec_in(double *dev, const double *host, int64_t n) { h2d(dev, host, sizeof(double) * (size_t)n); }
+    virtual void vec_out(double *host, const double *dev, int64_t n) { d2h(host, dev, sizeof(double) * (size_t)n); }
     virtual void zero(void *dst, size_t bytes) = 0;                   // async on the stream
     virtual void sync() = 0;
 

@@ -37,7 +37,7 @@ ALLREDUCE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p
 
 class CommHooks(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("halo_begin", HALO_BEGIN_T), ("halo_end", HALO_END_T),
-                ("allreduce", ALLREDUCE_T)]
+                ("allreduce", ALLREDUCE_T), ("collective_exchange", C.c_int32)]
 
 
 class Result(C.Structure):

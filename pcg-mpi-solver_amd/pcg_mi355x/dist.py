@@ -64,25 +64,44 @@ class RcclComm:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [cls.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(rank, world, device, box[0])
+        self = cls(rank, world, device, box[0])
+        self.group = group                          # result-file offsets / barriers of this job go over the same group
+        return self
 
     @classmethod
-    def from_file(cls, rank, world, device, path, timeout_s=120.0):
-        """Bootstrap without torch.distributed: rank 0 writes the id to `path` (atomically), the others wait for it."""
+    def from_file(cls, rank, world, device, path, timeout_s=120.0, launch_id=None, max_age_s=300.0):
+        """Bootstrap without torch.distributed: rank 0 writes the id to `path` (atomically), the others wait for it.
+        A file left behind by an EARLIER launch must not be taken for this one's: rank 0 removes it before anything else, the
+        file carries `launch_id` (any string every rank of this launch knows - the launcher's job id, MASTER_PORT, ...) and
+        the other ranks accept only a file with their own launch_id; without one they refuse files older than max_age_s."""
         import os
+        tag = (launch_id if launch_id is not None else "").encode()
         if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             uid = cls.new_unique_id()
             with open(path + ".tmp", "wb") as f:
-                f.write(uid)
+                f.write(len(tag).to_bytes(4, "little") + tag + uid)
             os.replace(path + ".tmp", path)
         else:
             t0 = time.time()
-            while not os.path.exists(path):
+            uid = None
+            while uid is None:
                 if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"no RCCL unique id at {path}")
+                    raise TimeoutError(f"no RCCL unique id of this launch at {path}")
+                try:
+                    fresh = launch_id is not None or time.time() - os.path.getmtime(path) <= max_age_s
+                    with open(path, "rb") as f:
+                        raw = f.read()
+                    n = int.from_bytes(raw[:4], "little")
+                    if fresh and raw[4:4 + n] == tag and len(raw) == 4 + n + _lib.RCCL_ID_BYTES:
+                        uid = raw[4 + n:]
+                        break
+                except OSError:
+                    pass
                 time.sleep(0.01)
-            with open(path, "rb") as f:
-                uid = f.read()
         return cls(rank, world, device, uid)
 
     @property
@@ -235,6 +254,6 @@ class TorchComm:
                 return -1
 
         hooks = _lib.CommHooks(None, _lib.HALO_BEGIN_T(halo_begin), _lib.HALO_END_T(halo_end),
-                               _lib.ALLREDUCE_T(allreduce))
+                               _lib.ALLREDUCE_T(allreduce), 1)       # all_to_all_single: every rank of the group has to enter
         hooks._keep = (halo_begin, halo_end, allreduce)      # keep the closures alive
         return hooks

@@ -14,12 +14,13 @@ the list what the reference's functions (:226-238, :346-352, :356-598) do on eve
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 
 import numpy as np
 
 from . import _lib
-from ._lib import check
+from ._lib import check, PcgError
 from .operator import from_refmeshpart
 from .solver import SolveInfo, _account
 
@@ -60,6 +61,17 @@ class _MemberComm:
         pass
 
 
+def default_devices(n_parts):
+    """Member k -> device k.  More parts than visible GPUs is an error (RCCL refuses two ranks of one communicator on one
+    device) unless the tests' shared-GPU stand-in for librccl (PCG_RCCL_LIB) or the CPU test double is in use."""
+    have = _lib.lib().pcg_device_count()
+    if have > 0 and n_parts > have and not os.environ.get("PCG_RCCL_LIB"):
+        raise PcgError(f"{n_parts} parts but only {have} GPU(s) visible: a device group needs one GPU per part "
+                       f"(use torchrun with one rank per GPU on several nodes, or fewer parts)")
+    have = max(1, have)
+    return [k % have for k in range(n_parts)]
+
+
 class DeviceGroup:
     def __init__(self, devices):
         self.devices = [int(d) for d in devices]
@@ -85,8 +97,7 @@ class DeviceGroup:
         (host assembly is multi-threaded itself), each on its member's device."""
         n = len(parts)
         if devices is None:
-            have = max(1, _lib.lib().pcg_device_count())
-            devices = [k % have for k in range(n)]
+            devices = default_devices(n)
         if sorted(int(p.get("Id", k)) for k, p in enumerate(parts)) != list(range(n)):
             raise ValueError("parts must be the complete list with Id 0..N-1 (one part per member, pcg_solver.py:91)")
         parts = sorted(parts, key=lambda p: int(p.get("Id", 0)))

@@ -147,10 +147,10 @@ def _main_group(args, n_parts):
     if os.path.exists(args.results) and os.listdir(args.results):
         from datetime import datetime
         os.rename(args.results.rstrip(os.sep), args.results.rstrip(os.sep) + "_" + datetime.now().strftime("%d%m%Y_%H%M%S"))
-    have = max(1, _lib.lib().pcg_device_count())
+    from .group import default_devices
     t_start = time.time()
     flag, relres, it, gs = run_load_steps_group(parts, os.path.join(args.results, "ResVecData") + os.sep,
-                                                [k % have for k in range(n_parts)], args.operator)
+                                                default_devices(n_parts), args.operator)
     total = time.time() - t_start
     gs.close()
     os.makedirs(os.path.join(args.results, "PlotData"), exist_ok=True)

@@ -233,3 +233,41 @@ def test_neighbours_without_comm_is_an_error(hostops):
     pm.configure(comm=None)
     with pytest.raises(pm.PcgError):
         pm.get_operator(parts[0])
+
+
+@pytest.mark.parametrize("collective", [0, 1])
+def test_lone_part_enters_the_exchange_only_when_the_hooks_are_collective(hostops, collective):
+    """pcg_comm_hooks.collective_exchange.  A part without neighbours that has hooks set (world size 1, or an island
+    part of a multi-part job) calls halo_begin(NULL, NULL, 0) / halo_end only for a communicator that implements the exchange
+    as a group-wide collective; a point-to-point communicator (the reference's Isend / Recv over an empty NbrMPIdVector,
+    pcg_solver.py:318-328) never sees a call."""
+    from pcg_mi355x import _lib
+    from pcg_mi355x._lib import check
+    _, parts = golden_cases.build_case("n9_p1")
+    P = parts[0]
+    op = pm.get_operator(P)
+    calls = {"begin": 0, "end": 0, "allreduce": 0, "bad": 0}
+
+    def hb(ctx, send, recv, count, stream):
+        calls["begin"] += 1
+        calls["bad"] += int(count != 0 or bool(send) or bool(recv))
+        return 0
+
+    def he(ctx, stream):
+        calls["end"] += 1
+        return 0
+
+    def ar(ctx, buf, count, stream):
+        calls["allreduce"] += 1
+        return 0
+    keep = (_lib.HALO_BEGIN_T(hb), _lib.HALO_END_T(he), _lib.ALLREDUCE_T(ar))
+    hooks = _lib.CommHooks(None, *keep, collective)
+    check(op._L.pcg_set_comm(op._h, hooks), "pcg_set_comm")
+    fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+    x, res, _ = op.solve(fext, None, op.build_jacobi(), 1e-7, 10000, P["GlobData"]["GlobNDofEff"])
+    check(op._L.pcg_set_comm(op._h, None), "pcg_set_comm")
+    assert (res.flag, res.iter) == (0, 118) and calls["allreduce"] > 2 * 118 and calls["bad"] == 0
+    if collective:
+        assert calls["begin"] == calls["end"] >= res.n_matvec
+    else:
+        assert calls["begin"] == calls["end"] == 0

@@ -243,7 +243,9 @@ def test_group_argument_errors(hostops):
         x = np.zeros(3)
         assert L.pcg_group_apply(g._h, (C.c_void_p * 2)(x.ctypes.data, x.ctypes.data), (C.c_void_p * 2)(x.ctypes.data, x.ctypes.data)) != 0
         assert b"member 0 has no engine" in L.pcg_last_error()
-        op = from_refmeshpart(parts[1], device=0, comm=g.comms[1])     # created on device 0, member 1 lives on device 1
+        with pytest.raises(hostops.PcgError, match="communicator lives on device 1, the engine on device 0"):
+            from_refmeshpart(parts[1], device=0, comm=g.comms[1])     # pcg_set_comm_native checks the device
+        op = from_refmeshpart(parts[1], device=0, comm=g.comms[0])     # created on device 0, member 1 lives on device 1
         try:
             with pytest.raises(hostops.PcgError, match="was created on device 0"):
                 g.attach(1, op)

@@ -110,7 +110,7 @@ class ThreadComm:
                 self.w.barrier.abort()
                 return -1
 
-        hooks = _lib.CommHooks(None, _lib.HALO_BEGIN_T(halo_begin), _lib.HALO_END_T(halo_end), _lib.ALLREDUCE_T(allreduce))
+        hooks = _lib.CommHooks(None, _lib.HALO_BEGIN_T(halo_begin), _lib.HALO_END_T(halo_end), _lib.ALLREDUCE_T(allreduce), 1)   # barrier-based: collective
         hooks._keep = (halo_begin, halo_end, allreduce)
         return hooks
 

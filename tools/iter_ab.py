@@ -14,27 +14,39 @@ kinds = sys.argv[2].split(",")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 switches = [a.split("=", 1) for a in sys.argv[4:]] or [["PCG_VEC_FUSED", "1|0"]]
 out = []
+CREATE = ("PCG_LAYOUT_SOA", "PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK")   # read when the operator is built
+create = [sw for sw in switches if sw[0] in CREATE] or [["_", "-"]]
+switches = [sw for sw in switches if sw[0] not in CREATE] or [["_", "-"]]
 for N in Ns:
     P = make_parts(Brick(N))[0]
     for kind in kinds:
-        op = from_refmeshpart(P, kind=kind)
-        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
-        inv = op.build_jacobi()
-        for var, vals in switches:
+      for cvar, cvals in create:
+        for cv in cvals.split("|"):
+          os.environ[cvar] = cv
+          op = from_refmeshpart(P, kind=kind)
+          fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+          inv = op.build_jacobi()
+          for var, vals in switches:
             for rep in range(2):
                 for v in vals.split("|"):
                     os.environ[var] = v
-                    op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
-                    op.solve_run(20)
-                    op.set_profiling(True)
-                    torch.cuda.synchronize(); t0 = time.perf_counter()
-                    r = op.solve_run(steps)
-                    torch.cuda.synchronize(); t = time.perf_counter() - t0
-                    op.set_profiling(False)
-                    op.solve_end()
-                    rec = {"N": N, "dof": op.n, "kind": kind, var: v, "rep": rep, "us_per_iter": t / steps * 1e6, "it_per_s": steps / t,
-                           "operator_us": r.spmv_ms_sum / max(1, r.spmv_count) * 1e3, "vec_us": r.vec_ms_sum / max(1, r.vec_count) * 1e3}
+                    rec = {"N": N, "dof": op.n, "kind": kind, cvar: cv, var: v, "rep": rep}
+                    for prof in (False, True):                        # un-profiled window first (events around every launch perturb it)
+                        op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
+                        op.solve_run(20)
+                        op.set_profiling(prof)
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        r = op.solve_run(steps)
+                        torch.cuda.synchronize(); t = time.perf_counter() - t0
+                        op.set_profiling(False)
+                        op.solve_end()
+                        if not prof:
+                            rec.update(us_per_iter=t / steps * 1e6, it_per_s=steps / t)
+                        else:
+                            rec.update(operator_us=r.spmv_ms_sum / max(1, r.spmv_count) * 1e3, vec_us=r.vec_ms_sum / max(1, r.vec_count) * 1e3)
+                    rec.pop("_", None)
                     out.append(rec); print(rec, file=sys.stderr, flush=True)
             os.environ.pop(var, None)
-        op.close()
+          op.close()
+        os.environ.pop(cvar, None)
 print(json.dumps(out))
