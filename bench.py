@@ -105,28 +105,41 @@ def launch_ranks(args):
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         log("launching", args.gpus, "ranks:", " ".join(cmd[1:8]), "...")
         limit = float(os.environ.get("PCG_BENCH_RANKS_TIMEOUT_S", "900"))     # a hung collective must not eat the caller's whole budget
-        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            out, _ = p.communicate(timeout=limit)
+            out, err = p.communicate(timeout=limit)
         except subprocess.TimeoutExpired:
             log(f"ranks did not finish within {limit:.0f} s - terminating the launch (process group {p.pid})")
             import signal
             os.killpg(p.pid, signal.SIGTERM)
             try:
-                out, _ = p.communicate(timeout=30)
+                out, err = p.communicate(timeout=30)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)
-                out, _ = p.communicate()
-            return subprocess.CompletedProcess(cmd, 124, out, None)
-        return subprocess.CompletedProcess(cmd, p.returncode, out, None)
+                out, err = p.communicate()
+            sys.stderr.write(err or "")
+            return subprocess.CompletedProcess(cmd, 124, out, (err or "") + f"\n[bench] ranks did not finish within {limit:.0f} s")
+        sys.stderr.write(err or "")
+        return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+    def why(err):
+        """The lines of the ranks' stderr that say what failed (RCCL / HIP / engine errors), for the JSON line."""
+        keys = ("nccl", "rccl", "pcg_", "hip", "error", "Error", "did not finish")
+        hit = [l.strip() for l in (err or "").splitlines() if any(k in l for k in keys) and "Traceback" not in l]
+        return " | ".join(hit[-6:])[-900:]
     r = run({})
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if (r.returncode != 0 or not line) and args.comm == "native" and os.environ.get("PCG_BENCH_NO_RETRY") != "1":
         # keep the scaling point measurable if the native communicator cannot come up on this node: same kernels, same
-        # RCCL, but the collectives are issued through torch.distributed callbacks; the line says which transport ran
-        log(f"native-communicator run failed (rc {r.returncode}); retrying with --comm torch")
-        r = run({"PCG_BENCH_COMM": "torch", "PCG_BENCH_NATIVE_FAILED": "1"})
+        # RCCL, but the collectives are issued through torch.distributed callbacks; the line says which transport ran AND
+        # carries what the native run reported (comm.native_error)
+        reason = why(r.stderr) or f"exit code {r.returncode}, no diagnostic on stderr"
+        log(f"native-communicator run failed (rc {r.returncode}): {reason}; retrying with --comm torch")
+        r = run({"PCG_BENCH_COMM": "torch", "PCG_BENCH_NATIVE_FAILED": "1", "PCG_BENCH_NATIVE_ERROR": reason})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:                                      # nothing ran: the driver still gets a line that says why
+        line = [json.dumps({"metric": "PCG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3D elastostatic CSR", "value": None, "n_gpus": args.gpus,
+                            "error": why(r.stderr) or f"exit code {r.returncode}", "unit": "iterations/s"})]
     if line:
         print(line[-1], flush=True)
     return r.returncode if r.returncode != 0 else (0 if line else 1)
@@ -315,11 +328,11 @@ def octree_object(measure, log):
     mesh = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0)
     opart = make_octree_parts(mesh, 1)[0]
     obj = {"workload": "multi-level 2:1-balanced octree mesh around a sphere (GradedOctreeMesh((12,12,12), levels=4, band=1.2)), Jacobi-PCG Tol 1e-7, 1 part",
-           "mesh": mesh.summary(), "mesh_setup_s": time.perf_counter() - t0, "steps": 200, "warmup": 20}
+           "mesh": mesh.summary(), "mesh_setup_s": time.perf_counter() - t0, "steps": 150, "warmup": 20}
     for kind in ("sell", "dict", "ebe"):
-        mm = measure(kind, opart, steps=200, warmup=20, standalone_reps=30)
+        mm = measure(kind, opart, steps=150, warmup=20, standalone_reps=30)
         op = mm["op"]
-        e = {"value": 200 / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / 200 * 1e3, "operator_avg_ms": mm["op_ms"],
+        e = {"value": 150 / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / 150 * 1e3, "operator_avg_ms": mm["op_ms"],
              "standalone_operator": mm["standalone"], "solve": mm["final"], "setup_s": mm["t_setup"],
              "vector_phase_ms": mm["vec"]["avg_launch_ms"] if mm["vec"] else None}
         by, fl = op.operator_cost()
@@ -336,6 +349,18 @@ def octree_object(measure, log):
         op.close()
         log(f"[octree {kind}] {e['value']:.0f} it/s, operator {e['operator_avg_ms']:.4f} ms, solve {e['solve']}")
     opart.pop("_pcg_mi355x_operator", None)
+    # The value dictionary needs <= 65535 distinct 3x3 blocks.  The random two-phase material above (Ck in {1, 3} x cell size, per
+    # element) makes 151 716 of them on this mesh - the plain format is used, `table.distinct_blocks` = 0 says so.  With ONE
+    # material (Ck = cell size) the same mesh has 22 333: the dictionary applies, its head sits in LDS, the tail goes through L2.
+    mesh1 = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0, two_phase=False)
+    upart = make_octree_parts(mesh1, 1)[0]
+    mm = measure("dict", upart, steps=150, warmup=20, standalone_reps=30)
+    obj["assembled_dictionary_single_material"] = {
+        "note": "same mesh, one material instead of the random two-phase scaling: the only variant of this mesh the dictionary format applies to",
+        "value": 150 / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / 150 * 1e3, "operator_avg_ms": mm["op_ms"],
+        "standalone_operator": mm["standalone"], "solve": mm["final"], "table": mm["op"].matrix_dictionary_info()}
+    mm["op"].close()
+    upart.pop("_pcg_mi355x_operator", None)
     return obj
 
 
@@ -465,12 +490,16 @@ def main():
         gd = part["GlobData"]
         eff = np.asarray(part["LocDofEff"], np.int64)
         inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
-        extra = steps if world > 1 else 0       # N > 1: a second window with the communication timers on
+        extra = 2 * steps                       # the instrumented window (+ N > 1: a window with the communication timers on)
         max_iter = max(int(gd["MaxIter"]), warmup + steps + extra + 1)
         op.solve_begin(part["Fext"], np.zeros(op.n), inv, float(gd["Tol"]), max_iter, int(gd["GlobNDofEff"]))
         r = op.solve_run(warmup)
         assert r.status == 4 and r.iters_done == warmup, "solve ended inside the warm-up window"
-        op.set_profiling(True)                        # HIP events around every operator launch from here on
+        # Timed window: exactly K iterations.  The headline operator (sell) carries HIP events around its operator launches INSIDE
+        # the window (the roofline's launch time is of the timed region; two event records against a 1.2 ms iteration); the
+        # short-iteration operators are timed un-instrumented and their kernels in a second window of K iterations - event
+        # records cost ~8 us per iteration, 3 % of a 0.3 ms iteration.
+        op.set_profiling(kind == "sell", what=1)
         fence()
         t0 = time.perf_counter()
         r = op.solve_run(steps)                  # exactly K PCG iterations
@@ -478,10 +507,19 @@ def main():
         elapsed_local = time.perf_counter() - t0
         assert r.iters_done == warmup + steps and r.status == 4, \
             f"solve ended inside the timed window (iters_done={r.iters_done}); use fewer steps"
-        op_ms = max(r.spmv_ms_sum / max(1, r.spmv_count), 1e-9)
-        n_op = int(r.spmv_count)
+        r1 = r
+        op.set_profiling(True, what=3)                # second window: events around operator AND vector-phase launches
+        fence()
+        r = op.solve_run(steps)
+        fence()
+        op.set_profiling(False)
+        if r.status != 4:
+            raise RuntimeError("solve ended inside the instrumented window; use fewer steps")
+        src = r1 if kind == "sell" else r
+        op_ms = max(src.spmv_ms_sum / max(1, src.spmv_count), 1e-9)
+        n_op = int(src.spmv_count)
         vec = None
-        if r.vec_count > 0:                           # the vector phase (k_vec): HIP events around its launches in the timed window
+        if r.vec_count > 0:                           # the vector phase (k_vec): HIP events around its launches (second window)
             fused = world == 1 and os.environ.get("PCG_VEC_FUSED", "1") != "0"
             vb = (73.0 if fused else 57.0) * op.n       # p, q, r, x, M^-1 in + flags + r', x' out (57 B/dof) [+ p in, p' out: 16 B/dof]
             vms = r.vec_ms_sum / r.vec_count
@@ -492,8 +530,7 @@ def main():
                                         "z = M^-1 r' stays in registers across the grid barrier" if fused else
                                         "57 B/dof: p, q, r, x, M^-1 read + 1 flag byte + r', x' written"),
                    "bound": "hbm", "achieved": vb / (vms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        op.set_profiling(False)
+                   "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, "measured_in": "a second window of K iterations with events around every launch"}
         elapsed, per_rank = gather_max(elapsed_local)
         comm_info = None
         if world > 1 and getattr(comm, "native", False):   # second window: HIP events around the exchange wait / all-reduces
@@ -531,6 +568,7 @@ def main():
 
     box = box_identity(dev) if rank == 0 else None
     stream = None
+    setup_all = None
 
     m = None
     if args.operator in ("both", "sell"):
@@ -617,6 +655,11 @@ def main():
                 comm.close()                 # ncclCommDestroy while the HIP runtime is still up, not at interpreter exit
             dist.destroy_process_group()
 
+    if world > 1:                                   # every rank's host set-up (its part + its operator), for the record
+        mine = {"rank": rank, "refmeshpart_s": round(t_parts, 2),
+                "operator_s": {k: round(v["t_setup"], 2) for k, v in (("sell", m), ("dict", dm), ("ebe", e)) if v is not None}}
+        setup_all = [None] * world
+        dist.all_gather_object(setup_all, mine)
     if rank != 0:
         shutdown()
         return
@@ -688,7 +731,10 @@ def main():
             except Exception as ex:      # noqa: BLE001
                 log(f"live PMC traffic measurement failed: {ex!r}")
     if world > 1:
-        out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]]}
+        out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]],
+                       "per_rank_setup_s": setup_all}
+        if os.environ.get("PCG_BENCH_NATIVE_ERROR"):
+            out["comm"]["native_error"] = os.environ["PCG_BENCH_NATIVE_ERROR"]
         if head["comm"]:
             out["comm"].update(head["comm"])
     if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:

@@ -225,7 +225,9 @@ int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res);
 int pcg_solve(pcg_engine *e, const double *b, const double *x0, const double *inv_diag, double tol,
               int64_t max_iter, int64_t glob_n_eff, double *x_out, double *hist, int64_t hist_cap,
               pcg_result *res);
-int pcg_set_profiling(pcg_engine *e, int32_t on);
+/* HIP events on the engine's stream around launches of a solve: bit 0 = the operator launches (pcg_result.spmv_ms_sum / spmv_count),
+ * bit 1 = the vector-phase launches (vec_ms_sum / vec_count); 0 = off.  Events cost a few microseconds per iteration. */
+int pcg_set_profiling(pcg_engine *e, int32_t what);
 int pcg_engine_device(const pcg_engine *e);      /* the device id the engine was created on */
 
 /* ---- device group: ONE process drives several GPUs (SURVEY 8b pcg_group_*) ------------------------------------------

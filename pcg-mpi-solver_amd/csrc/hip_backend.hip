@@ -38,12 +38,6 @@ class HipBackend : public Backend {
     hipStream_t st2_ = nullptr, ls_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool ebe_two_streams_ = false;
-    // Layout of the device vectors (length n_): node-major (3 node + dir, the C ABI's numbering) or, for an assembled 3x3-block
-    // operator with 64-row slices, direction-major (dir * n_nodes + node; kernels_spmv.hpp SOA): the x gathers and y stores
-    // of the SpMV are then coalesced wave accesses.  vec_in / vec_out convert at the engine's boundary; PCG_LAYOUT_SOA=0
-    // keeps node-major vectors (A/B).  The matrix-free operator and the scalar-row format use node-major vectors.
-    bool soa_ = false;
-    double *d_stage_ = nullptr;
     // matrix
     int bs_ = 3;
     int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
@@ -102,7 +96,7 @@ class HipBackend : public Backend {
     double *d_part_fix_ = nullptr;    // kMaxPartials
     int cnt_spmv_ = 0, cnt_fix_ = 0, cnt_vec_ = 0;
     // profiling
-    bool prof_ = false;
+    bool prof_ = false, prof_vec_ = false;     // HIP events around the operator launches / the vector-phase launches
     static constexpr int kMaxEv = 8192;
     std::vector<hipEvent_t> ev0_, ev1_, evv0_, evv1_;   // operator launches / vector-phase launches
     int ev_used_ = 0, evv_used_ = 0;
@@ -182,7 +176,7 @@ public:
         if (const char *e = getenv("PCG_SPMV_XCD")) xcd_aware_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_BENCH_SPMV_DOT")) bench_dot_ = atoi(e) != 0;
         if (const char *e = getenv("PCG_ALLOC_CONTIG")) alloc_contig_ = atoi(e);
-        if (const char *e = getenv("PCG_SPMV_DICT_BLOCK")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) dict_block_ = b; }
+        if (const char *e = getenv("PCG_SPMV_DICT_BLOCK")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 640 || b == 1024) dict_block_ = b; }
         reload_tuning();
     }
     ~HipBackend() override
@@ -190,7 +184,7 @@ public:
         (void)hipSetDevice(dev_);
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
-                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_stage_})
+                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_ptr4_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke, (void *)D.ke_rows})
@@ -257,8 +251,6 @@ public:
         d_diag_ = (double *)alloc(sizeof(double) * m.diag.size());
         d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
         h2d(d_slice_ptr_, m.slice_ptr.data(), sizeof(int64_t) * m.slice_ptr.size());
-        soa_ = m.bs == 3 && m.C == 64;
-        if (const char *e = getenv("PCG_LAYOUT_SOA")) soa_ = soa_ && atoi(e) != 0;
         // 16-bit column offsets when every slice's columns span < 65536 (k_spmv COL16); PCG_SPMV_COL16=0 keeps 32 bits
         bool col16 = m.bs == 3 && m.n_slices > 0;
         if (const char *e = getenv("PCG_SPMV_COL16")) col16 = col16 && atoi(e) != 0;
@@ -273,15 +265,25 @@ public:
             }
         }
         if (col16 && !m.bidx.empty()) {
-            // dictionary format: ONE 32-bit word per stored block, column offset (low half) and table index (high half)
-            std::vector<unsigned> ci(m.cols.size());
-            for (int64_t sl = 0; sl < m.n_slices; ++sl)
-                for (int64_t k = m.slice_ptr[sl] * m.C, b = m.slice_ptr[sl + 1] * m.C; k < b; ++k)
-                    ci[k] = (unsigned)(m.cols[k] - cbase[sl]) | ((unsigned)m.bidx[k] << 16);
-            d_cols16_ = (unsigned short *)alloc(sizeof(unsigned) * std::max<size_t>(1, ci.size()));
+            // dictionary format: a stored block is ONE 32-bit word (column offset | table index << 16) and a lane's words of four
+            // consecutive block columns sit together (k_spmv_dict COL16): ci[((ptr4[s] + k / 4) * 64 + lane) * 4 + k % 4]
+            std::vector<int64_t> ptr4((size_t)m.n_slices + 1, 0);
+            for (int64_t sl = 0; sl < m.n_slices; ++sl) ptr4[sl + 1] = ptr4[sl] + (m.slice_ptr[sl + 1] - m.slice_ptr[sl] + 3) / 4;
+            std::vector<unsigned> ci((size_t)ptr4.back() * 256, 0u);
+            for (int64_t sl = 0; sl < m.n_slices; ++sl) {
+                const int64_t base = m.slice_ptr[sl], w = m.slice_ptr[sl + 1] - base;
+                for (int64_t k = 0; k < w; ++k)
+                    for (int l = 0; l < 64; ++l) {
+                        const size_t q = (size_t)(base + k) * 64 + l;
+                        ci[((size_t)(ptr4[sl] + k / 4) * 64 + l) * 4 + k % 4] = (unsigned)(m.cols[q] - cbase[sl]) | ((unsigned)m.bidx[q] << 16);
+                    }
+            }
+            d_cols16_ = (unsigned short *)alloc(sizeof(unsigned) * std::max<size_t>(4, ci.size()));
             d_colbase_ = (int *)alloc(sizeof(int) * cbase.size());
+            d_ptr4_ = (int64_t *)alloc(sizeof(int64_t) * ptr4.size());
             h2d(d_cols16_, ci.data(), sizeof(unsigned) * ci.size());
             h2d(d_colbase_, cbase.data(), sizeof(int) * cbase.size());
+            h2d(d_ptr4_, ptr4.data(), sizeof(int64_t) * ptr4.size());
             dict_packed_ = true;
         } else if (col16) {
             std::vector<unsigned short> c16(m.cols.size());
@@ -317,10 +319,10 @@ public:
                 }
                 const int bytes = (int)kDictLdsBytesMax;
                 auto raise = [&](const void *fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); };
-#define PCG_RAISE2(D, C16, M) raise((const void *)k_spmv_dict<D, C16, true, 1024, M, true>); raise((const void *)k_spmv_dict<D, C16, true, 1024, M, false>)
-                PCG_RAISE2(true, true, true);   PCG_RAISE2(false, true, true);  PCG_RAISE2(true, false, true);  PCG_RAISE2(false, false, true);
-                PCG_RAISE2(true, true, false);  PCG_RAISE2(false, true, false); PCG_RAISE2(true, false, false); PCG_RAISE2(false, false, false);
-#undef PCG_RAISE2
+                raise((const void *)k_spmv_dict<true, true, true, 1024, true>);   raise((const void *)k_spmv_dict<false, true, true, 1024, true>);
+                raise((const void *)k_spmv_dict<true, false, true, 1024, true>);  raise((const void *)k_spmv_dict<false, false, true, 1024, true>);
+                raise((const void *)k_spmv_dict<true, true, true, 1024, false>);  raise((const void *)k_spmv_dict<false, true, true, 1024, false>);
+                raise((const void *)k_spmv_dict<true, false, true, 1024, false>); raise((const void *)k_spmv_dict<false, false, true, 1024, false>);
                 dict_big_ = true;
             } else if (dict_lds_) {
                 if (const char *e = getenv("PCG_SPMV_DICT_LDS_ENTRIES")) {
@@ -332,32 +334,8 @@ public:
         } else {
             h2d(d_vals_, m.vals.data(), sizeof(double) * m.vals.size());
         }
-        if (soa_) {
-            std::vector<double> dg(m.diag.size());
-            for (int64_t j = 0; j < n_nodes_; ++j)
-                for (int d = 0; d < 3; ++d) dg[(size_t)d * n_nodes_ + j] = m.diag[3 * (size_t)j + d];
-            h2d(d_diag_, dg.data(), sizeof(double) * dg.size());
-        } else {
-            h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
-        }
+        h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
-    }
-    void vec_in(double *dev, const double *host, int64_t n) override
-    {
-        if (!soa_ || n != n_) { h2d(dev, host, sizeof(double) * (size_t)n); return; }
-        if (!d_stage_) d_stage_ = (double *)alloc(sizeof(double) * (size_t)n_);
-        HIP_CHECK(hipMemcpyAsync(d_stage_, host, sizeof(double) * (size_t)n_, hipMemcpyHostToDevice, st_));
-        hipLaunchKernelGGL(k_to_soa, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, dev, d_stage_, n_nodes_);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(st_));
-    }
-    void vec_out(double *host, const double *dev, int64_t n) override
-    {
-        if (!soa_ || n != n_) { d2h(host, dev, sizeof(double) * (size_t)n); return; }
-        if (!d_stage_) d_stage_ = (double *)alloc(sizeof(double) * (size_t)n_);
-        hipLaunchKernelGGL(k_from_soa, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, d_stage_, dev, n_nodes_);
-        HIP_CHECK(hipGetLastError());
-        d2h(host, d_stage_, sizeof(double) * (size_t)n_);
     }
     void upload_ebe(const EbeHost &m) override
     {
@@ -578,14 +556,7 @@ public:
     bool ebe_can_split() const override { return ebe_ranges_[0].empty() && ebe_ranges_[1].empty(); }
     void upload_masks(const uint8_t *f, int64_t n) override
     {
-        if (soa_) {
-            std::vector<uint8_t> t((size_t)n);
-            for (int64_t j = 0; j < n_nodes_; ++j)
-                for (int d = 0; d < 3; ++d) t[(size_t)d * n_nodes_ + j] = f[3 * (size_t)j + d];
-            h2d(d_flags_, t.data(), (size_t)n);
-        } else {
-            h2d(d_flags_, f, (size_t)n);
-        }
+        h2d(d_flags_, f, (size_t)n);
         for (int ph = 0; ph < 2; ++ph) {                     // k_ebe_hex reads the dot weights from its slot table
             if (!hex_tab_[ph].tslot) continue;
             std::vector<unsigned short> t(hex_tslot_host_[ph]);
@@ -606,26 +577,15 @@ public:
         halo_count_ = (int64_t)h.send_idx.size();
         if (ebe_) nb_dofs_ = h.fix_dof.empty() ? 0 : (int64_t)h.fix_dof.back() + 1;
         d_send_idx_ = (int *)alloc(sizeof(int) * h.send_idx.size());
-        if (soa_) {                                          // interface dofs arrive node-major (3 node + dir): device addresses
-            std::vector<int> si(h.send_idx.size());
-            for (size_t k = 0; k < si.size(); ++k) si[k] = (int)((int64_t)(h.send_idx[k] % 3) * n_nodes_ + h.send_idx[k] / 3);
-            h2d(d_send_idx_, si.data(), sizeof(int) * si.size());
-        } else {
-            h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
-        }
-        // dense CSR over all boundary-slice dofs (row t; direction-major vectors: t = dir * boundary nodes + node, k_fixup)
-        const int64_t nbn = nb_dofs_ / 3;
-        auto row_of = [&](int64_t a) { return soa_ ? (a % 3) * nbn + a / 3 : a; };
+        h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
+        // dense CSR over all boundary-slice dofs
         std::vector<int> fptr((size_t)nb_dofs_ + 1, 0);
-        for (size_t k = 0; k < h.fix_dof.size(); ++k) fptr[row_of(h.fix_dof[k]) + 1] = (int)(h.fix_ptr[k + 1] - h.fix_ptr[k]);
+        for (size_t k = 0; k < h.fix_dof.size(); ++k) fptr[h.fix_dof[k] + 1] = (int)(h.fix_ptr[k + 1] - h.fix_ptr[k]);
         for (int64_t d = 0; d < nb_dofs_; ++d) fptr[d + 1] += fptr[d];
-        std::vector<int> fpos(h.fix_pos.size());
-        for (size_t k = 0; k < h.fix_dof.size(); ++k)
-            std::copy(h.fix_pos.begin() + h.fix_ptr[k], h.fix_pos.begin() + h.fix_ptr[k + 1], fpos.begin() + fptr[row_of(h.fix_dof[k])]);
         d_fptr_ = (int *)alloc(sizeof(int) * fptr.size());
         h2d(d_fptr_, fptr.data(), sizeof(int) * fptr.size());
-        d_fpos_ = (int *)alloc(sizeof(int) * std::max<size_t>(1, fpos.size()));
-        h2d(d_fpos_, fpos.data(), sizeof(int) * fpos.size());
+        d_fpos_ = (int *)alloc(sizeof(int) * std::max<size_t>(1, h.fix_pos.size()));
+        h2d(d_fpos_, h.fix_pos.data(), sizeof(int) * h.fix_pos.size());
     }
 
     template <int RPL>
@@ -656,39 +616,39 @@ public:
     bool dict_lds_ = false;
     // Workgroup size of the dictionary kernel: every workgroup holds one copy of the table (head) in LDS, so larger workgroups
     // put more waves behind one copy.  0 = automatic: 256 threads while four copies fit next to each other on a CU
-    // (tables up to ~40 KB), else 512; tables beyond kDictLdsBytes: 1024 threads, one workgroup per CU.
-    // PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 1024) for tables within kDictLdsBytes.
+    // (tables up to ~40 KB), 640 while two fit; tables beyond kDictLdsBytes: 1024 threads, one workgroup per CU.
+    // PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 640 / 1024) for tables within kDictLdsBytes.
     int dict_block_ = 0;
     static constexpr size_t kDictLdsBytesMax = 152 * 1024;   // of the CU's 160 KB (1945 entries)
     int n_lds_ = 0;                                           // entries of the LDS copy (all of them unless dict_mixed_)
     bool dict_mixed_ = false, dict_big_ = false;
-    bool dict_packed_ = false;                                // column offset + table index in one 32-bit word (16-bit columns)
+    bool dict_packed_ = false;                                // 16-bit columns: column offset + table index in one word, four words per load
+    int64_t *d_ptr4_ = nullptr;                               // ... groups of four block columns before each slice
     int64_t dict_lds_entries() const override { return n_lds_; }
     template <bool COL16>
     void launch_spmv_dict(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
         const size_t lds = dict_lds_ ? (size_t)n_lds_ * 80 : 0;            // entries padded to 80 B in LDS
         const int64_t fit = lds ? std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds + 128))) : 8;     // copies per CU (160 KB LDS)
-        int blk = dict_big_ ? 1024 : (dict_block_ ? dict_block_ : (fit >= 4 ? 256 : 512));
-        // workgroups per CU: what LDS leaves room for, and at most 16 waves per CU in flight (95 VGPRs: 5 per SIMD)
-        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(fit, (blk == 256 ? spmv_blocks_per_cu_ : 1024 / blk)));
+        // 256 threads while four or more copies fit on a CU; two or three copies: 640 threads (10 waves behind a copy, two
+        // workgroups = 20 waves per CU = the 5 per SIMD that 91-96 VGPRs allow; 512 gave 16); one copy: 1024
+        int blk = dict_big_ ? 1024 : (dict_block_ ? dict_block_ : (fit >= 4 ? 256 : (fit >= 2 ? 640 : 1024)));
+        // workgroups per CU: what LDS leaves room for, and at most 20 waves per CU in flight (<= 96 VGPRs: 5 per SIMD)
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(fit, 1280 / blk));
         const int wpb = blk / 64;
         int64_t g = std::min<int64_t>((hi - lo + wpb - 1) / wpb, std::min<int64_t>((int64_t)n_cu_ * per_cu, kMaxPartials));
         g = std::max<int64_t>(8, (g + 7) / 8 * 8);
         grid = (int)g;
 #define PCG_LAUNCH_DICT(D, L, B, M)                                                                                               \
-        do {                                                                                                                      \
-            if (soa_) hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B, M, true>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols,  \
-                                         d_colbase_, d_bidx_, d_dict_, n_lds_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_);     \
-            else hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B, M, false>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols,     \
-                                    d_colbase_, d_bidx_, d_dict_, n_lds_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_);          \
-        } while (0)
+        hipLaunchKernelGGL((k_spmv_dict<D, COL16, L, B, M>), dim3(grid), dim3(B), lds, st_, d_slice_ptr_, cols, d_colbase_, d_ptr4_, \
+                           d_bidx_, d_dict_, n_lds_, x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_)
 #define PCG_LAUNCH_DICT_B(B, M)                                                                                                   \
         do {                                                                                                                      \
             if (dot) { if (lds) PCG_LAUNCH_DICT(true, true, B, M); else PCG_LAUNCH_DICT(true, false, B, false); }                 \
             else { if (lds) PCG_LAUNCH_DICT(false, true, B, M); else PCG_LAUNCH_DICT(false, false, B, false); }                   \
         } while (0)
         if (blk == 1024) { if (dict_mixed_) PCG_LAUNCH_DICT_B(1024, true); else PCG_LAUNCH_DICT_B(1024, false); }
+        else if (blk == 640) PCG_LAUNCH_DICT_B(640, false);
         else if (blk == 512) PCG_LAUNCH_DICT_B(512, false);
         else PCG_LAUNCH_DICT_B(256, false);
 #undef PCG_LAUNCH_DICT_B
@@ -699,14 +659,12 @@ public:
     template <int RPL, bool COL16>
     void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_, x, y, d_flags_, d_part_spmv_,
-                               lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
-        };
-        if constexpr (RPL == 1) {
-            if (soa_) { if (dot) go(k_spmv<1, true, COL16, true>); else go(k_spmv<1, false, COL16, true>); return; }
-        }
-        if (dot) go(k_spmv<RPL, true, COL16, false>); else go(k_spmv<RPL, false, COL16, false>);
+        if (dot)
+            hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
+        else
+            hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
     }
     int col_index_bytes() const override { return d_cols16_ ? 2 : 4; }
     void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
@@ -735,10 +693,10 @@ public:
         int grid = (int)std::min<int64_t>((nb_dofs_ + kBlock - 1) / kBlock, 1024);
         if (with_dot)
             hipLaunchKernelGGL((k_fixup<true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, soa_ ? nb_dofs_ / 3 : (int64_t)0, n_nodes_, d_part_fix_);
+                               nb_dofs_, d_part_fix_);
         else
             hipLaunchKernelGGL((k_fixup<false>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, soa_ ? nb_dofs_ / 3 : (int64_t)0, n_nodes_, d_part_fix_);
+                               nb_dofs_, d_part_fix_);
         HIP_CHECK(hipGetLastError());
         if (with_dot) cnt_fix_ = grid;
     }
@@ -840,7 +798,7 @@ public:
             a.pb = cnt_fix_ ? d_part_fix_ : nullptr; a.count_b = cnt_fix_;
         }
         a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_;
-        const bool rec = prof_ && evv_used_ < kMaxEv;
+        const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {
             a.seq = ++vec_seq_;
@@ -903,9 +861,10 @@ public:
         hipLaunchKernelGGL(k_mask_free, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, x, d_flags_, n_);
         HIP_CHECK(hipGetLastError());
     }
-    void set_profiling(bool on) override
+    void set_profiling(int what) override
     {
-        prof_ = on;
+        const bool on = what != 0;
+        prof_ = (what & 1) != 0; prof_vec_ = (what & 2) != 0;
         if (on && ev0_.empty()) {
             ev0_.resize(kMaxEv); ev1_.resize(kMaxEv); evv0_.resize(kMaxEv); evv1_.resize(kMaxEv);
             for (int k = 0; k < kMaxEv; ++k) {

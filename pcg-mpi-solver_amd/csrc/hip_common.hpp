@@ -60,6 +60,13 @@ template <int RPL> struct VecT;
 template <> struct VecT<1> { using d = double; using i = int; };
 template <> struct VecT<2> { using d = double2; using i = int2; };
 
+// a 16-byte pair of doubles that is only 8-byte aligned: gfx950 global loads need dword alignment only, so the three
+// components of a node (24 contiguous bytes at 24 j) are one global_load_dwordx4 + one dwordx2 instead of three dwordx2 -
+// the L1 (TCP) takes 16 cycles per wave-level load instruction whatever its width (profiles/r03_pmc_*: 64 'cache accesses' per
+// four 64-lane loads), and the dictionary SpMV is bound by exactly that
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef v2d_t v2d_a8 __attribute__((aligned(8)));
+
 __device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ int ntload(const int *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ unsigned ntload(const unsigned *p) { return __builtin_nontemporal_load(p); }

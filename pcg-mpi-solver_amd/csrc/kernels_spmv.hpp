@@ -13,16 +13,7 @@ namespace pcg {
 // 74 instead of 76 bytes per stored block; chosen at upload when every slice spans fewer than 65536 block columns
 // (node numberings with a bandwidth below 32 k nodes, e.g. the 10 M-dof brick: 22 651).  Same columns, same order,
 // same arithmetic: results are bit-identical to the 32-bit form.
-// SOA: the engine's vectors are stored direction-major (component d of node j at d * n_nodes + j) instead of node-major
-// (3 j + d): the 64 lanes of a wave, whose block columns are mostly 64 consecutive nodes on a mesh, then gather x with three
-// 512-B coalesced loads (8 x 64-B L1 tag look-ups each) instead of three 24-B-strided ones (24 each), and store y the same
-// way.  Same products in the same order per row: the rows of y hold the same bits in either layout.
-template <bool SOA>
-__device__ __forceinline__ size_t vec_at(int64_t node, int64_t n_nodes) { return SOA ? (size_t)node : 3 * (size_t)node; }
-template <bool SOA>
-__device__ __forceinline__ size_t vec_step(int64_t n_nodes) { return SOA ? (size_t)n_nodes : (size_t)1; }
-
-template <int RPL, bool DOT, bool COL16, bool SOA = false>
+template <int RPL, bool DOT, bool COL16>
 __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
                                                  const int *__restrict__ colbase,
                                                  const double *__restrict__ vals, const double *__restrict__ x,
@@ -67,9 +58,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
 #pragma unroll
             for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
             if constexpr (RPL == 1) {
-                const double *xp = x + vec_at<SOA>(jv, n_nodes);
-                const size_t xs = vec_step<SOA>(n_nodes);
-                const double x0 = xp[0], x1 = xp[xs], x2 = xp[2 * xs];
+                const double *xp = x + 3 * (size_t)jv;
+                const v2d_a8 x01 = *reinterpret_cast<const v2d_a8 *>(xp);      // 24 contiguous bytes per lane: one 16-B + one 8-B load
+                const double x0 = x01.x, x1 = x01.y, x2 = xp[2];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     acc[0][a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[0][a])));
@@ -88,18 +79,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
         for (int h = 0; h < RPL; ++h) {
             const int64_t row = s * C + (int64_t)lane * RPL + h;
             if (row < n_nodes) {
-                const size_t r0 = vec_at<SOA>(row, n_nodes), rs = vec_step<SOA>(n_nodes);
-                double *yp = y + r0;
+                double *yp = y + 3 * row;
                 if (xcd_aware & 2) {
-                    __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + rs);
-                    __builtin_nontemporal_store(acc[h][2], yp + 2 * rs);
-                } else { yp[0] = acc[h][0]; yp[rs] = acc[h][1]; yp[2 * rs] = acc[h][2]; }
+                    __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
+                    __builtin_nontemporal_store(acc[h][2], yp + 2);
+                } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
                 if constexpr (DOT) {
-                    const uint8_t *fp = flags + r0;
-                    const double *xp = x + r0;
+                    const uint8_t *fp = flags + 3 * row;
+                    const double *xp = x + 3 * row;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
-                        if ((fp[a * rs] & 3) == 3) dot += xp[a * rs] * acc[h][a];
+                        if ((fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
                 }
             }
         }
@@ -122,14 +112,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
 // MIXED (with LDSD): the table is larger than LDS; its n_lds most frequent entries (the host orders the table by descending
 // frequency) are the LDS copy, a lane whose block is one of the others reads it through L1/L2 - a divergent branch that
 // costs nothing when no lane of the wave needs it.
-#ifndef PCG_DICT_UNROLL
-#define PCG_DICT_UNROLL 3     // block columns in flight per lane (tools/dict_unroll_ab.sh builds the alternatives)
-#endif
-// COL16: ONE 32-bit word per stored block - the 16-bit column offset in the low half, the table index in the high half
-// (cols_any = that array, bidx unused): one wave-level load per block column instead of two.
-template <bool DOT, bool COL16, bool LDSD, int BLK, bool MIXED = false, bool SOA = false>
+// COL16: a stored block is ONE 32-bit word - the 16-bit column offset in the low half, the table index in the high half - and
+// a lane's words of four consecutive block columns are one 16-byte load (cols_any = uint4[(ptr4[s] + k / 4) * 64 + lane]; a
+// slice's last group is padded, its padding never multiplied): 0.25 wave-level loads per block column instead of two.  Together
+// with the 16 + 8-byte x gather that is 2.25 vector-memory instructions per block column instead of 5; the L1 takes 16 cycles
+// for each whatever its width, which is what bounded this kernel (profiles/r03_pmc_spmv_dict_and_plain_before.md).
+// !COL16 (a slice spans 65536 block columns or more): 32-bit columns and 16-bit indices in two arrays, one block column at a time.
+template <bool DOT, bool COL16, bool LDSD, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
-                                                      const int *__restrict__ colbase, const unsigned short *__restrict__ bidx,
+                                                      const int *__restrict__ colbase, const int64_t *__restrict__ ptr4,
+                                                      const unsigned short *__restrict__ bidx,
                                                       const double *__restrict__ dict, int n_lds,
                                                       const double *__restrict__ x, double *__restrict__ y,
                                                       const uint8_t *__restrict__ flags, double *__restrict__ partials,
@@ -138,10 +130,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ s
     // LDS copy of the table: entries padded to 80 B (16-B aligned) so that a block is four ds_read_b128 + one ds_read_b64 -
     // 256 B/clk per CU; the 72-B layout compiles to ds_read2_b64 pairs, which run at half that rate (MI355X_MICROARCH.md, LDS)
     extern __shared__ __align__(16) double sdict[];
-    using CV = typename std::conditional<COL16, unsigned, int>::type;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int WPB = BLK / 64;                              // waves per workgroup: they share one copy of the table
-    const size_t xs = vec_step<SOA>(n_nodes);
     if constexpr (LDSD) {
         for (int i = threadIdx.x; i < 9 * n_lds; i += BLK) sdict[10 * (i / 9) + i % 9] = dict[i];
         __syncthreads();
@@ -151,22 +141,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ s
     for (int64_t s = slice_lo + (int64_t)blockIdx.x * WPB + wid; s < slice_hi; s += wstride) {
         const int64_t base = slice_ptr[s];
         const int w = (int)(slice_ptr[s + 1] - base);
-        const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
-        const unsigned short *ip = bidx + (size_t)base * 64 + lane;
-        int cb = 0;
-        if constexpr (COL16) cb = colbase[s];
         double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll PCG_DICT_UNROLL
-        for (int k = 0; k < w; ++k) {
-            int j, id;
-            if constexpr (COL16) {
-                const unsigned ci = ntload(cp + (size_t)k * 64);
-                j = (int)(ci & 0xffffu) + cb;
-                id = (int)(ci >> 16);
-            } else {
-                j = ntload(cp + (size_t)k * 64);
-                id = ntload(ip + (size_t)k * 64);
-            }
+        auto block = [&](int j, int id) {                      // acc += table[id] . x[3 j .. 3 j + 2], the lanes of k_spmv in its order
             double v[9];
             if (LDSD && (!MIXED || id < n_lds)) {
                 const double2 *e2 = reinterpret_cast<const double2 *>(sdict + 10 * id);
@@ -178,22 +154,47 @@ __global__ __launch_bounds__(BLK) void k_spmv_dict(const int64_t *__restrict__ s
 #pragma unroll
                 for (int c = 0; c < 9; ++c) v[c] = b[c];
             }
-            const double *xp = x + vec_at<SOA>(j, n_nodes);
-            const double x0 = xp[0], x1 = xp[xs], x2 = xp[2 * xs];
+            const double *xp = x + 3 * (size_t)j;
+            const v2d_a8 x01 = *reinterpret_cast<const v2d_a8 *>(xp);
+            const double x0 = x01.x, x1 = x01.y, x2 = xp[2];
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+        };
+        if constexpr (COL16) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const int cb = colbase[s];
+            const u4 *cp = reinterpret_cast<const u4 *>(cols_any) + (size_t)ptr4[s] * 64 + lane;
+            const int nfull = w >> 2, rem = w & 3;
+#pragma unroll 1
+            for (int k4 = 0; k4 < nfull; ++k4) {
+                const u4 c = __builtin_nontemporal_load(cp + (size_t)k4 * 64);
+                block((int)(c.x & 0xffffu) + cb, (int)(c.x >> 16));
+                block((int)(c.y & 0xffffu) + cb, (int)(c.y >> 16));
+                block((int)(c.z & 0xffffu) + cb, (int)(c.z >> 16));
+                block((int)(c.w & 0xffffu) + cb, (int)(c.w >> 16));
+            }
+            if (rem) {                                         // wave-uniform
+                const u4 c = __builtin_nontemporal_load(cp + (size_t)nfull * 64);
+                block((int)(c.x & 0xffffu) + cb, (int)(c.x >> 16));
+                if (rem > 1) block((int)(c.y & 0xffffu) + cb, (int)(c.y >> 16));
+                if (rem > 2) block((int)(c.z & 0xffffu) + cb, (int)(c.z >> 16));
+            }
+        } else {
+            const int *cp = reinterpret_cast<const int *>(cols_any) + (size_t)base * 64 + lane;
+            const unsigned short *ip = bidx + (size_t)base * 64 + lane;
+#pragma unroll 3
+            for (int k = 0; k < w; ++k) block(ntload(cp + (size_t)k * 64), ntload(ip + (size_t)k * 64));
         }
         const int64_t row = s * 64 + lane;
         if (row < n_nodes) {
-            const size_t r0 = vec_at<SOA>(row, n_nodes);
-            double *yp = y + r0;
-            yp[0] = acc[0]; yp[xs] = acc[1]; yp[2 * xs] = acc[2];
+            double *yp = y + 3 * row;
+            yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
             if constexpr (DOT) {
-                const uint8_t *fp = flags + r0;
-                const double *xr = x + r0;
+                const uint8_t *fp = flags + 3 * row;
+                const double *xr = x + 3 * row;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    if ((fp[a * xs] & 3) == 3) dot += xr[a * xs] * acc[a];
+                    if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
             }
         }
     }

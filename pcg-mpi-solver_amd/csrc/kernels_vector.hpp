@@ -66,19 +66,17 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
         send[m] = y[idx[m]];
 }
 
-// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs.
-// nbn > 0: direction-major vectors (kernels_spmv.hpp SOA): boundary dof t = dir * nbn + node lives at dir * n_nodes + node.
+// y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
                                                   const int *__restrict__ fptr, const int *__restrict__ fpos,
                                                   const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
-                                                  int64_t nb, int64_t nbn, int64_t n_nodes, double *__restrict__ partials)
+                                                  int64_t nb, double *__restrict__ partials)
 {
     double dot = 0.0;
-    for (int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x; t < nb; t += (int64_t)gridDim.x * kBlock) {
-        const int64_t d = nbn ? (t / nbn) * n_nodes + t % nbn : t;
+    for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
         double v = y[d];
-        const int q0 = fptr[t], q1 = fptr[t + 1];
+        const int q0 = fptr[d], q1 = fptr[d + 1];
         for (int q = q0; q < q1; ++q) v += recv[fpos[q]];
         if (q1 > q0) y[d] = v;
         if constexpr (DOT)
@@ -90,19 +88,6 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
         block_sum<1>(v, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
     }
-}
-
-// node-major (3 node + dir, the C ABI's numbering) <-> direction-major (dir * n_nodes + node) copies of a whole vector:
-// only at the boundary of the engine (pcg_apply, pcg_solve_begin / _end, ...), never inside the iteration
-__global__ __launch_bounds__(kBlock) void k_to_soa(double *__restrict__ dst, const double *__restrict__ src, int64_t n_nodes)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < 3 * n_nodes; i += (int64_t)gridDim.x * kBlock)
-        dst[i] = src[3 * (i % n_nodes) + i / n_nodes];
-}
-__global__ __launch_bounds__(kBlock) void k_from_soa(double *__restrict__ dst, const double *__restrict__ src, int64_t n_nodes)
-{
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < 3 * n_nodes; i += (int64_t)gridDim.x * kBlock)
-        dst[i] = src[(i % 3) * n_nodes + i / 3];
 }
 
 // ------------------------------------------------------------------------------------------------

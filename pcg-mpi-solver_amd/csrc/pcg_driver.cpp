@@ -861,9 +861,9 @@ int pcg_apply(pcg_engine *e, const double *x, double *y)
 {
     return guarded("pcg_apply", e, [&]() -> int {
         double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->vec_in(dx, x, e->n);
+        e->be->h2d(dx, x, sizeof(double) * (size_t)e->n);
         e->apply(dx, dy, false);
-        e->be->vec_out(y, dy, e->n);
+        e->be->d2h(y, dy, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -874,7 +874,7 @@ int pcg_diag(pcg_engine *e, double *d)
         double *dd = e->scratch(0);
         e->be->copy_diag(dd);                   // :282-287 element diagonals, assembled
         e->halo_sum(dd);                        // :303-334
-        e->be->vec_out(d, dd, e->n);
+        e->be->d2h(d, dd, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -887,7 +887,7 @@ int pcg_build_jacobi(pcg_engine *e, double *inv_diag_out)
         e->halo_sum(dd);
         e->be->invert_free(e->v_minv, dd);      // :351-352
         e->jacobi_built = true;
-        if (inv_diag_out) e->be->vec_out(inv_diag_out, e->v_minv, e->n);
+        if (inv_diag_out) e->be->d2h(inv_diag_out, e->v_minv, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -896,13 +896,13 @@ int pcg_update_bc(pcg_engine *e, const double *ref_load, const double *ud, doubl
 {
     return guarded("pcg_update_bc", e, [&]() -> int {
         double *dud = e->scratch(0), *dudi = e->scratch(1), *dfdi = e->scratch(2), *df = e->scratch(3);
-        e->be->vec_in(dud, ud, e->n);
-        e->be->vec_in(df, ref_load, e->n);
+        e->be->h2d(dud, ud, sizeof(double) * (size_t)e->n);
+        e->be->h2d(df, ref_load, sizeof(double) * (size_t)e->n);
         e->be->scale(dudi, delta, dud);                     // :234
         e->apply(dudi, dfdi, false);                        // :235
         e->be->axpby(df, delta, df, -1.0, dfdi);            // :236-237
-        if (fext_out) e->be->vec_out(fext_out, df, e->n);
-        if (udi_out) e->be->vec_out(udi_out, dudi, e->n);
+        if (fext_out) e->be->d2h(fext_out, df, sizeof(double) * (size_t)e->n);
+        if (udi_out) e->be->d2h(udi_out, dudi, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -911,8 +911,8 @@ int pcg_dot_w(pcg_engine *e, const double *a, const double *b, double *out)
 {
     return guarded("pcg_dot_w", e, [&]() -> int {
         double *da = e->scratch(0), *db = e->scratch(1);
-        e->be->vec_in(da, a, e->n);
-        e->be->vec_in(db, b, e->n);
+        e->be->h2d(da, a, sizeof(double) * (size_t)e->n);
+        e->be->h2d(db, b, sizeof(double) * (size_t)e->n);
         e->be->dot_w(da, db);
         e->be->reduce_dotw(e->d_st + ST_SQR);
         e->allreduce(e->d_st + ST_SQR, 1);
@@ -926,7 +926,7 @@ int pcg_set_profiling(pcg_engine *e, int32_t on)
 {
     return guarded("pcg_set_profiling", e, [&]() -> int {
         e->profiling = on != 0;
-        e->be->set_profiling(on != 0);
+        e->be->set_profiling(on);
         return 0;
     });
 }
@@ -953,13 +953,13 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         s.tol = tol;
         s.max_iter = max_iter;
         const size_t bytes = sizeof(double) * (size_t)e->n;
-        be.vec_in(e->v_b, b, e->n);                                           // :377
-        if (x0) be.vec_in(e->v_x[0], x0, e->n);                               // :378
+        be.h2d(e->v_b, b, sizeof(double) * (size_t)e->n);                                           // :377
+        if (x0) be.h2d(e->v_x[0], x0, sizeof(double) * (size_t)e->n);                               // :378
         else be.zero(e->v_x[0], bytes);
         be.mask_free(e->v_x[0]);                                            // :408,:411 (X_Unq is 0 on fixed dofs)
         if (inv_diag) {
             if (!e->v_minv_user) e->v_minv_user = e->vec();
-            be.vec_in(e->v_minv_user, inv_diag, e->n);
+            be.h2d(e->v_minv_user, inv_diag, sizeof(double) * (size_t)e->n);
             be.mask_free(e->v_minv_user);
             s.minv = e->v_minv_user;
         } else {
@@ -1042,7 +1042,7 @@ int pcg_solve_end(pcg_engine *e, double *x_out, pcg_result *res)
             s.iter += 1;                                                    // :584
             if (s.status == PCG_STATUS_RUNNING) s.status = PCG_STATUS_NORMAL;
         }
-        if (x_out) e->be->vec_out(x_out, xf, e->n);
+        if (x_out) e->be->d2h(x_out, xf, sizeof(double) * (size_t)e->n);
         e->be->sync();
         s.t_total += now_s() - t0;
         fill_result(e, res);
@@ -1068,7 +1068,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
         std::vector<double> hx((size_t)e->n);
         uint64_t sd = 0x9E3779B97F4A7C15ull;                 // random (not zero-filled) operand: DVFS-honest
         for (auto &v : hx) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5; }
-        e->be->vec_in(dx, hx.data(), e->n);
+        e->be->h2d(dx, hx.data(), sizeof(double) * (size_t)e->n);
         return e->be->bench_spmv(dx, dy, warmup, reps, ms_each);
     });
 }
@@ -1133,12 +1133,12 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
         double *dpo = e->scratch(3);
-        e->be->vec_in(dp, p, e->n); e->be->vec_in(dr, r, e->n); e->be->vec_in(dm, inv_diag, e->n);
+        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n); e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n);
         double st[ST_COUNT] = {0};
         st[ST_RHO_NEXT] = beta;                               // beta = st[RHO_NEXT] / rho_prev with rho_prev = 1: exact
         e->be->h2d(e->d_st, st, sizeof(st));
         e->be->update_p(dpo, dp, dr, dm, e->d_st, 1.0, first != 0);
-        e->be->vec_out(p, dpo, e->n);
+        e->be->d2h(p, dpo, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -1151,8 +1151,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         ensure_solver_buffers(e);
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2];
-        e->be->vec_in(dp, p, e->n); e->be->vec_in(dq, q, e->n); e->be->vec_in(dr, r, e->n);
-        e->be->vec_in(dm, inv_diag, e->n); e->be->vec_in(dxo, x_old, e->n);
+        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dq, q, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n); e->be->h2d(dxo, x_old, sizeof(double) * (size_t)e->n);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         e->be->h2d(e->d_st, st, sizeof(st));
@@ -1160,8 +1160,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         e->be->reduce_update(e->d_st + ST_SQP);
         e->read_status();
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->vec_out(r, drn, e->n);
-        e->be->vec_out(x_new, dxn, e->n);
+        e->be->d2h(r, drn, sizeof(double) * (size_t)e->n);
+        e->be->d2h(x_new, dxn, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -1178,8 +1178,8 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         if (fused && !e->be->vec_fused_available()) return set_error("pcg_k_vec_iteration: the fused form is not available");
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2], *dpn = e->v_x[3];
-        e->be->vec_in(dp, p, e->n); e->be->vec_in(dq, q, e->n); e->be->vec_in(dr, r, e->n);
-        e->be->vec_in(dm, inv_diag, e->n); e->be->vec_in(dxo, x_old, e->n);
+        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dq, q, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n); e->be->h2d(dxo, x_old, sizeof(double) * (size_t)e->n);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         st[ST_RHO_NEXT] = rho;
@@ -1192,9 +1192,9 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         e->read_status();
         if (e->h_st[ST_ERR] != 0) return set_error("pcg_k_vec_iteration: the grid barrier timed out");
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->vec_out(r, drn, e->n);
-        e->be->vec_out(x_new, dxn, e->n);
-        e->be->vec_out(p_next, dpn, e->n);
+        e->be->d2h(r, drn, sizeof(double) * (size_t)e->n);
+        e->be->d2h(x_new, dxn, sizeof(double) * (size_t)e->n);
+        e->be->d2h(p_next, dpn, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -1204,12 +1204,12 @@ int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, 
     return guarded("pcg_k_residual", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *db = e->scratch(0), *da = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
-        e->be->vec_in(db, b, e->n); e->be->vec_in(da, ax, e->n); e->be->vec_in(dm, inv_diag, e->n);
+        e->be->h2d(db, b, sizeof(double) * (size_t)e->n); e->be->h2d(da, ax, sizeof(double) * (size_t)e->n); e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n);
         e->be->residual(db, da, dr, dm);
         e->be->reduce_residual(e->d_st + ST_SQR);
         e->read_status();
         for (int k = 0; k < 3; ++k) sums3[k] = e->h_st[ST_SQR + k];
-        e->be->vec_out(r, dr, e->n);
+        e->be->d2h(r, dr, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }
@@ -1219,7 +1219,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
     return guarded("pcg_k_spmv_local", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->vec_in(dx, x, e->n);
+        e->be->h2d(dx, x, sizeof(double) * (size_t)e->n);
         if (e->kind == 1) {
             if (pxy) e->be->begin_dot();
             e->ebe_dot_fused = e->be->ebe_apply(dx, dy, 0, 2, true, pxy != nullptr, 0) && pxy;
@@ -1233,7 +1233,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
             e->read_status();
             *pxy = e->h_st[ST_PQ];
         }
-        e->be->vec_out(y, dy, e->n);
+        e->be->d2h(y, dy, sizeof(double) * (size_t)e->n);
         return 0;
     });
 }

@@ -194,11 +194,6 @@ public:
     virtual void h2d(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
     virtual void d2h(void *dst, const void *src, size_t bytes) = 0;   // ordered on the stream, host-synchronous
     virtual void d2d(void *dst, const void *src, size_t bytes) = 0;   // async on the stream
-    // Whole vectors of the engine (length n) between the C ABI's numbering (dof = 3 * node + dir) and the back end's own
-    // layout of a device vector (the HIP back end keeps the vectors of an assembled 3x3-block operator direction-major);
-    // host-synchronous like h2d / d2h.  Everything between them - the vector kernels - is layout-agnostic.
-    virtual void vec_in(double *dev, const double *host, int64_t n) { h2d(dev, host, sizeof(double) * (size_t)n); }
-    virtual void vec_out(double *host, const double *dev, int64_t n) { d2h(host, dev, sizeof(double) * (size_t)n); }
     virtual void zero(void *dst, size_t bytes) = 0;                   // async on the stream
     virtual void sync() = 0;
 
@@ -269,7 +264,7 @@ public:
     virtual void scale(double *out, double a, const double *x) = 0;
     virtual void mask_free(double *x) = 0;                                // zero the fixed dofs
     // profiling of the SpMV launches with events on the stream
-    virtual void set_profiling(bool on) = 0;
+    virtual void set_profiling(int what) = 0;              // bit 0: events around the operator launches, bit 1: around vec_update
     virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
     virtual void collect_profile_vec(double *ms_sum, int64_t *count) { *ms_sum = 0; *count = 0; }   // the vec_update launches
     virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;

@@ -99,6 +99,19 @@ class Brick:
         off = np.array([dx + N * dy + N * N * dz for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)], np.int64)
         return base[:, None] + off[None, :]
 
+    def node_elem_parts(self, node_ids: np.ndarray, elem_part: np.ndarray) -> np.ndarray:
+        """(len(node_ids), 8) part ids of the up to eight elements around each node (-1 where the lattice ends): what a rank
+        needs to find its neighbours from ITS OWN nodes only, without building any other part's node set."""
+        n = np.asarray(node_ids, np.int64)
+        N, n1 = self.N, self.Ne1
+        i, j, k = n % N, (n // N) % N, n // (N * N)
+        out = np.full((len(n), 8), -1, np.int32)
+        for a in range(8):
+            ei, ej, ek = i - (a & 1), j - ((a >> 1) & 1), k - ((a >> 2) & 1)
+            ok = (ei >= 0) & (ei < n1) & (ej >= 0) & (ej < n1) & (ek >= 0) & (ek < n1)
+            out[ok, a] = elem_part[((ek[ok] * n1) + ej[ok]) * n1 + ei[ok]]
+        return out
+
     def load_vector(self) -> np.ndarray:
         F = np.zeros(self.n_dof)
         N = self.N
@@ -166,12 +179,6 @@ def make_parts(brick: Brick, elem_part: np.ndarray | None = None, tol: float = 1
     F = brick.load_vector()
     fixed = np.zeros(brick.n_dof, bool)
     fixed[brick.fixed_dofs()] = True
-    node_mask = []
-    if n_parts > 1:
-        for pid in range(n_parts):
-            m = np.zeros(brick.n_node, bool)
-            m[brick.elem_nodes(np.flatnonzero(elem_part == pid)).ravel()] = True
-            node_mask.append(m)
     parts = []
     for pid in only:
         eids = np.flatnonzero(elem_part == pid)                      # ascending element ids
@@ -229,18 +236,20 @@ def make_parts(brick: Brick, elem_part: np.ndarray | None = None, tol: float = 1
         parts.append(part)
     # neighbours, overlap lists, ownership weights (partition_mesh.py:817-887); candidate order is
     # ascending part id (identify_PotentialNeighbours loops `for MP_Id_j in range(N_TotalMeshPart)`)
+    # Every part finds its neighbours from ITS OWN nodes: the parts of the (up to eight) elements around each of them
+    # (a rank of a multi-GPU job builds one part; no other part's node set is ever formed).
     ref_dir = np.arange(3)[:, None]
     for p in parts:
-        for qid in range(n_parts):
-            if qid == p["Id"] or n_parts == 1:
+        adj = brick.node_elem_parts(p["NodeIdVector"], elem_part) if n_parts > 1 else None
+        for qid in (np.unique(adj) if n_parts > 1 else []):
+            if qid == p["Id"] or qid < 0:
                 continue
-            ov = np.flatnonzero(node_mask[p["Id"]] & node_mask[qid])             # = intersect1d (:822), ascending
-            if len(ov) == 0:
+            loc = np.flatnonzero((adj == qid).any(axis=1))                        # = intersect1d (:822) of the two node sets, ascending
+            if len(loc) == 0:
                 continue
-            loc = np.searchsorted(p["NodeIdVector"], ov)
             p["OvrlpLocalNodeIdVecList"].append(loc)
             p["OvrlpLocalDofVecList"].append((3 * loc + ref_dir).T.ravel())      # :826 node-major
-            p["NbrMPIdVector"].append(qid)
+            p["NbrMPIdVector"].append(int(qid))
             if p["Id"] > qid:                                                     # :885-887
                 p["DofWeightVector"][p["OvrlpLocalDofVecList"][-1]] = 0
                 p["NodeWeightVector"][loc] = 0

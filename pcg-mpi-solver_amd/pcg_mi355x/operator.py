@@ -297,8 +297,9 @@ class Operator:
             hist = hist[:max(0, min(int(res.iters_done), int(max_iter)))]
         return x, res, hist
 
-    def set_profiling(self, on=True):
-        check(self._L.pcg_set_profiling(self._h, 1 if on else 0), "pcg_set_profiling")
+    def set_profiling(self, on=True, what=3):
+        """HIP events around the operator launches (what & 1) and the vector-phase launches (what & 2) of the solve windows."""
+        check(self._L.pcg_set_profiling(self._h, int(what) if on else 0), "pcg_set_profiling")
 
     def bench_spmv(self, warmup=10, reps=100):
         ms = np.zeros(reps, np.float32)

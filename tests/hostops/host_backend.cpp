@@ -281,7 +281,7 @@ public:
     }
     void scale(double *o, double a, const double *x) override { for (int64_t i = 0; i < n_; ++i) o[i] = a * x[i]; }
     void mask_free(double *x) override { for (int64_t i = 0; i < n_; ++i) if (!is_free(i)) x[i] = 0.0; }
-    void set_profiling(bool) override {}
+    void set_profiling(int) override {}
     void collect_profile(double *ms, int64_t *c) override { *ms = 0; *c = 0; }
     int bench_hbm(size_t, int, int reps, float *ms) override { for (int k = 0; k < reps; ++k) ms[k] = 0.f; return 0; }
     int bench_spmv(const double *x, double *y, int, int reps, float *ms) override

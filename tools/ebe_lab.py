@@ -13,18 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
 import numpy as np
 from pcg_mi355x import _lib
-if os.environ.get("PCG_LAB_LIB"):            # an ablation build of the engine (tools/ebe_ablation.sh): results are WRONG by design
+if os.environ.get("PCG_LAB_LIB"):            # another build of the engine (development)
     _lib.use_library(os.environ["PCG_LAB_LIB"])
 ABLATION = bool(os.environ.get("PCG_LAB_LIB"))
 from pcg_mi355x.brick import Brick, make_parts
 from pcg_mi355x.operator import from_refmeshpart
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 150
-DEFAULT = ["chunk_512:PCG_EBE_HEX=0,PCG_EBE_EPT=2", "chunk_256:PCG_EBE_HEX=0,PCG_EBE_EPT=1",
-           "hexs_512_two_pass_atomic:PCG_EBE_HEX=1,PCG_EBE_EPT=2,PCG_EBE_ACC=1", "hexs_512_two_pass_rmw:PCG_EBE_HEX=1,PCG_EBE_EPT=2,PCG_EBE_ACC=0",
-           "hex_256_atomic:PCG_EBE_HEX=1,PCG_EBE_EPT=1,PCG_EBE_ACC=1", "hex_256_rmw:PCG_EBE_HEX=1,PCG_EBE_EPT=1,PCG_EBE_ACC=0"]
+# (round 3: the round-1 kernel, the read-add-write accumulation and the matrix-core variant were removed from the library; what is
+#  still selectable is the chunk size of the hex8 class)
+DEFAULT = ["hexs_512_two_pass:PCG_EBE_EPT=2", "hex_256:PCG_EBE_EPT=1"]
 configs = [a for a in sys.argv[1:] if ":" in a] or DEFAULT
-KNOBS = ("PCG_EBE_HEX", "PCG_EBE_EPT", "PCG_EBE_MFMA", "PCG_BENCH_SPMV_DOT", "PCG_EBE_PERSIST", "PCG_EBE_ACC")
+KNOBS = ("PCG_EBE_EPT", "PCG_BENCH_SPMV_DOT")
 
 b = Brick(N)
 P = make_parts(b)[0]
