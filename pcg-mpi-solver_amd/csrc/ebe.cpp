@@ -4,6 +4,7 @@
 //   * every other pattern type -> greedy element colouring, one conflict-free launch per colour;
 //   * local diag(A) in the reference's own accumulation order (pcg_solver.py:282-300).
 // Everything is deterministic: orders depend only on the input tables.
+#include <cstdlib>
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -390,6 +391,22 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 close_chunk(g, o, sc, lids, nsub, bnd);
                 return true;
             };
+            // Pattern types with hanging nodes (64-element chunks, one element per lane of k_ebe_rows) are sparse: on a graded
+            // octree mesh a type's elements lie scattered along the transition shells, and Morton cells of <= 64 elements are
+            // mostly far from full (round 3: 2 222 chunks for 265 k elements at 1 M dof).  They are packed GREEDILY instead:
+            // runs of up to 64 consecutive elements of the type's Morton order, shortened only where the tile would exceed its
+            // node or sub-colour limits.  The hex8 class keeps the cell recursion (full boxes = regular LDS tiles).
+            const char *gev = std::getenv("PCG_EBE_GREEDY_CHUNKS");                      // =0: Morton cells for every class (A/B)
+            if (!C.cls[cls_of[g]].full && coords && !(gev && gev[0] == '0')) {
+                size_t lo_ = 0;
+                while (lo_ < L.size()) {
+                    size_t len = std::min(chunk_elems, L.size() - lo_);
+                    while (len > 1 && !try_emit(lo_, lo_ + len)) len = len > 8 ? len * 3 / 4 : len - 1;
+                    if (len == 1 && !try_emit(lo_, lo_ + 1)) throw std::runtime_error("ebe: an element does not fit a chunk of its class");
+                    lo_ += len;
+                }
+                continue;
+            }
             // explicit stack: (lo, hi, bit)
             struct Cell { size_t lo, hi; int bit; };
             std::vector<Cell> stack;

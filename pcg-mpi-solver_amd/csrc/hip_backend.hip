@@ -616,7 +616,7 @@ public:
     bool dict_lds_ = false;
     // Workgroup size of the dictionary kernel: every workgroup holds one copy of the table (head) in LDS, so larger workgroups
     // put more waves behind one copy.  0 = automatic: 256 threads while four copies fit next to each other on a CU
-    // (tables up to ~40 KB), 640 while two fit; tables beyond kDictLdsBytes: 1024 threads, one workgroup per CU.
+    // (tables up to ~40 KB), else 512; tables beyond kDictLdsBytes: 1024 threads, one workgroup per CU.
     // PCG_SPMV_DICT_BLOCK overrides (256 / 512 / 640 / 1024) for tables within kDictLdsBytes.
     int dict_block_ = 0;
     static constexpr size_t kDictLdsBytesMax = 152 * 1024;   // of the CU's 160 KB (1945 entries)
@@ -630,9 +630,10 @@ public:
     {
         const size_t lds = dict_lds_ ? (size_t)n_lds_ * 80 : 0;            // entries padded to 80 B in LDS
         const int64_t fit = lds ? std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds + 128))) : 8;     // copies per CU (160 KB LDS)
-        // 256 threads while four or more copies fit on a CU; two or three copies: 640 threads (10 waves behind a copy, two
-        // workgroups = 20 waves per CU = the 5 per SIMD that 91-96 VGPRs allow; 512 gave 16); one copy: 1024
-        int blk = dict_big_ ? 1024 : (dict_block_ ? dict_block_ : (fit >= 4 ? 256 : (fit >= 2 ? 640 : 1024)));
+        // 256 threads while four or more copies fit on a CU, else 512 (two workgroups = 16 waves per CU).  640 threads (two
+        // workgroups = 20 waves = the 5 per SIMD that 91 VGPRs allow) measured SLOWER at 10 M dof: 242 vs 188 us in the loop
+        // (profiles/r03_dict_block_640_vs_512.log) - selectable with PCG_SPMV_DICT_BLOCK=640, not the default.
+        int blk = dict_big_ ? 1024 : (dict_block_ ? dict_block_ : (fit >= 4 ? 256 : 512));
         // workgroups per CU: what LDS leaves room for, and at most 20 waves per CU in flight (<= 96 VGPRs: 5 per SIMD)
         const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(fit, 1280 / blk));
         const int wpb = blk / 64;
