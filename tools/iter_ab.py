@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-iteration time of the PCG loop, same process / same operator A/B over environment switches the engine re-reads at
 solve_begin (PCG_VEC_FUSED, PCG_VEC_NT, PCG_VEC_KREG, PCG_LOOK_AHEAD is read at creation).
-usage: python tools/iter_ab.py N[,N..] kind[,kind..] [steps] [VAR=a|b ...]      e.g.  iter_ab.py 75,150 ebe,dict 200 PCG_VEC_FUSED=1|0"""
+usage: python tools/iter_ab.py N[,N..] kind[,kind..] [steps] [VAR=a|b ...]      e.g.  iter_ab.py 75,150 ebe,dict 200 PCG_VEC_FUSED=1|0
+N = nodes per side of the brick, or oct1m / oct10m = the graded octree mesh."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -9,16 +10,20 @@ import numpy as np
 import torch
 from pcg_mi355x.brick import Brick, make_parts
 from pcg_mi355x.operator import from_refmeshpart
-Ns = [int(a) for a in sys.argv[1].split(",")]
+Ns = [a if a.startswith("oct") else int(a) for a in sys.argv[1].split(",")]      # brick nodes per side, or oct1m / oct10m
 kinds = sys.argv[2].split(",")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 switches = [a.split("=", 1) for a in sys.argv[4:]] or [["PCG_VEC_FUSED", "1|0"]]
 out = []
-CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT")   # read when the operator is built
+CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT", "PCG_EBE_GREEDY_CHUNKS")   # read when the operator is built
 create = [sw for sw in switches if sw[0] in CREATE] or [["_", "-"]]
 switches = [sw for sw in switches if sw[0] not in CREATE] or [["_", "-"]]
 for N in Ns:
-    P = make_parts(Brick(N))[0]
+    if isinstance(N, str):                       # the multi-level graded octree mesh (pcg_mi355x.octree.GradedOctreeMesh)
+        from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+        P = make_octree_parts(GradedOctreeMesh({"oct1m": (12, 12, 12), "oct10m": (38, 38, 38)}[N], 4, band=1.2), 1)[0]
+    else:
+        P = make_parts(Brick(N))[0]
     for kind in kinds:
       for cvar, cvals in create:
         for cv in cvals.split("|"):

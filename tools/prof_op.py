@@ -17,11 +17,11 @@ from pcg_mi355x.operator import from_refmeshpart
 kind = sys.argv[1] if len(sys.argv) > 1 else "ebe"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-if os.environ.get("PROF_OCTREE"):          # two-level octree mesh with hanging-node transition patterns (nd = 39)
-    from pcg_mi355x.octree import TwoLevelMesh, make_octree_parts
-    m = TwoLevelMesh(N, N, N // 2, N // 8)
+if os.environ.get("PROF_OCTREE"):          # PROF_OCTREE=1m|10m: the multi-level graded octree mesh (N is ignored)
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    m = GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[os.environ["PROF_OCTREE"]], 4, band=1.2)
     P = make_octree_parts(m, 1)[0]
-    print("octree mesh", m.n_dof, "dof", {k: len(v) for k, v in m.cells.items()})
+    print("octree mesh", m.summary())
 else:
     P = make_parts(Brick(N))[0]
 for kd in kind.split(","):                  # several operators in one process (one rocprofv3 pass covers them all)
