@@ -340,7 +340,6 @@ def octree_object(measure, log):
         if kind in ("sell", "dict"):
             info = op.matrix_info()
             e["sell_padding"] = info["stored_blocks"] / max(1, info["nnzb"]) - 1
-            e["sell_row_sorting"] = getattr(op, "sell_sort", None)      # SELL-C-sigma: rows sorted by length inside 2048-row windows
             e["nnz"] = op.nnz
         if kind == "dict":
             e["table"] = op.matrix_dictionary_info()        # distinct blocks, how many sit in LDS, the share of stored blocks those cover

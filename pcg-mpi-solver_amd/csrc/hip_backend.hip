@@ -35,9 +35,13 @@ class HipBackend : public Backend {
     // phase (disjoint exclusive nodes, disjoint boundary slots; fork / join with events).  Measured on the two-level octree
     // mesh (1.2 M dof): a stand-alone apply 0.065 -> 0.059 ms, but the PCG iteration 0.097 -> 0.100 ms - the two cross-stream
     // waits per apply cost the look-ahead loop more than the overlap returns - so it is off by default.  ls_ = launch stream.
-    hipStream_t st2_ = nullptr, ls_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    bool ebe_two_streams_ = false;
+    // Round 3: ONE side stream per node-count class, measured on the multi-level octree mesh (1 M dof: the hanging-node classes
+    // take 35 + 29 us next to the 30 us of the hex8 launch): 105 vs 107 us per apply, 130.8 vs 131.0 us per iteration - the
+    // launches are throughput-bound, not tail-bound, so running them side by side buys nothing (profiles/r03_octree_ab_sessionG.log).
+    // Still opt-in only: PCG_EBE_STREAMS=1.
+    hipStream_t st2_[kChunkClasses] = {}, ls_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_[kChunkClasses] = {};
+    int ebe_streams_mode_ = 0;                   // 1: PCG_EBE_STREAMS=1
     // matrix
     int bs_ = 3;
     int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
@@ -153,11 +157,13 @@ public:
             throw std::runtime_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
         n_cu_ = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (int c = 1; c < kChunkClasses; ++c) {
+            HIP_CHECK(hipStreamCreateWithFlags(&st2_[c], hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_join_[c], hipEventDisableTiming));
+        }
         ls_ = st_;
-        if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_two_streams_ = atoi(e) != 0;
+        if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_streams_mode_ = atoi(e) != 0 ? 1 : 0;
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
@@ -205,8 +211,10 @@ public:
             for (auto e : ev_slot_) (void)hipEventDestroy(e);
         }
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-        if (ev_join_) (void)hipEventDestroy(ev_join_);
-        if (st2_) (void)hipStreamDestroy(st2_);
+        for (int c = 1; c < kChunkClasses; ++c) {
+            if (ev_join_[c]) (void)hipEventDestroy(ev_join_[c]);
+            if (st2_[c]) (void)hipStreamDestroy(st2_[c]);
+        }
         if (st_) (void)hipStreamDestroy(st_);
     }
     const char *name() const override { return "hip-gfx950"; }
@@ -518,23 +526,27 @@ public:
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
             int others = 0;
             for (int c = 1; c < kChunkClasses; ++c) others += chc_[c].count[ph] > 0;
-            const bool fork = ebe_two_streams_ && chc_[0].count[ph] > 0 && others > 0;
-            if (fork) {                                          // the other classes beside the hex8 launch
+            const bool fork = others > 0 && (chc_[0].count[ph] > 0 || others > 1) &&
+                              ebe_streams_mode_ == 1;
+            if (fork) {                                          // every other class on its own stream beside the hex8 launch
                 HIP_CHECK(hipEventRecord(ev_fork_, st_));
-                HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
+                for (int c = 1; c < kChunkClasses; ++c)
+                    if (chc_[c].count[ph]) HIP_CHECK(hipStreamWaitEvent(st2_[c], ev_fork_, 0));
             }
             for (int c = 0; c < kChunkClasses; ++c) {            // one launch per node-count class
                 const auto &D = chc_[c];
                 if (!D.count[ph]) continue;
-                ls_ = (fork && c > 0) ? st2_ : st_;
+                ls_ = (fork && c > 0) ? st2_[c] : st_;
                 const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
                 if (fuse) cnt_ebe_ += np;
             }
             ls_ = st_;
-            if (fork) {
-                HIP_CHECK(hipEventRecord(ev_join_, st2_));
-                HIP_CHECK(hipStreamWaitEvent(st_, ev_join_, 0));
-            }
+            if (fork)
+                for (int c = 1; c < kChunkClasses; ++c)
+                    if (chc_[c].count[ph]) {
+                        HIP_CHECK(hipEventRecord(ev_join_[c], st2_[c]));
+                        HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[c], 0));
+                    }
             if (sh_count_[ph]) {
                 const int grid = (3 * sh_count_[ph] + kBlock - 1) / kBlock;
                 double *part = d_part_ebe_ + cnt_ebe_;

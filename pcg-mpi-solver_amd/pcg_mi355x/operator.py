@@ -381,46 +381,6 @@ def _blocked_node_order(xyz, is_b, block=8):
     return np.concatenate([np.flatnonzero(is_b), interior[np.argsort(key[interior], kind="stable")]])
 
 
-def _sell_padding(lens, C=64):
-    """Stored / true block count - 1 of SELL-C slices over rows of these lengths (consecutive rows per slice)."""
-    n = len(lens)
-    pad = (-n) % C
-    l2 = np.concatenate([lens, np.zeros(pad, lens.dtype)]).reshape(-1, C)
-    return float(l2.max(axis=1).sum() * C) / max(1, int(lens.sum())) - 1.0
-
-
-def _sort_rows_in_windows(groups, n_nodes, order, n_bnd, n_threads=0, window=2048, min_padding=0.10):
-    """SELL-C-sigma: when the 64-row slices of the assembled operator would be padded by more than `min_padding` (rows of very
-    different lengths next to each other - the hanging-node rows of an octree mesh among its hex8 rows: 57 % on the 1 M-dof
-    graded mesh), reorder the rows inside windows of `window` consecutive rows by descending length, separately in the interface
-    block [0, n_bnd) and the interior, so that a slice holds rows of (nearly) one length while a row stays within `window`
-    positions of its neighbours (x-gather locality).  order: old node ids in engine order -> (refined order, padding before,
-    after); None when nothing is to gain.  One extra symbolic assembly (row lengths) on the host."""
-    L = _lib.lib()
-    perm = np.empty(n_nodes, np.int64)
-    perm[order] = np.arange(n_nodes)
-    arr, keep = _pack_groups(groups)
-    h = C.c_void_p()
-    check(L.pcg_asm_create(n_nodes, len(groups), arr, perm.ctypes.data, n_threads, C.byref(h)), "pcg_asm_create")
-    try:
-        rowptr = np.empty(n_nodes + 1, np.int64)
-        check(L.pcg_asm_rowptr(h, rowptr.ctypes.data), "pcg_asm_rowptr")
-    finally:
-        L.pcg_asm_destroy(h)
-    lens = np.diff(rowptr)                                   # per NEW node id
-    before = _sell_padding(lens)
-    if before <= min_padding:
-        return None
-    new_pos = np.arange(n_nodes)
-    for lo, hi in ((0, n_bnd), (n_bnd, n_nodes)):
-        for a in range(lo, hi, window):
-            b = min(a + window, hi)
-            new_pos[a:b] = a + np.argsort(-lens[a:b], kind="stable")
-    refined = np.asarray(order)[new_pos]                     # old ids in the refined engine order
-    after = _sell_padding(lens[new_pos])
-    return refined, before, after
-
-
 def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, kind="sell", ebe_chunked=True):
     """Build the GPU operator of one RefMeshPart (see module docstring for the keys read).
     kind: "sell" = assembled SELL-BSR3 matrix (default), "dict" = the same matrix with its values replaced by a dictionary of
@@ -438,26 +398,20 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
     n_bnd = 0
     xyz = part.get("NodeCoordVec")              # (3*NNode,) x,y,z per node (partition_mesh.py:357); optional
     blocked = kind == "ebe" and xyz is not None and os.environ.get("PCG_EBE_BLOCKED_ORDER", "1") == "1"
-    sort_rows = kind in ("sell", "dict") and int(rows_per_lane) in (0, 1) and os.environ.get("PCG_SELL_SORT", "1") == "1"
-    sell_sort = None
-    if len(nbr) or blocked or sort_rows:
+    # (Round 3 measured SELL-C-sigma here - rows sorted by length inside 2048-row windows, which takes the padding of the octree
+    #  mesh from 56.6 % to 2.1 % - and removed it again: lanes of a slice then hold rows from anywhere in the window, the x gather
+    #  loses its lane-to-lane locality and the SpMV gained 3 % for 35 % fewer bytes: profiles/r03_octree_ab_sessionG.log.)
+    if len(nbr) or blocked:
         is_b = np.zeros(n_nodes, bool)
         for v in ovl:
             is_b[v // 3] = True
         order = _blocked_node_order(xyz, is_b) if blocked else None
         if order is None:
             order = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])     # old ids, interface first
+        node_perm = np.empty(n_nodes, np.int64)
+        node_perm[order] = np.arange(n_nodes)
         n_bnd = int(is_b.sum())
-        if sort_rows:
-            ref = _sort_rows_in_windows(groups, n_nodes, order, n_bnd, n_threads)
-            if ref is not None:
-                order, sell_sort = ref[0], {"padding_before": ref[1], "padding_after": ref[2]}
-        if len(nbr) or blocked or sell_sort is not None:
-            node_perm = np.empty(n_nodes, np.int64)
-            node_perm[order] = np.arange(n_nodes)
-            dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
-        else:
-            n_bnd = 0
+        dof_map = (3 * node_perm[:, None] + np.arange(3)[None, :]).ravel()
     if kind == "ebe":
         op = Operator(n_nodes, None, None, None, n_bnd, dof_map, device, 0, ebe_groups=groups, node_perm=node_perm,
                       node_coords=xyz, ebe_chunked=ebe_chunked)
@@ -472,7 +426,6 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
             op = Operator(n_nodes, rowptr, cols, vals, n_bnd, dof_map, device, fmt)
     else:
         raise ValueError(kind)
-    op.sell_sort = sell_sort                 # {"padding_before", "padding_after"} when the rows were sorted inside windows
     w = np.asarray(part["DofWeightVector"], float)
     if not np.all((w == 0) | (w == 1)):
         raise PcgError("DofWeightVector must be 0/1 (partition_mesh.py:870-887)")
