@@ -164,6 +164,7 @@ public:
         }
         ls_ = st_;
         if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_streams_mode_ = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("PCG_EBE_ROWS_LDS")) rows_lds_mode_ = atoi(e) != 0 ? 1 : 0;
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
@@ -486,15 +487,33 @@ public:
             hipLaunchKernelGGL(k_ebe_generic, dim3(grid), dim3(kBlock), 0, st_, D.dof, D.sgn_bytes, D.ck, D.ke, x, y, D.nd, D.ne,
                                r.lo, r.hi);
     }
+    // hanging-node classes: Ke through LDS (k_ebe_rows KLDS) when it does not fit the scalar cache AND the launch is latency-bound
+    // (at most four workgroups per CU).  Measured on the octree mesh (profiles/r03_octree_rows_kernel_lds_ab_sessionI.log): 1 M dof
+    // (a few hundred chunks per class) operator 106 -> 91 us, iteration 131 -> 115 us; 10 M dof (thousands of chunks: throughput-
+    // bound, and every workgroup copies 18-41 KB of Ke for its 64 elements) 509 -> 568 us.  PCG_EBE_ROWS_LDS=0 / 1 overrides.
+    int rows_lds_mode_ = -1;
+    bool rows_lds_raised_[4] = {false, false, false, false};
     template <int NNP>
     void launch_rows(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
-        if (dot)
-            hipLaunchKernelGGL((k_ebe_rows<NNP, true>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
-        else
-            hipLaunchKernelGGL((k_ebe_rows<NNP, false>), dim3(D.count[ph]), dim3(kChunkThreads), 0, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_,
-                               d_ch_dst_, d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        constexpr int NDP = 3 * NNP;
+        const bool klds = rows_lds_mode_ >= 0 ? rows_lds_mode_ != 0 : (NNP >= 16 && D.count[ph] <= 4 * n_cu_);
+        auto go = [&](auto kern, size_t lds) {
+            hipLaunchKernelGGL(kern, dim3(D.count[ph]), dim3(kChunkThreads), lds, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_, d_ch_dst_,
+                               d_ch_tslot_, D.lid, D.ck, D.sgn, D.ke_rows, x, y, d_ch_buf_, d_flags_, part, dot_lo);
+        };
+        if (klds) {
+            const size_t lds = sizeof(double) * NDP * NDP;
+            const int slot = NNP == 8 ? 0 : NNP == 16 ? 1 : NNP == 24 ? 2 : 3;
+            if (!rows_lds_raised_[slot]) {                       // beyond the default dynamic-LDS window (per device: a member)
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_ebe_rows<NNP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_ebe_rows<NNP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                rows_lds_raised_[slot] = true;
+            }
+            if (dot) go(k_ebe_rows<NNP, true, true>, lds); else go(k_ebe_rows<NNP, false, true>, lds);
+        } else {
+            if (dot) go(k_ebe_rows<NNP, true, false>, 0); else go(k_ebe_rows<NNP, false, false>, 0);
+        }
     }
     // -> number of dot partials the launch writes
     int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)

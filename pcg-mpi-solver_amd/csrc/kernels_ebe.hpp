@@ -356,7 +356,12 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
 // shared write-out are those of k_ebe_hex; every wave gathers all NDP inputs (the tile is in LDS, the redundancy is 4 LDS
 // reads instead of 1 per input).
 // ------------------------------------------------------------------------------------------------
-template <int NNP, bool DOT>
+// KLDS (round 3): the workgroup copies the pattern's Ke (NDP x NDP doubles in the per-wave layout, 18 / 41 / 74 KB for 16 / 24 / 32
+// nodes) into LDS once, with coalesced vector loads, and the contraction reads its coefficients from there (the lanes of a wave
+// read ONE address: broadcast ds_read_b128).  Through scalar loads a 41 KB matrix does not stay in the 16 KB scalar cache: every
+// one of the 72 columns was an L2 round trip (~0.5 us) with nothing to hide it behind - 35 us for 12.7 k elements on the 1 M-dof
+// octree mesh, against 30 us for 229 k hex8 elements (whose 4.6 KB Ke does stay cached; they keep the SGPR path).
+template <int NNP, bool DOT, bool KLDS = false>
 __global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
     const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
     const unsigned short *__restrict__ tslot, const unsigned short *__restrict__ lid, const double *__restrict__ ck, const unsigned *__restrict__ sgn,
@@ -404,16 +409,33 @@ __global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
         }
     }
     __syncthreads();
-    const double *K = ke_rows + ((size_t)h.w * 4 + wave) * NDP * RPW;       // this wave's rows: [column b][row a]
     double acc[RPW];
 #pragma unroll
     for (int a = 0; a < RPW; ++a) acc[a] = 0.0;
+    if constexpr (KLDS) {
+        extern __shared__ __align__(16) double ks[];         // [wave][column b][row a], the layout of ke_rows
+        const double2 *src = reinterpret_cast<const double2 *>(ke_rows + (size_t)h.w * NDP * NDP);
+        double2 *dst2 = reinterpret_cast<double2 *>(ks);
+        for (int i = threadIdx.x; i < NDP * NDP / 2; i += kChunkThreads) dst2[i] = src[i];
+        __syncthreads();
+        const double *K = ks + (size_t)wave * NDP * RPW;
+#pragma unroll 4
+        for (int b = 0; b < NDP; ++b) {
+            if (b < nd) {
+                const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);               // :277-279
 #pragma unroll
-    for (int b = 0; b < NDP; ++b) {
-        if (b < nd) {                                        // nd is block-uniform: scalar compare, loops stay unrolled
-            const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);                   // :277-279
+                for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                   // :279 Ke @ (.)
+            }
+        }
+    } else {
+        const double *K = ke_rows + ((size_t)h.w * 4 + wave) * NDP * RPW;   // this wave's rows: [column b][row a]
 #pragma unroll
-            for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                       // :279 Ke @ (.)
+        for (int b = 0; b < NDP; ++b) {
+            if (b < nd) {                                    // nd is block-uniform: scalar compare, loops stay unrolled
+                const double u = c * flip_sign(xs[l3[b / 3] + b % 3], sg[b >> 5], b & 31);               // :277-279
+#pragma unroll
+                for (int a = 0; a < RPW; ++a) acc[a] = fma(K[b * RPW + a], u, acc[a]);                   // :279 Ke @ (.)
+            }
         }
     }
     const int row0 = wave * RPW;                             // global row of acc[0]
