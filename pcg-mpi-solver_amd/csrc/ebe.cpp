@@ -381,7 +381,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 int nsub = 0;
                 bool bnd = false;
                 if (!sub_colour(g, o, sc, lids, nsub, bnd)) return false;
-                if (C.cls[cls_of[g]].full) {                 // hex8 class: sub-colour groups start on 16-slot tiles (k_ebe_mfma)
+                if (C.cls[cls_of[g]].full) {                 // hex8 class: sub-colour groups start on 16-slot tiles
                     std::vector<int> cnt(nsub, 0);
                     for (int c : sc) cnt[c]++;
                     size_t padded = 0;

@@ -7,14 +7,16 @@
 // XCD-partitioned mapping - block b & 7 = XCD owns one contiguous eighth - is kept behind
 // PCG_SPMV_XCD=1; it measured 2.5 % slower: one matrix stream beats eight, x comes from MALL),
 // reductions are wave64 shuffles -> LDS -> one partial per block -> a fixed tree (no float
-// atomics: bit-reproducible run to run), and the vector part of an iteration is fused into two
-// streaming kernels.  No MFMA: MI355X's f64 matrix rate equals its vector rate and the assembled
+// atomics: bit-reproducible run to run), and the vector part of an iteration is ONE streaming
+// kernel with a grid barrier and its reductions inside (k_vec, kernels_vector.hpp).  The kernels
+// live in kernels_{spmv,ebe,vector,probe}.hpp; this file is the back end that owns the device
+// data and launches them.  No MFMA: MI355X's f64 matrix rate equals its vector rate and the assembled
 // path is HBM-bound; the matrix-free operator (k_ebe_*) runs its 24x24 contraction on the vector
 // FMA pipe with the element matrix as SGPR operands.
 //
 // Reference semantics implemented (src/solver/pcg_solver.py): k_spmv = calcMatVecProd :265-300 on
 // the assembled operator (+ fused p.Ap.w :487); k_fixup = :332-334; k_update_p = :447,:472-479;
-// k_fused_update = :501-516 plus :447-462 of the next iteration; k_residual = :413-416/:530-533;
+// k_vec = :487-516 plus :447-479 of the next iteration (kernels_vector.hpp); k_residual = :413-416/:530-533;
 // k_dot_w = np.dot(a, b*w) :381.
 #include "hip_common.hpp"
 #include "kernels_spmv.hpp"
@@ -127,7 +129,7 @@ class HipBackend : public Backend {
     int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
     bool bench_dot_ = false;
     // Non-temporal accesses in the vector kernels (PCG_VEC_NT, bit mask; A/B: tools/vec_nt_ab.py re-reads it per solve).
-    // bit 0: the vectors the iteration rewrites (p in k_update_p; r', x' in k_fused_update) are stored non-temporally.  Plain
+    // bit 0: the vectors the iteration rewrites (p in k_update_p; r', x', p' in k_vec) are stored non-temporally.  Plain
     //        stores leave the rewritten lines dirty in the memory-side cache; they are then written out underneath the next
     //        operator's read stream: a stand-alone SpMV whose x was just rewritten by a plain-store kernel runs 2.5-6 % slower,
     //        with `nt` stores 0.5-1 % (sc1 / sc0 sc1 do not help; profiles/r02_spmv_launch_context.txt).  In the loop at

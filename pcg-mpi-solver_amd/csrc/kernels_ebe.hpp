@@ -52,18 +52,18 @@ __global__ __launch_bounds__(kBlock) void k_ebe(const int *__restrict__ dof, con
 
 // ------------------------------------------------------------------------------------------------
 // hex8 chunks, second form (k_ebe_hex).  Same algorithm, same summation order per node and the same host-side chunk
-// structures as k_ebe_chunk; what changes is how a workgroup gets to its arithmetic and back:
+// structures as the round-1 kernel (k_ebe_chunk, removed in round 3); what changed is how a workgroup gets to its arithmetic and back:
 //   * per-LAUNCH tables (HexTab): block b finds its header, node list (padded to MAXN entries, -1 = none) and element
 //     slots at fixed strides of b - no chunk-id list, no header -> offsets dependency: the node ids, the element data
 //     and the header are three independent loads issued together, the x gather is the only dependent round trip
-//     (k_ebe_chunk: chunk id -> header -> node ids -> x);
+//     (round 1: chunk id -> header -> node ids -> x);
 //   * element slot of thread t, copy j: ((t >> 6) * EPT + j) * 64 + (t & 63): a wave owns EPT consecutive 64-slot runs,
 //     so slot order = (wave, j) order, and the LDS accumulation runs wave after wave (each wave its sub-colours in
 //     ascending order, LDS operations of one wave are ordered) with ONE block barrier per wave instead of one per
 //     sub-colour: 4 instead of 8-10 per chunk, same order of additions;
 //   * a sign is an XOR of the sign bit (shift, and, xor) instead of compare + select + two moves.
 // EPT / NPT (tile nodes per thread) / LB (blocks per CU asked of the register allocator) are template parameters so that
-// the occupancy trade-off can be measured (PCG_EBE_HEX, tools/ebe_lab.py).
+// the occupancy trade-off can be measured (tools/ebe_lab.py).
 // ------------------------------------------------------------------------------------------------
 struct HexTab {
     const int4 *hdr;              // per chunk: n_nodes, n_sub, ke index, any sign bit set

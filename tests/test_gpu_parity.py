@@ -643,7 +643,7 @@ def test_eight_parts_on_one_gpu_match_one_part_at_mid_size(gpu_lib, kind):
 
 def test_mixed_chunked_and_colour_groups_with_neighbours_on_gpu(gpu_lib):
     """ADVICE r1 (see tests/test_irregular_meshes.py): parts with neighbours whose groups are partly chunkable, partly
-    colour-launched - k_ebe_chunk / k_ebe_shared stores and k_ebe read-modify-writes in one operator, with the exchange."""
+    colour-launched - chunk kernel / k_ebe_shared stores and k_ebe read-modify-writes in one operator, with the exchange."""
     from test_irregular_meshes import check_mixed_layout_multi_part
     check_mixed_layout_multi_part(True)
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Same-process A/B of PCG_VEC_NT (non-temporal stores in k_update_p / k_fused_update): PCG iterations/s and the
+"""Same-process A/B of PCG_VEC_NT (non-temporal stores in k_update_p / k_vec): PCG iterations/s and the
 in-loop operator time for both operators.  usage: vec_nt_ab.py [N] [steps]   (development)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
