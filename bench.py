@@ -314,8 +314,16 @@ def pmc_traffic_live(args):
         rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_spmv<1, true%' and counter_name = ?",
                           (ctr,)).fetchall()
         vals[ctr] = (float(rows[0][0]), int(rows[0][1]))
-    return {"bytes": 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"][0],
-            "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1]}
+        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_vec<true>%' and counter_name = ?",
+                          (ctr,)).fetchall()
+        vals["vec_" + ctr] = (float(rows[0][0] or 0.0), int(rows[0][1]))
+    out = {"bytes": 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"][0],
+           "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1]}
+    if vals["vec_FETCH_SIZE"][1] > 0:             # the vector-phase launch of the same passes (16-B streaming loads: the same x2 correction)
+        out["vec"] = {"bytes": 2.0 * vals["vec_FETCH_SIZE"][0] * 1024 + vals["vec_WRITE_SIZE"][0] * 1024,
+                      "FETCH_SIZE_KB_raw": vals["vec_FETCH_SIZE"][0], "WRITE_SIZE_KB_raw": vals["vec_WRITE_SIZE"][0],
+                      "dispatches": vals["vec_FETCH_SIZE"][1]}
+    return out
 
 
 def octree_object(measure, log):
@@ -530,7 +538,8 @@ def main():
                                         "z = M^-1 r' stays in registers across the grid barrier" if fused else
                                         "57 B/dof: p, q, r, x, M^-1 read + 1 flag byte + r', x' written"),
                    "bound": "hbm", "achieved": vb / (vms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, "measured_in": "a second window of K iterations with events around every launch"}
+                   "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                   "measured_in": "a second window of K iterations with events around every launch"}
         elapsed, per_rank = gather_max(elapsed_local)
         comm_info = None
         if world > 1 and getattr(comm, "native", False):   # second window: HIP events around the exchange wait / all-reduces
@@ -728,6 +737,12 @@ def main():
                                                    f"(FETCH_SIZE {live['FETCH_SIZE_KB_raw']:.0f} KB x2 gfx950 correction + WRITE_SIZE {live['WRITE_SIZE_KB_raw']:.0f} KB, "
                                                    f"mean of {live['dispatches']} launches)")
                 out["roofline"]["traffic_over_bytes"] = live["bytes"] / sell_bytes
+                if live.get("vec") and out.get("roofline_vector_phase"):
+                    v = out["roofline_vector_phase"]
+                    v["traffic"] = live["vec"]["bytes"]
+                    v["traffic_over_bytes"] = live["vec"]["bytes"] / v["bytes_per_launch"]
+                    v["traffic_note"] = (f"same two PMC passes: FETCH_SIZE {live['vec']['FETCH_SIZE_KB_raw']:.0f} KB x2 + WRITE_SIZE "
+                                         f"{live['vec']['WRITE_SIZE_KB_raw']:.0f} KB, mean of {live['vec']['dispatches']} launches of k_vec<true>")
             except Exception as ex:      # noqa: BLE001
                 log(f"live PMC traffic measurement failed: {ex!r}")
     if world > 1:
