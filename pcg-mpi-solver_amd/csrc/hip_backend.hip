@@ -350,14 +350,17 @@ public:
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
     }
     // Where the value array lands physically is not the engine's choice, and it matters: the identical launch ran at 1.05 and at
-    // 1.22 ms in consecutive processes on ONE box (profiles/r03_pmc_*direction_major.md).  So the upload tries
-    // a few placements of the array (a second / third allocation made while the earlier ones are still held, i.e. other physical
-    // pages; device-to-device copy), times a handful of SpMV launches on each and keeps the fastest.  Same bytes, same kernel,
-    // same results - only where the 6.5 GB live.  PCG_SPMV_PLACEMENTS=k (default 3; 1 = off), arrays of 256 MB .. 24 GB only.
+    // 1.22 ms in consecutive processes on ONE box, and FOUR allocations of the same 6.5 GB array inside one process gave 1.124 /
+    // 1.061 / 1.039 / 1.081 ms per stand-alone launch (profiles/r03_value_array_placements_standalone.txt).  This probe
+    // (PCG_SPMV_PLACEMENTS=k, OFF by default) tries k placements at upload - each allocated while the earlier ones are still held,
+    // device-to-device copy - and keeps the fastest.  It is off because the stand-alone winner is NOT the in-loop winner: with
+    // the probe the SpMV of the PCG loop ran at 1.143 / 1.194 ms against 1.054 / 1.030 ms without it (same box, alternating
+    // processes, profiles/r03_value_array_placements_in_loop.txt) - what counts is the placement of the value array RELATIVE
+    // to the vectors allocated after it, which the probe's own allocations disturb.  Kept as the reproducer of that finding.
     std::vector<float> placement_ms_;
     void probe_value_placement(const SellHost &m)
     {
-        int k = 3;
+        int k = 1;
         if (const char *e = getenv("PCG_SPMV_PLACEMENTS")) k = std::max(1, std::min(8, atoi(e)));
         const size_t bytes = sizeof(double) * m.vals.size();
         if (k < 2 || bs_ != 3 || C_ != 64 || bytes < ((size_t)256 << 20) || bytes > ((size_t)24 << 30) || (!d_cols16_ && !d_cols_)) return;
