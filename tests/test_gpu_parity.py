@@ -275,7 +275,9 @@ def test_solve_matches_reference_fixture(gpu_lib, name):
         return
     assert out is None
     if name == "n9_stagnate":
-        # rounding-floor stagnation: the exit iteration depends on last-bit noise; gate on outcome
+        # rounding-floor stagnation: in a FREE-RUNNING solve the exit iteration (and with MaxIter 1500 even Flag 3 vs 1) depends on
+        # last-bit noise of the reduction order, so the outcome is gated here; the stagnation counter and the exit themselves are
+        # pinned on the HIP kernels with identical inputs in tests/test_lockstep.py::test_stagnation_exit_in_lock_step
         assert info.flag in (1, 3) and info.relres < 1e-12
         return
     tol_u = 1e-8 if info.flag == 0 else 1e-6
