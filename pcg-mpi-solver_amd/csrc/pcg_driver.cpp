@@ -1133,12 +1133,12 @@ int pcg_k_update_p(pcg_engine *e, double *p, const double *r, const double *inv_
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dp = e->scratch(0), *dr = e->scratch(1), *dm = e->scratch(2);
         double *dpo = e->scratch(3);
-        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n); e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dp, p, bytes); e->be->h2d(dr, r, bytes); e->be->h2d(dm, inv_diag, bytes);
         double st[ST_COUNT] = {0};
         st[ST_RHO_NEXT] = beta;                               // beta = st[RHO_NEXT] / rho_prev with rho_prev = 1: exact
         e->be->h2d(e->d_st, st, sizeof(st));
         e->be->update_p(dpo, dp, dr, dm, e->d_st, 1.0, first != 0);
-        e->be->d2h(p, dpo, sizeof(double) * (size_t)e->n);
+        e->be->d2h(p, dpo, bytes);
         return 0;
     });
 }
@@ -1151,8 +1151,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         ensure_solver_buffers(e);
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2];
-        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dq, q, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n);
-        e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n); e->be->h2d(dxo, x_old, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
+        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         e->be->h2d(e->d_st, st, sizeof(st));
@@ -1160,8 +1160,8 @@ int pcg_k_fused_update(pcg_engine *e, double alpha, const double *p, const doubl
         e->be->reduce_update(e->d_st + ST_SQP);
         e->read_status();
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->d2h(r, drn, sizeof(double) * (size_t)e->n);
-        e->be->d2h(x_new, dxn, sizeof(double) * (size_t)e->n);
+        e->be->d2h(r, drn, bytes);
+        e->be->d2h(x_new, dxn, bytes);
         return 0;
     });
 }
@@ -1178,8 +1178,8 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         if (fused && !e->be->vec_fused_available()) return set_error("pcg_k_vec_iteration: the fused form is not available");
         double *dp = e->scratch(0), *dq = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
         double *dxo = e->v_x[0], *dxn = e->v_x[1], *drn = e->v_x[2], *dpn = e->v_x[3];
-        e->be->h2d(dp, p, sizeof(double) * (size_t)e->n); e->be->h2d(dq, q, sizeof(double) * (size_t)e->n); e->be->h2d(dr, r, sizeof(double) * (size_t)e->n);
-        e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n); e->be->h2d(dxo, x_old, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dp, p, bytes); e->be->h2d(dq, q, bytes); e->be->h2d(dr, r, bytes);
+        e->be->h2d(dm, inv_diag, bytes); e->be->h2d(dxo, x_old, bytes);
         double st[ST_COUNT] = {0};
         st[ST_ALPHA] = alpha;
         st[ST_RHO_NEXT] = rho;
@@ -1192,9 +1192,9 @@ int pcg_k_vec_iteration(pcg_engine *e, double alpha, double rho, const double *p
         e->read_status();
         if (e->h_st[ST_ERR] != 0) return set_error("pcg_k_vec_iteration: the grid barrier timed out");
         for (int k = 0; k < 5; ++k) sums5[k] = e->h_st[ST_SQP + k];
-        e->be->d2h(r, drn, sizeof(double) * (size_t)e->n);
-        e->be->d2h(x_new, dxn, sizeof(double) * (size_t)e->n);
-        e->be->d2h(p_next, dpn, sizeof(double) * (size_t)e->n);
+        e->be->d2h(r, drn, bytes);
+        e->be->d2h(x_new, dxn, bytes);
+        e->be->d2h(p_next, dpn, bytes);
         return 0;
     });
 }
@@ -1204,12 +1204,12 @@ int pcg_k_residual(pcg_engine *e, const double *b, const double *ax, double *r, 
     return guarded("pcg_k_residual", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *db = e->scratch(0), *da = e->scratch(1), *dr = e->scratch(2), *dm = e->scratch(3);
-        e->be->h2d(db, b, sizeof(double) * (size_t)e->n); e->be->h2d(da, ax, sizeof(double) * (size_t)e->n); e->be->h2d(dm, inv_diag, sizeof(double) * (size_t)e->n);
+        e->be->h2d(db, b, bytes); e->be->h2d(da, ax, bytes); e->be->h2d(dm, inv_diag, bytes);
         e->be->residual(db, da, dr, dm);
         e->be->reduce_residual(e->d_st + ST_SQR);
         e->read_status();
         for (int k = 0; k < 3; ++k) sums3[k] = e->h_st[ST_SQR + k];
-        e->be->d2h(r, dr, sizeof(double) * (size_t)e->n);
+        e->be->d2h(r, dr, bytes);
         return 0;
     });
 }
@@ -1219,7 +1219,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
     return guarded("pcg_k_spmv_local", e, [&]() -> int {
         const size_t bytes = sizeof(double) * (size_t)e->n;
         double *dx = e->scratch(0), *dy = e->scratch(1);
-        e->be->h2d(dx, x, sizeof(double) * (size_t)e->n);
+        e->be->h2d(dx, x, bytes);
         if (e->kind == 1) {
             if (pxy) e->be->begin_dot();
             e->ebe_dot_fused = e->be->ebe_apply(dx, dy, 0, 2, true, pxy != nullptr, 0) && pxy;
@@ -1233,7 +1233,7 @@ int pcg_k_spmv_local(pcg_engine *e, const double *x, double *y, double *pxy)
             e->read_status();
             *pxy = e->h_st[ST_PQ];
         }
-        e->be->d2h(y, dy, sizeof(double) * (size_t)e->n);
+        e->be->d2h(y, dy, bytes);
         return 0;
     });
 }
