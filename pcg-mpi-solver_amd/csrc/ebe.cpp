@@ -4,6 +4,8 @@
 //   * every other pattern type -> greedy element colouring, one conflict-free launch per colour;
 //   * local diag(A) in the reference's own accumulation order (pcg_solver.py:282-300).
 // Everything is deterministic: orders depend only on the input tables.
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <array>
@@ -220,6 +222,8 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         K.ce = c == 0 ? kChunkThreads * ept : 64;
         K.words = 3 * K.nnp / 32 + 1;
         K.max_nodes = (c == 0 && ept == 1) ? 512 : kChunkMaxNodes;      // 8x8x4 hex cells -> 405 nodes: a 2-nodes-per-thread tile
+        const char *dv = std::getenv("PCG_EBE_DIRECT");                              // =0: node tiles for every class (A/B)
+        K.direct = c >= 1 && c <= 3 && !(dv && dv[0] == '0');
     }
     for (int g = 0; g < n_groups; ++g)
         if (chunkable[g]) {
@@ -231,7 +235,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             ke_index[g] = (int32_t)(K.ke_col.size() / ((size_t)ndp * ndp));
             for (int b = 0; b < ndp; ++b)
                 for (int a = 0; a < ndp; ++a) K.ke_col.push_back(a < nd && b < nd ? gs[g].ke[(size_t)a * nd + b] : 0.0);
-            if (c != 0) {                                   // row-split layout: wave w owns rows [w*ndp/4, (w+1)*ndp/4)
+            if (c != 0 && !K.direct) {                      // row-split layout: wave w owns rows [w*ndp/4, (w+1)*ndp/4)
                 const int rpw = ndp / 4;
                 for (int w = 0; w < 4; ++w)
                     for (int b = 0; b < ndp; ++b)
@@ -396,6 +400,44 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             // mostly far from full (round 3: 2 222 chunks for 265 k elements at 1 M dof).  They are packed GREEDILY instead:
             // runs of up to 64 consecutive elements of the type's Morton order, shortened only where the tile would exceed its
             // node or sub-colour limits.  The hex8 class keeps the cell recursion (full boxes = regular LDS tiles).
+            // Hanging-node classes without a node tile (k_ebe_direct): a chunk is a run of 64 consecutive elements of the type's
+            // Morton order, full except for the last one; an entry of `nodes` / `dst` per element-node incidence.
+            if (C.cls[cls_of[g]].direct) {
+                auto &K = C.cls[cls_of[g]];
+                const int CE = K.ce, W = K.words;
+                for (size_t lo_ = 0; lo_ < L.size(); lo_ += (size_t)CE) {
+                    const int ne = (int)std::min<size_t>((size_t)CE, L.size() - lo_);
+                    const int32_t cid = (int32_t)C.n_chunks++;
+                    const int32_t kci = (int32_t)K.n_chunks++;
+                    const size_t off = C.nodes.size(), nn = (size_t)nno * CE;
+                    C.nodes.resize(off + nn, -1);
+                    C.tslot.resize(off + nn, 0);
+                    C.direct_entries += (int64_t)nn;
+                    K.ck.resize((size_t)(kci + 1) * CE, 0.0);
+                    K.sgn.resize((size_t)(kci + 1) * W * CE, 0u);
+                    for (int lane = ne; lane < CE; ++lane) K.sgn[((size_t)kci * W + (W - 1)) * CE + lane] = 0xff000000u;   // padding marker
+                    bool bnd = false;
+                    for (int t = 0; t < ne; ++t) {
+                        const int64_t e = L[lo_ + t].e;
+                        for (int l = 0; l < nno; ++l) {
+                            const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + e]);
+                            C.nodes[off + (size_t)l * CE + t] = (int32_t)node;
+                            bnd |= node < n_boundary_nodes;
+                        }
+                        K.ck[(size_t)kci * CE + t] = in.ck[e];
+                        for (int w = 0; w < W; ++w) {
+                            uint32_t bits = 0;
+                            for (int a = 32 * w; a < std::min(in.nd, 32 * w + 32); ++a)
+                                if (in.sign[(int64_t)a * in.ne + e]) bits |= (1u << (a - 32 * w));
+                            K.sgn[((size_t)kci * W + w) * CE + t] = bits;
+                        }
+                    }
+                    C.hdr.insert(C.hdr.end(), {(int32_t)off, (int32_t)nn, 0, ke_index[g], kci, in.nd, cls_of[g], (ne + 15) / 16});
+                    chunk_phase.push_back(bnd ? 0 : 1);
+                    K.list[bnd ? 0 : 1].push_back(cid);
+                }
+                continue;
+            }
             const char *gev = std::getenv("PCG_EBE_GREEDY_CHUNKS");                      // =0: Morton cells for every class (A/B)
             if (!C.cls[cls_of[g]].full && coords && !(gev && gev[0] == '0')) {
                 size_t lo_ = 0;
@@ -435,14 +477,16 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     // ---- exclusive / shared tile nodes, boundary slots, per-phase fix-up lists ----------------------------
     {
         std::vector<int32_t> cnt((size_t)n_nodes, 0);
-        for (int32_t nd : C.nodes) cnt[nd]++;
+        for (int32_t nd : C.nodes)
+            if (nd >= 0) cnt[nd]++;                                    // (-1: padding slot of a direct chunk)
         for (int64_t i = 0; i < n_nodes; ++i)
             if (cnt[i] == 0) { C.needs_zero = true; break; }
         // phase in which a shared node becomes final = max phase of the chunks that contain it
         std::vector<uint8_t> final_phase((size_t)n_nodes, 0);
         for (int64_t c = 0; c < C.n_chunks; ++c) {
             const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1];
-            for (int k = 0; k < nn; ++k) final_phase[C.nodes[off + k]] = std::max(final_phase[C.nodes[off + k]], chunk_phase[c]);
+            for (int k = 0; k < nn; ++k)
+                if (C.nodes[off + k] >= 0) final_phase[C.nodes[off + k]] = std::max(final_phase[C.nodes[off + k]], chunk_phase[c]);
         }
         std::vector<int32_t> sh_index((size_t)n_nodes, -1);           // index into sh_node of its final phase
         for (int64_t i = 0; i < n_nodes; ++i)
@@ -471,6 +515,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1];
             for (int k = 0; k < nn; ++k) {
                 const int32_t nd = C.nodes[off + k];
+                if (nd < 0) { C.dst[off + k] = INT32_MIN; continue; }
                 if (cnt[nd] == 1) { C.dst[off + k] = 3 * nd; continue; }
                 const int ph = final_phase[nd];
                 const int32_t slot = phase_base[ph] + fill[ph][sh_index[nd]]++;
@@ -483,6 +528,24 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             out.n_colors[ph] = std::max<int32_t>(out.n_colors[ph], launches);
         }
         if (!out.ranges[0].empty() || !out.ranges[1].empty()) C.needs_zero = true;   // other groups accumulate with +=
+        if (const char *sv = std::getenv("PCG_EBE_STATS"); sv && sv[0] == '1') {      // planner statistics (development aid)
+            std::vector<int64_t> tile_nodes(kChunkClasses, 0), shared_tile_nodes(kChunkClasses, 0);
+            for (int64_t c = 0; c < C.n_chunks; ++c) {
+                const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1], cl = C.hdr[(size_t)c * 8 + 6];
+                tile_nodes[cl] += nn;
+                for (int k = 0; k < nn; ++k) shared_tile_nodes[cl] += C.dst[off + k] < 0 && C.dst[off + k] != INT32_MIN;
+            }
+            std::vector<int64_t> elems(kChunkClasses, 0);
+            for (int g = 0; g < n_groups; ++g)
+                if (chunkable[g]) elems[cls_of[g]] += gs[g].ne;
+            for (int c = 0; c < kChunkClasses; ++c)
+                if (C.cls[c].n_chunks)
+                    fprintf(stderr, "ebe plan: class %d (<= %d nodes, %d slots/chunk): %lld elements in %lld chunks, %lld tile nodes (%lld to boundary slots)\n",
+                            c, C.cls[c].nnp, C.cls[c].ce, (long long)elems[c], (long long)C.cls[c].n_chunks, (long long)tile_nodes[c],
+                            (long long)shared_tile_nodes[c]);
+            fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots\n", (long long)n_nodes,
+                    (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots);
+        }
     }
 }
 

@@ -62,7 +62,7 @@ class HipBackend : public Backend {
     // chunked matrix-free operator
     struct ChunkClassDev {
         int nnp = 8, ept = 1;
-        bool full = false;
+        bool full = false, direct = false;
         int *list[2] = {nullptr, nullptr};
         int count[2] = {0, 0};
         unsigned short *lid = nullptr;
@@ -167,6 +167,7 @@ public:
         ls_ = st_;
         if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_streams_mode_ = atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("PCG_EBE_ROWS_LDS")) rows_lds_mode_ = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("PCG_EBE_XCD")) ebe_xcd_ = std::max(0, atoi(e));
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
         d_part_spmv_ = (double *)alloc(sizeof(double) * kMaxPartials);
         d_part_fix_ = (double *)alloc(sizeof(double) * kMaxPartials);
@@ -451,7 +452,7 @@ public:
             for (int c = 0; c < kChunkClasses; ++c) {
                 const auto &K = C.cls[c];
                 auto &D = chc_[c];
-                D.nnp = K.nnp; D.ept = K.ept; D.full = K.full;
+                D.nnp = K.nnp; D.ept = K.ept; D.full = K.full; D.direct = K.direct;
                 if (K.n_chunks == 0) continue;
                 up(D.lid, K.lid); up(D.ck, K.ck); up(D.sgn, K.sgn); up(D.ke, K.ke_col);
                 if (!K.ke_rows.empty()) up(D.ke_rows, K.ke_rows);
@@ -508,7 +509,7 @@ public:
                 std::copy(&K.lid[(size_t)kci * 8 * CE], &K.lid[(size_t)kci * 8 * CE] + 8 * CE, &lid[b * 8 * CE]);
             }
             hex_tab_[ph] = HexTab{(const int4 *)up(hdr), (const int *)up(nodes), (const int *)up(dst), (const unsigned short *)up(tslot),
-                                  (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn)};
+                                  (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn), ebe_xcd_};
             hex_nodes_host_[ph] = nodes;
             hex_tslot_host_[ph] = tslot;
         }
@@ -550,8 +551,8 @@ public:
     // (at most four workgroups per CU).  Measured on the octree mesh (profiles/r03_octree_rows_kernel_lds_ab_sessionI.log): 1 M dof
     // (a few hundred chunks per class) operator 106 -> 91 us, iteration 131 -> 115 us; 10 M dof (thousands of chunks: throughput-
     // bound, and every workgroup copies 18-41 KB of Ke for its 64 elements) 509 -> 568 us.  PCG_EBE_ROWS_LDS=0 / 1 overrides.
-    int rows_lds_mode_ = -1;
-    bool rows_lds_raised_[4] = {false, false, false, false};
+    int rows_lds_mode_ = -1, ebe_xcd_ = 64;     // PCG_EBE_XCD: 0 off, 1 contiguous eighths, G runs of G chunks (measured: 64)
+    bool rows_lds_raised_[4] = {false, false, false, false}, direct_raised_[4] = {false, false, false, false};
     template <int NNP>
     void launch_rows(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
@@ -574,6 +575,24 @@ public:
             if (dot) go(k_ebe_rows<NNP, true, false>, 0); else go(k_ebe_rows<NNP, false, false>, 0);
         }
     }
+    // hanging-node classes without a node tile: Ke(NDP x NDP) . U(NDP x 64) on the matrix cores, Ke in LDS (k_ebe_direct)
+    template <int NNP>
+    void launch_direct(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        constexpr int NDP = 3 * NNP;
+        const size_t lds = sizeof(double) * NDP * NDP;
+        const int slot = NNP == 16 ? 1 : NNP == 24 ? 2 : 3;
+        if (!direct_raised_[slot]) {                             // beyond the default dynamic-LDS window (per device: a member)
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_ebe_direct<NNP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_ebe_direct<NNP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            direct_raised_[slot] = true;
+        }
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(D.count[ph]), dim3(kChunkThreads), lds, ls_, D.list[ph], d_ch_hdr_, d_ch_nodes_, d_ch_dst_, D.ck,
+                               D.sgn, D.ke, x, y, d_ch_buf_, d_flags_, part, dot_lo, ebe_xcd_);
+        };
+        if (dot) go(k_ebe_direct<NNP, true>); else go(k_ebe_direct<NNP, false>);
+    }
     // -> number of dot partials the launch writes
     int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
@@ -588,9 +607,9 @@ public:
             if (D.full) throw std::runtime_error("hex8 class without its launch tables");
             launch_rows<8>(D, ph, x, y, dot, part, dot_lo);                          // fewer than 8 nodes, padded
             break;
-        case 16: launch_rows<16>(D, ph, x, y, dot, part, dot_lo); break;
-        case 24: launch_rows<24>(D, ph, x, y, dot, part, dot_lo); break;
-        default: launch_rows<32>(D, ph, x, y, dot, part, dot_lo); break;
+        case 16: if (D.direct) launch_direct<16>(D, ph, x, y, dot, part, dot_lo); else launch_rows<16>(D, ph, x, y, dot, part, dot_lo); break;
+        case 24: if (D.direct) launch_direct<24>(D, ph, x, y, dot, part, dot_lo); else launch_rows<24>(D, ph, x, y, dot, part, dot_lo); break;
+        default: if (D.direct) launch_direct<32>(D, ph, x, y, dot, part, dot_lo); else launch_rows<32>(D, ph, x, y, dot, part, dot_lo); break;
         }
         return D.count[ph];
     }

@@ -74,7 +74,25 @@ struct HexTab {
     const unsigned short *lid;    // [n][8][CE]
     const double *ck;             // [n][CE]
     const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
+    int xcd;                      // chunk = xcd_chunk(workgroup) instead of the workgroup index
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i -> XCD i % 8).  Consecutive chunks are spatial neighbours and share
+// the nodes on their common faces: with this mapping an XCD works through RUNS of consecutive chunks, so a neighbour's x lines are
+// in the XCD's own L2.  mode 1: XCD k takes the k-th contiguous eighth of the list; mode G >= 2: runs of G chunks dealt round-robin
+// (same locality inside a run, and the XCDs stay balanced where the cost of a chunk drifts along the list); 0: chunk = workgroup.
+__device__ __forceinline__ int xcd_chunk(int bid, int n, int mode)
+{
+    if (mode == 0) return bid;
+    const int xcd = bid & 7, idx = bid >> 3;
+    if (mode == 1) {
+        const int q = n >> 3, r = n & 7;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int grp = idx / mode, within = idx - grp * mode;
+    if ((grp + 1) * 8 * mode > n) return bid;                // the last, partial super-group keeps its order
+    return (grp * 8 + xcd) * mode + within;
+}
 
 __device__ __forceinline__ double flip_sign(double v, unsigned sg, int b)
 {
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hex(HexTab T, const d
     constexpr int CE = kChunkThreads * EPT, MAXN = kChunkThreads * NPT, ND = 24;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
     const int4 h = T.hdr[b];
     // ---- three independent groups of loads: element slots, node table, (header above) --------------------------
     unsigned sg[EPT];
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
     constexpr int SEQ = 2, NPT = 3, CE = kChunkThreads * SEQ, MAXN = kChunkThreads * NPT, ND = 24;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6;
+    const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
     const int4 h = T.hdr[b];
     unsigned sg;
     double c;
@@ -468,6 +486,117 @@ __global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
                 if ((fp[0] & 3) == 3) dot += xs[sl3[j]] * y0;
                 if ((fp[1] & 3) == 3) dot += xs[sl3[j] + 1] * y1;
                 if ((fp[2] & 3) == 3) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hanging-node pattern types WITHOUT a node tile, on the matrix cores: k_ebe_direct (round 3).
+// A tile pays when the elements of a chunk share nodes (8 x 8 x 8 hex8 cells: 729 nodes for 512 elements).  The elements of
+// ONE hanging-node pattern type do not: they lie scattered along the transition shells of an octree mesh, their neighbours are
+// of other types.  Measured on the graded octree mesh (planner statistics, PCG_EBE_STATS=1): 8.9 / 15.3 tile nodes per element
+// in the 16- / 24-node classes = no node is used twice, every tile node is shared with OTHER chunks and leaves through the
+// boundary slots anyway, and the tile's node limit keeps the chunks at 55 / 42 of 64 elements.  k_ebe_rows spent its time in the
+// chain chunk -> header -> node lists -> x -> LDS -> barrier -> ... -> LDS -> barrier -> y at 2 - 4 workgroups per CU (128 us per
+// class at 10 M dof for work that takes the arithmetic units 15 us; neither Ke from LDS, nor the matrix cores on the same tile
+// skeleton, nor dropping the ordered LDS accumulation changed that: profiles/r03_octree_rows_kernels_sessionO.md).
+// Here a chunk is 64 elements of one type and nothing else:
+//   * per element-node incidence the planner stores the node id and the destination (ebe.cpp: an incidence of a node that no
+//     other element touches goes straight to y, every other one to its own boundary slot; k_ebe_shared sums the slots of a node
+//     in a fixed order) - the chunk's part of `nodes` / `dst` is (local node, element slot)-major, 64 consecutive elements per
+//     local node: coalesced index loads;
+//   * Y(NDP x 64) = Ke(NDP x NDP) . U(NDP x 64) on v_mfma_f64_16x16x4_f64: wave w owns the elements 16 w .. 16 w + 15,
+//       A (16 x 4): lane l holds Ke[16 mt + col][4 ks + g]   (col = l & 15, g = l >> 4)  - LDS copy of Ke (one ds_read_b64 per
+//                   lane feeds a whole 16 x 4 tile; a broadcast read or a scalar load feeds ONE coefficient)
+//       B (4 x 16): lane l holds u[dof 4 ks + g] of element col                          - gathered from x, sign and Ck applied
+//       D (16x16):  lane l, register r holds y[dof 16 mt + g + 4 r] of element col
+//     so a lane gathers and scatters the SAME dofs {g, g + 4, g + 8, ...} of its element;
+//   * no LDS besides Ke (18 / 41 / 74 KB for 16 / 24 / 32 nodes), one barrier, no atomics: every output has its own address.
+// The f64 matrix cores of gfx950 run at the rate of the vector FMAs (78.6 TFLOP/s): the point is the operand supply and the
+// shape of the kernel, not the arithmetic peak.
+// ------------------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int NNP, bool DOT>
+__global__ __launch_bounds__(kChunkThreads, (NNP <= 16 ? 4 : NNP <= 24 ? 3 : 2)) void k_ebe_direct(
+    const int *__restrict__ chunk_list, const int4 *__restrict__ hdr, const int *__restrict__ nodes, const int *__restrict__ dstl,
+    const double *__restrict__ ck, const unsigned *__restrict__ sgn, const double *__restrict__ ke_col, const double *__restrict__ x,
+    double *__restrict__ y, double *__restrict__ buf, const uint8_t *__restrict__ flags, double *__restrict__ partials, long long dot_lo,
+    int xcd)
+{
+    constexpr int CE = 64, NDP = 3 * NNP, MT = (NDP + 15) / 16, KS = NDP / 4, W = NDP / 32 + 1;
+    static_assert(NDP % 4 == 0, "whole k-steps");
+    extern __shared__ __align__(16) double ks_lds[];         // Ke, column-major: ks_lds[b * NDP + a] = Ke[a][b]
+    const int chunk = chunk_list[xcd_chunk(blockIdx.x, gridDim.x, xcd)];
+    const int4 h = hdr[2 * chunk];                           // entry offset, -, -, ke index in class
+    const int4 h2 = hdr[2 * chunk + 1];                      // chunk index in class, nd, class, 16-element tiles in use
+    const int kci = h2.x, nd = h2.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int e = 16 * wave + col;                           // element slot of this lane (four lanes per element)
+    {                                                        // Ke -> LDS (L2 hits: every chunk of the type reads the same matrix)
+        const double2 *src = reinterpret_cast<const double2 *>(ke_col + (size_t)h.w * NDP * NDP);
+        double2 *dst2 = reinterpret_cast<double2 *>(ks_lds);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < NDP * NDP / 2; i += kChunkThreads) dst2[i] = src[i];
+    }
+    unsigned sg[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) sg[w] = ntload(sgn + ((size_t)kci * W + w) * CE + e);
+    const double c = ntload(ck + (size_t)kci * CE + e);      // 0 for padding slots
+    auto sign_bit = [&](int d) -> unsigned {                 // d is not a compile-time constant (g): select the word
+        unsigned word = sg[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) word = (d >> 5) == w ? sg[w] : word;
+        return (word >> (d & 31)) & 1u;
+    };
+    const int *my_nodes = nodes + h.x + e, *my_dst = dstl + h.x + e;
+    double xv[KS];                                           // x at the dofs g + 4 m of this lane's element (signed, times Ck)
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        const unsigned d = g + 4 * m, k = d / 3;
+        int node = -1;
+        if ((int)d < nd) node = ntload(my_nodes + k * CE);   // -1: padding slot
+        xv[m] = node >= 0 ? x[3 * (size_t)node + (d - 3 * k)] : 0.0;                                      // :277 gather
+    }
+    __syncthreads();
+    d4_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (wave < h2.w) {                                       // 16-element tiles in use (the last chunk of a type may be short)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = 4 * ks + g;
+            const double u = c * (sign_bit(d) ? -xv[ks] : xv[ks]);                                        // :278-279 sign, Ck
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int a = 16 * mt + col;                 // rows beyond NDP (last tile of 24 / 72): zero
+                const double kv = (16 * mt + 15 < NDP || a < NDP) ? ks_lds[d * NDP + a] : 0.0;
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, u, acc[mt], 0, 0, 0);                  // :279 Ke @ (.)
+            }
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        const unsigned d = g + 4 * m, k = d / 3;
+        if ((int)d < nd) {
+            const int dc = ntload(my_dst + k * CE);          // >= 0: y offset of the node; < 0: -(boundary slot + 1); INT_MIN: padding
+            if (dc != INT_MIN) {
+                const double a = acc[m / 4][m % 4];
+                const double o = sign_bit(d) ? -a : a;                                                    // :280
+                const int comp = d - 3 * k;
+                double *out = dc >= 0 ? y + dc + comp : buf + 3 * (size_t)(-dc - 1) + comp;
+                *out = o;                                                                                  // :300 (summed by k_ebe_shared)
+                if (DOT && dc >= 0 && dc + comp >= dot_lo && (flags[dc + comp] & 3) == 3) dot += x[dc + comp] * o;   // fused p.Ap.w (:487)
             }
         }
     }

@@ -670,10 +670,11 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         {   // bytes one apply moves, from the uploaded structures (Ke itself stays in the scalar / L2 caches)
             double b = 0, f = 0;
             const auto &Ch = m.chunked;
-            b += 34.0 * (double)Ch.nodes.size();             // per tile node: id 4 + dst 4 + slot 2, x tile in 24
+            b += 34.0 * (double)(Ch.nodes.size() - Ch.direct_entries);   // per tile node: id 4 + dst 4 + slot 2, x tile in 24
+            b += 32.0 * (double)Ch.direct_entries;           // per incidence of a chunk without a tile: id 4 + dst 4, x in 24
             b += 24.0 * (double)Ch.nodes.size();             //                y (exclusive) or boundary slot out 24
-            for (const auto &K : Ch.cls)                     // per element slot: local node ids, Ck, sign words
-                b += (double)K.n_chunks * K.ce * (2.0 * K.nnp + 8.0 + 4.0 * K.words);
+            for (const auto &K : Ch.cls)                     // per element slot: local node ids (tile classes), Ck, sign words
+                b += (double)K.n_chunks * K.ce * ((K.direct ? 0.0 : 2.0 * K.nnp) + 8.0 + 4.0 * K.words);
             b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
             for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size();   // ... y out 24 + node id + run pointer
             b += 32.0 * (double)Ch.n_chunks;                 // chunk headers

@@ -120,6 +120,9 @@ struct EbeClassHost {
                                        // LANE; the four waves of the workgroup contract a quarter of the output rows each)
     int32_t words = 1;                 // sign words per element = NDP/32 + 1; bits 24..31 of the last word = sub-colour
     int32_t max_nodes = kChunkMaxNodes; // tile nodes a chunk of this class may have (512 for the 256-element hex8 chunks)
+    bool direct = false;               // no node tile (k_ebe_direct): the chunk's part of `nodes` / `dst` is per element-node INCIDENCE,
+                                       // (local node, element slot)-major with 64 slots per local node, -1 / INT_MIN in padding slots;
+                                       // lid is empty and tslot unused.  The 16- / 24- / 32-node classes unless PCG_EBE_DIRECT=0.
     int64_t n_chunks = 0;
     std::vector<uint16_t> lid;         // (n_chunks, nnp, ce) local node index of element-node l (0 for padding)
     std::vector<double> ck;            // (n_chunks, ce)   (0 for padding slots)
@@ -137,7 +140,8 @@ struct EbeChunkedHost {
     std::vector<uint16_t> tslot;       // same shape: slot of the node in the chunk's LDS tile (what `lid` refers to); the
                                        // slot order is chosen against LDS bank conflicts, see ebe.cpp tile_key
     std::vector<int32_t> dst;          // same shape: >= 0: y offset 3*node (exclusive node); < 0: -(boundary slot + 1)
-    int64_t n_slots = 0;               // boundary-buffer slots (one per (chunk, shared node))
+    int64_t n_slots = 0;               // boundary-buffer slots (one per (chunk, shared node); one per incidence in direct chunks)
+    int64_t direct_entries = 0;        // entries of `nodes` that belong to direct chunks (incl. padding slots)
     std::vector<int32_t> sh_node[2];   // per phase: shared nodes whose sum becomes final after that phase (ascending)
     std::vector<int32_t> sh_ptr[2];    //            CSR over their slots
     std::vector<int32_t> sh_slot[2];   //            slots in ascending chunk order; node-major numbering: sh_slot[ph][q] ==

@@ -59,6 +59,31 @@ public:
                 const int CE = K.ce, W = K.words, ndp = 3 * K.nnp;
                 const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
                 acc.assign((size_t)nd * CE, 0.0);
+                if (K.direct) {                                        // no node tile: one entry of nodes / dst per element-node incidence
+                    for (int lane = 0; lane < CE; ++lane) {
+                        if (C.nodes[off + lane] < 0) continue;          // padding slot
+                        const double c = K.ck[(size_t)kci * CE + lane];
+                        auto sb = [&](int a) { return (K.sgn[((size_t)kci * W + a / 32) * CE + lane] >> (a % 32)) & 1u; };
+                        double *a = &acc[(size_t)lane * nd];
+                        for (int b = 0; b < nd; ++b) {
+                            double v = x[3 * (int64_t)C.nodes[off + (size_t)(b / 3) * CE + lane] + b % 3];
+                            if (sb(b)) v = -v;
+                            v = c * v;
+                            for (int k = 0; k < nd; ++k) a[k] += Kc[(size_t)b * ndp + k] * v;
+                        }
+                        for (int k = 0; k < nd; ++k) {
+                            const int32_t dst = C.dst[off + (size_t)(k / 3) * CE + lane];
+                            const double o = sb(k) ? -a[k] : a[k];
+                            if (dst >= 0) {
+                                y[dst + k % 3] = o;
+                                if (fuse && dst + k % 3 >= dot_lo && own_free(dst + k % 3)) dot_spmv_ += x[dst + k % 3] * o;
+                            } else {
+                                ebuf_[(size_t)(-(int64_t)dst - 1) * 3 + k % 3] = o;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 for (int n = 0; n < nn; ++n)
                     for (int d = 0; d < 3; ++d) { xs[3 * C.tslot[off + n] + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
                 auto sbit = [&](int lane, int a) { return (K.sgn[((size_t)kci * W + a / 32) * CE + lane] >> (a % 32)) & 1u; };
