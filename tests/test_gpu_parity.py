@@ -597,6 +597,36 @@ def test_graded_octree_1m_dof(gpu_lib, oracle_c, kind):
         print("graded octree 1 M dof, matrix-free:", op.operator_info())
 
 
+@pytest.mark.gpu
+def test_hanging_node_kernels_with_and_without_node_tile_agree(gpu_lib, monkeypatch):
+    """The 16- / 24-node pattern classes run k_ebe_direct (no node tile, f64 matrix cores) by default and k_ebe_rows (LDS node
+    tile, vector FMAs) with PCG_EBE_DIRECT=0: same mat-vec (<= 1e-13 of each other and of the assembled operator), same fused
+    p.Ap, same solve (Flag, iteration count, solution <= 1e-9) on a three-level graded octree mesh; the planner puts every
+    element of those classes into full 64-element chunks."""
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    P0 = make_octree_parts(GradedOctreeMesh((4, 4, 4), 3, band=1.2), 1)[0]
+    x = None
+    res = {}
+    for tag, kind, direct in (("sell", "sell", None), ("tile", "ebe", "0"), ("direct", "ebe", "1")):
+        if direct is None: monkeypatch.delenv("PCG_EBE_DIRECT", raising=False)
+        else: monkeypatch.setenv("PCG_EBE_DIRECT", direct)
+        P = copy.deepcopy(P0)
+        pm.configure(comm=None, device=0, operator=kind)
+        op = pm.get_operator(P)
+        if x is None:
+            x = np.random.default_rng(11).standard_normal(op.n)
+        y = np.array(op.apply(x))
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+        res[tag] = (y, P["GlobData"]["TimeList_Flag"][1], P["GlobData"]["TimeList_Iter"][1], np.array(P["Un"]), op.operator_info())
+    pm.configure(comm=None, device=0, operator="sell")
+    for a in ("tile", "direct"):
+        assert relerr(res[a][0], res["sell"][0]) < 1e-13
+        assert res[a][1] == res["sell"][1] == 0 and abs(res[a][2] - res["sell"][2]) <= 2
+        assert relerr(res[a][3], res["sell"][3]) < 1e-9
+    assert relerr(res["direct"][0], res["tile"][0]) < 1e-13
+    assert res["direct"][4]["n_chunks"] <= res["tile"][4]["n_chunks"]      # full chunks: never more than with the tile limits
+
+
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 @pytest.mark.parametrize("case", ["n9_p2", "n9_p8", "n9_p2_flag4", "oct_p3", "oct_p2_z", "goct_p4"])
 def test_multi_part_kernels_on_one_gpu(gpu_lib, case, kind):
