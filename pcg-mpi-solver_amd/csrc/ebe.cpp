@@ -532,17 +532,19 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             std::vector<int64_t> tile_nodes(kChunkClasses, 0), shared_tile_nodes(kChunkClasses, 0);
             for (int64_t c = 0; c < C.n_chunks; ++c) {
                 const int32_t off = C.hdr[(size_t)c * 8], nn = C.hdr[(size_t)c * 8 + 1], cl = C.hdr[(size_t)c * 8 + 6];
-                tile_nodes[cl] += nn;
-                for (int k = 0; k < nn; ++k) shared_tile_nodes[cl] += C.dst[off + k] < 0 && C.dst[off + k] != INT32_MIN;
+                for (int k = 0; k < nn; ++k) {                      // (direct chunks: element-node incidences, padding slots skipped)
+                    tile_nodes[cl] += C.nodes[off + k] >= 0;
+                    shared_tile_nodes[cl] += C.dst[off + k] < 0 && C.dst[off + k] != INT32_MIN;
+                }
             }
             std::vector<int64_t> elems(kChunkClasses, 0);
             for (int g = 0; g < n_groups; ++g)
                 if (chunkable[g]) elems[cls_of[g]] += gs[g].ne;
             for (int c = 0; c < kChunkClasses; ++c)
                 if (C.cls[c].n_chunks)
-                    fprintf(stderr, "ebe plan: class %d (<= %d nodes, %d slots/chunk): %lld elements in %lld chunks, %lld tile nodes (%lld to boundary slots)\n",
-                            c, C.cls[c].nnp, C.cls[c].ce, (long long)elems[c], (long long)C.cls[c].n_chunks, (long long)tile_nodes[c],
-                            (long long)shared_tile_nodes[c]);
+                    fprintf(stderr, "ebe plan: class %d (<= %d nodes, %d slots/chunk%s): %lld elements in %lld chunks, %lld %s (%lld to boundary slots)\n",
+                            c, C.cls[c].nnp, C.cls[c].ce, C.cls[c].direct ? ", no node tile" : "", (long long)elems[c], (long long)C.cls[c].n_chunks, (long long)tile_nodes[c],
+                            C.cls[c].direct ? "element-node incidences" : "tile nodes", (long long)shared_tile_nodes[c]);
             fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots\n", (long long)n_nodes,
                     (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots);
         }

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_ebe_rows(
 // A tile pays when the elements of a chunk share nodes (8 x 8 x 8 hex8 cells: 729 nodes for 512 elements).  The elements of
 // ONE hanging-node pattern type do not: they lie scattered along the transition shells of an octree mesh, their neighbours are
 // of other types.  Measured on the graded octree mesh (planner statistics, PCG_EBE_STATS=1): 8.9 / 15.3 tile nodes per element
-// in the 16- / 24-node classes = no node is used twice, every tile node is shared with OTHER chunks and leaves through the
+// for 11.3 / 18.4 incidences in the 16- / 24-node classes (a fifth re-used inside the chunk), every tile node is shared with OTHER chunks and leaves through the
 // boundary slots anyway, and the tile's node limit keeps the chunks at 55 / 42 of 64 elements.  k_ebe_rows spent its time in the
 // chain chunk -> header -> node lists -> x -> LDS -> barrier -> ... -> LDS -> barrier -> y at 2 - 4 workgroups per CU (128 us per
 // class at 10 M dof for work that takes the arithmetic units 15 us; neither Ke from LDS, nor the matrix cores on the same tile
