@@ -194,7 +194,8 @@ public:
         (void)hipSetDevice(dev_);
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
-                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_ptr4_})
+                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
+                        (void *)d_ov_vals_, (void *)d_ov_mask_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke, (void *)D.ke_rows})
@@ -349,6 +350,18 @@ public:
         }
         h2d(d_diag_, m.diag.data(), sizeof(double) * m.diag.size());
         nb_dofs_ = std::min<int64_t>(n_, n_bnd_slices_ * C_ * m.bs);
+        if (m.ov_slices > 0) {                              // split matrix: the overflow part (k_spmv_ovf)
+            ov_slices_ = m.ov_slices; ov_bnd_slices_ = m.ov_bnd_slices;
+            auto up = [&](auto *&dst, const auto &v) {
+                using T = std::remove_reference_t<decltype(*dst)>;
+                dst = (T *)alloc(sizeof(v[0]) * std::max<size_t>(1, v.size()));
+                h2d(dst, v.data(), sizeof(v[0]) * v.size());
+            };
+            up(d_ov_slice_ptr_, m.ov_slice_ptr); up(d_ov_rows_, m.ov_rows); up(d_ov_cols_, m.ov_cols); up(d_ov_vals_, m.ov_vals);
+            static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "mask words");
+            d_ov_mask_ = (unsigned long long *)alloc(sizeof(uint64_t) * m.ov_mask.size());
+            h2d(d_ov_mask_, m.ov_mask.data(), sizeof(uint64_t) * m.ov_mask.size());
+        }
     }
     // Where the value array lands physically is not the engine's choice, and it matters: the identical launch ran at 1.05 and at
     // 1.22 ms in consecutive processes on ONE box, and FOUR allocations of the same 6.5 GB array inside one process gave 1.124 /
@@ -771,11 +784,34 @@ public:
     {
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_);
         else
             hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2));
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_);
     }
+    // overflow part of a split matrix (k_spmv_ovf) for the base slices [lo, hi): its partials follow those of the base launch
+    int launch_overflow(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int part_off)
+    {
+        if (ov_slices_ == 0) return 0;
+        int64_t olo, ohi;
+        if (lo == 0) olo = 0; else if (lo == n_bnd_slices_) olo = ov_bnd_slices_; else throw std::runtime_error("spmv: slice range does not match the overflow part");
+        if (hi == n_slices_) ohi = ov_slices_; else if (hi == n_bnd_slices_) ohi = ov_bnd_slices_; else throw std::runtime_error("spmv: slice range does not match the overflow part");
+        if (ohi <= olo) return 0;
+        const int grid = spmv_grid(ohi - olo);
+        if (part_off + grid > kMaxPartials) throw std::runtime_error("spmv: too many dot partials");
+        if (dot)
+            hipLaunchKernelGGL((k_spmv_ovf<true>), dim3(grid), dim3(kBlock), 0, st_, d_ov_slice_ptr_, d_ov_rows_, d_ov_cols_, d_ov_vals_, x, y,
+                               d_flags_, d_part_spmv_ + part_off, olo, ohi);
+        else
+            hipLaunchKernelGGL((k_spmv_ovf<false>), dim3(grid), dim3(kBlock), 0, st_, d_ov_slice_ptr_, d_ov_rows_, d_ov_cols_, d_ov_vals_, x, y,
+                               d_flags_, d_part_spmv_ + part_off, olo, ohi);
+        return grid;
+    }
+    int64_t ov_slices_ = 0, ov_bnd_slices_ = 0;
+    int64_t *d_ov_slice_ptr_ = nullptr;
+    int *d_ov_rows_ = nullptr, *d_ov_cols_ = nullptr;
+    double *d_ov_vals_ = nullptr;
+    unsigned long long *d_ov_mask_ = nullptr;
     int col_index_bytes() const override { return d_cols16_ ? 2 : 4; }
     void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
     {
@@ -786,9 +822,10 @@ public:
         last_spmv_grid_ = grid;
         if (C_ == 64) launch_spmv<1>(x, y, lo, hi, with_dot, grid);
         else launch_spmv<2>(x, y, lo, hi, with_dot, grid);
+        const int ov_grid = launch_overflow(x, y, lo, hi, with_dot, last_spmv_grid_);
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (hi == n_slices_) ++ev_applies_; }
-        if (with_dot) cnt_spmv_ = last_spmv_grid_;          // (the dictionary kernel may have launched a smaller grid)
+        if (with_dot) cnt_spmv_ = last_spmv_grid_ + ov_grid;   // (the dictionary kernel may have launched a smaller grid)
     }
     void halo_pack(const double *y, double *send) override
     {

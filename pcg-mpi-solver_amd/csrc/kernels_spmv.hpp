@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                                                  const double *__restrict__ vals, const double *__restrict__ x,
                                                  double *__restrict__ y, const uint8_t *__restrict__ flags,
                                                  double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
-                                                 int64_t n_nodes, int xcd_aware)
+                                                 int64_t n_nodes, int xcd_aware, const unsigned long long *__restrict__ ov_mask)
 {
     constexpr int C = 64 * RPL;
     using DV = typename VecT<RPL>::d;
@@ -85,12 +85,68 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                     __builtin_nontemporal_store(acc[h][2], yp + 2);
                 } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
                 if constexpr (DOT) {
+                    // (a row that continues in the overflow part is not final here: k_spmv_ovf adds its term)
+                    const bool final_here = RPL != 1 || ov_mask == nullptr || ((ov_mask[s] >> lane) & 1ull) == 0;
                     const uint8_t *fp = flags + 3 * row;
                     const double *xp = x + 3 * row;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
-                        if ((fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
+                        if (final_here && (fp[a] & 3) == 3) dot += xp[a] * acc[h][a];
                 }
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// Overflow part of a split SELL matrix (SellHost::ov_*, sell.cpp split_overflow): the rows that are longer than their slice's
+// base width, compacted, 64 per slice.  A lane RESUMES the sum of its row from the y that k_spmv stored and continues through
+// the remaining block columns in their original order with the same three fused multiply-adds per component: y ends up with
+// the bits of the unsplit matrix.  The fused p.Ap term of these rows is formed here (k_spmv leaves them out).
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_ovf(const int64_t *__restrict__ slice_ptr, const int *__restrict__ rows,
+                                                     const int *__restrict__ cols, const double *__restrict__ vals,
+                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                     const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                     int64_t slice_lo, int64_t slice_hi)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
+    double dot = 0.0;
+    for (int64_t s = slice_lo + (int64_t)blockIdx.x * kWavesPerBlock + wid; s < slice_hi; s += wstride) {
+        const int64_t base = slice_ptr[s];
+        const int w = (int)(slice_ptr[s + 1] - base);
+        const int row = ntload(rows + s * 64 + lane);
+        const double *vp = vals + (size_t)base * 9 * 64 + lane;
+        const int *cp = cols + (size_t)base * 64 + lane;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (row >= 0) { acc[0] = y[3 * (size_t)row]; acc[1] = y[3 * (size_t)row + 1]; acc[2] = y[3 * (size_t)row + 2]; }
+#pragma unroll 3
+        for (int k = 0; k < w; ++k) {
+            const int j = ntload(cp + (size_t)k * 64);
+            double v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
+            const double *xp = x + 3 * (size_t)j;
+            const v2d_a8 x01 = *reinterpret_cast<const v2d_a8 *>(xp);
+            const double x0 = x01.x, x1 = x01.y, x2 = xp[2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+        }
+        if (row >= 0) {
+            double *yp = y + 3 * (size_t)row;
+            yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+            if constexpr (DOT) {
+                const uint8_t *fp = flags + 3 * (size_t)row;
+                const double *xr = x + 3 * (size_t)row;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
             }
         }
     }

@@ -50,7 +50,7 @@ struct pcg_engine {
     int32_t C = 64;
     int32_t kind = 0;                 // 0 = assembled SELL-BSR3 operator, 1 = matrix-free (EBE)
     int64_t n_bnd_dofs = 0;           // dofs [0, n_bnd_dofs) may receive interface contributions
-    int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0;
+    int64_t nnzb = 0, stored_blocks = 0, n_elem = 0, n_slots = 0, ov_slices = 0;
     int64_t n_unique = 0;             // distinct 3x3 blocks when the values are dictionary-compressed (0: plain values)
     int64_t n_dict_lds = 0;           // ... of which the SpMV kernel keeps the most frequent ones in LDS
     double dict_lds_share = 0;        // ... share of the stored blocks those cover
@@ -480,7 +480,7 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
     e->n_bnd_dofs = std::min<int64_t>(3 * n_nodes, m.n_bnd_slices * m.C * 3);
     e->C = m.C;
     e->nnzb = m.nnzb;
-    e->stored_blocks = m.slice_ptr.back() * m.C;
+    e->stored_blocks = (m.slice_ptr.back() + (m.ov_slices ? m.ov_slice_ptr.back() : 0)) * m.C;
     e->op_flops = 18.0 * (double)m.nnzb;
     if (std::getenv("PCG_MATRIX_FINGERPRINT")) {            // tests: two construction paths must produce the same operator
         auto fnv = [](uint64_t h, const void *p, size_t n) {
@@ -496,6 +496,10 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
         h = fnv(h, m.dict.data(), m.dict.size() * sizeof(double));
         h = fnv(h, m.dict_count.data(), m.dict_count.size() * sizeof(int64_t));
         h = fnv(h, m.diag.data(), m.diag.size() * sizeof(double));
+        h = fnv(h, m.ov_slice_ptr.data(), m.ov_slice_ptr.size() * sizeof(int64_t));
+        h = fnv(h, m.ov_rows.data(), m.ov_rows.size() * sizeof(int32_t));
+        h = fnv(h, m.ov_cols.data(), m.ov_cols.size() * sizeof(int32_t));
+        h = fnv(h, m.ov_vals.data(), m.ov_vals.size() * sizeof(double));
         e->fingerprint = h;
     }
     e->be->upload_matrix(m);
@@ -503,6 +507,10 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
     // once, the slice pointers
     const int cb = e->be->col_index_bytes();
     e->op_bytes = (72.0 + cb) * (double)e->stored_blocks + 16.0 * (double)e->n + (cb == 2 ? 12.0 : 8.0) * (double)(m.n_slices + 1);
+    if (m.ov_slices > 0)          // overflow part: 32-bit columns, a row id + y read back and written again per row, slice pointers, masks
+        e->op_bytes += (4.0 - cb) * (double)m.ov_slice_ptr.back() * m.C + 52.0 * 64.0 * (double)m.ov_slices + 8.0 * (double)(m.ov_slices + 1) +
+                       8.0 * (double)m.n_slices;
+    e->ov_slices = m.ov_slices;
     if (e->n_unique > 0) {
         e->n_dict_lds = std::min<int64_t>(e->n_unique, e->be->dict_lds_entries());
         double hot = 0, all = 0;
@@ -521,6 +529,19 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
     e->be->upload_masks(f.data(), e->n);
     *out = e.release();
     return 0;
+}
+
+// plain format: rows much longer than their slice's typical row continue in an overflow part (sell.cpp split_overflow; octree
+// meshes: 55 % of the stored blocks were padding).  PCG_SELL_SPLIT=0 keeps the single SELL matrix; =1 splits whenever any block goes.
+static void maybe_split(SellHost &m)
+{
+    if (!m.bidx.empty() || m.bs != 3 || m.C != 64) return;
+    double min_saving = 0.10;
+    if (const char *ev = std::getenv("PCG_SELL_SPLIT")) {
+        if (std::atoi(ev) == 0) return;
+        min_saving = 1e-9;
+    }
+    (void)split_overflow(m, min_saving, 16);
 }
 
 // format flag in rows_per_lane: bit 8 = replace the values by a dictionary of the matrix's distinct 3x3 blocks when there are
@@ -554,6 +575,7 @@ int pcg_create(int32_t device, int64_t n_nodes, const int64_t *rowptr, const int
         SellHost m;
         bsr_to_sell(n_nodes, rowptr, cols, vals, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, 8, m);
         if (want_dict) (void)compress_blocks(m, cap, 16);   // false: too many distinct blocks - the plain format stays
+        maybe_split(m);
         return finish_create(std::move(e), m, out);
     });
 }
@@ -578,6 +600,7 @@ int pcg_create_asm(int32_t device, const pcg_asm *a, int64_t n_boundary_nodes, i
         SellHost m;
         if (want_dict && asm_to_sell(a, n_boundary_nodes, 1, true, cap, m)) return finish_create(std::move(e), m, out);
         (void)asm_to_sell(a, n_boundary_nodes, rows_per_lane > 0 ? rows_per_lane : 1, false, cap, m);   // plain values (or too many distinct blocks)
+        maybe_split(m);
         return finish_create(std::move(e), m, out);
     });
 }

@@ -40,7 +40,23 @@ struct SellHost {
     std::vector<double> dict;             // most frequent block first
     std::vector<int64_t> dict_count;      // stored blocks per entry (descending)
     int64_t n_unique() const { return (int64_t)(dict.size() / 9); }
+    // Overflow part (split_overflow; plain format, C = 64): a slice stores only its first wb block columns (the slice pointers say
+    // so); rows longer than that CONTINUE in a second SELL matrix over the compacted list of those rows, in the same column order
+    // (k_spmv_ovf resumes from the y the base part left: the sum of a row is formed in the order of the unsplit matrix).
+    int64_t ov_slices = 0, ov_bnd_slices = 0;   // overflow slices [0, ov_bnd_slices) hold rows of the base slices [0, n_bnd_slices)
+    std::vector<int64_t> ov_slice_ptr;          // block columns per overflow slice (prefix sums)
+    std::vector<int32_t> ov_rows;               // (ov_slices, 64): the row of each lane, -1 = padding lane
+    std::vector<int32_t> ov_cols;               // like cols
+    std::vector<double> ov_vals;                // like vals
+    std::vector<uint64_t> ov_mask;              // per base slice: lanes whose row continues in the overflow part
 };
+
+// Octree meshes put rows of 27 ... 99 blocks side by side in every 64-row slice: SELL pads them all to the longest (55 % of the
+// stored blocks at 1 M / 10 M dof).  split_overflow picks per slice the base width that minimises (stored base blocks + 1.5 x
+// overflow blocks), moves the rest of the longer rows into the overflow part (rows sorted by excess length inside windows of 512
+// overflow rows: the padding of THAT matrix) and compacts the base arrays in place.  Returns false and leaves `m` unchanged when
+// less than `min_saving` of the stored blocks would go (bricks).  Row sums keep their order: results are bit-identical.
+bool split_overflow(SellHost &m, double min_saving, int n_threads);
 
 void csr_to_sell1(int64_t n, const int64_t *rowptr, const int32_t *cols, const double *vals, int64_t n_boundary_rows,
                   int n_threads, SellHost &out);

@@ -1,6 +1,7 @@
 // 3x3-block CSR -> SELL-C layout used by the SpMV kernel (see SellHost in pcg_internal.hpp),
 // plus the small shared utilities (error string, interface fix-up lists).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
@@ -69,6 +70,126 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
         }
         for (auto &t : th) t.join();
     }
+}
+
+bool split_overflow(SellHost &m, double min_saving, int n_threads)
+{
+    if (m.bs != 3 || m.C != 64 || m.ov_slices != 0 || m.n_slices == 0) return false;
+    const int C = 64;
+    const int64_t S = m.n_slices, tot = m.slice_ptr[S];
+    if (m.vals.size() != (size_t)tot * C * 9) return false;                  // plain format only
+    // effective row lengths: trailing all-zero blocks are padding (or contribute nothing)
+    std::vector<int32_t> len((size_t)S * C, 0);
+    auto scan = [&](int64_t s_lo, int64_t s_hi) {
+        for (int64_t s = s_lo; s < s_hi; ++s) {
+            const int64_t base = m.slice_ptr[s], w = m.slice_ptr[s + 1] - base;
+            int32_t *ln = &len[(size_t)s * C];
+            for (int64_t k = 0; k < w; ++k)
+                for (int c = 0; c < 9; ++c) {
+                    const double *v = &m.vals[((size_t)(base + k) * 9 + c) * C];
+                    for (int l = 0; l < C; ++l)
+                        if (v[l] != 0.0) ln[l] = (int32_t)(k + 1);
+                }
+        }
+    };
+    {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, S / 64 + 1));
+        std::vector<std::thread> th;
+        const int64_t chunk = (S + nt - 1) / nt;
+        for (int t = 1; t < nt; ++t)
+            if (t * chunk < S) th.emplace_back(scan, t * chunk, std::min(S, (t + 1) * chunk));
+        scan(0, std::min(S, chunk));
+        for (auto &t : th) t.join();
+    }
+    // base width per slice: min over w of 64 w + f sum(max(0, len - w)), w among the row lengths of the slice
+    double f = 1.5;                                                          // development knobs (tools/iter_ab.py)
+    size_t window = 512;
+    if (const char *ev = std::getenv("PCG_SELL_SPLIT_F")) f = std::max(0.5, std::atof(ev));
+    if (const char *ev = std::getenv("PCG_SELL_SPLIT_WINDOW")) window = (size_t)std::max(64, std::atoi(ev));
+    std::vector<int32_t> wb((size_t)S, 0);
+    int64_t base_cols = 0, excess = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        int32_t srt[64];
+        std::copy(&len[(size_t)s * C], &len[(size_t)s * C] + C, srt);
+        std::sort(srt, srt + C);
+        int64_t suffix = 0;                                                  // sum of the lengths above position i
+        double best = -1;
+        int32_t best_w = srt[C - 1];
+        for (int i = C - 1; i >= 0; --i) {
+            if (i == C - 1 || srt[i] != srt[i + 1]) {
+                const double cost = 64.0 * srt[i] + f * (double)(suffix - (int64_t)(C - 1 - i) * srt[i]);
+                if (best < 0 || cost < best) { best = cost; best_w = srt[i]; }
+            }
+            suffix += srt[i];
+        }
+        wb[s] = best_w;
+        base_cols += best_w;
+        for (int l = 0; l < C; ++l) excess += std::max(0, len[(size_t)s * C + l] - best_w);
+    }
+    if ((double)base_cols * C + 1.3 * (double)excess > (1.0 - min_saving) * (double)tot * C) return false;
+    // overflow rows: ascending row order, the interface rows' slices first; windows of 512 rows sorted by excess (stable)
+    struct Row { int32_t row, exc; };
+    std::vector<Row> rows;
+    m.ov_slice_ptr.assign(1, 0);
+    m.ov_mask.assign((size_t)S, 0);
+    auto emit_range = [&](int64_t s_lo, int64_t s_hi) {
+        rows.clear();
+        for (int64_t s = s_lo; s < s_hi; ++s)
+            for (int l = 0; l < C; ++l) {
+                const int32_t e = len[(size_t)s * C + l] - wb[s];
+                if (e > 0) { rows.push_back(Row{(int32_t)(s * C + l), e}); m.ov_mask[s] |= 1ull << l; }
+            }
+        for (size_t a = 0; a < rows.size(); a += window)
+            std::stable_sort(rows.begin() + a, rows.begin() + std::min(rows.size(), a + window), [](const Row &x, const Row &y) { return x.exc > y.exc; });
+        for (size_t a = 0; a < rows.size(); a += C) {
+            const size_t b = std::min(rows.size(), a + C);
+            int32_t w = 0;
+            for (size_t q = a; q < b; ++q) w = std::max(w, rows[q].exc);
+            const int64_t ob = m.ov_slice_ptr.back();
+            m.ov_slice_ptr.push_back(ob + w);
+            m.ov_rows.resize(m.ov_rows.size() + C, -1);
+            m.ov_cols.resize((size_t)(ob + w) * C, 0);
+            m.ov_vals.resize((size_t)(ob + w) * C * 9, 0.0);
+            int32_t *orow = &m.ov_rows[m.ov_rows.size() - C];
+            for (int l = 0; l < C; ++l) {
+                const bool live = a + l < b;
+                const int32_t r = live ? rows[a + l].row : rows[b - 1].row;  // padding lanes: zero blocks at a valid column
+                if (live) orow[l] = r;
+                const int64_t sb = m.slice_ptr[r / C] + wb[r / C];
+                for (int32_t j = 0; j < w; ++j) {
+                    const size_t dq = (size_t)(ob + j) * C + l;
+                    if (live && j < rows[a + l].exc) {
+                        m.ov_cols[dq] = m.cols[(size_t)(sb + j) * C + r % C];
+                        for (int c = 0; c < 9; ++c)
+                            m.ov_vals[((size_t)(ob + j) * 9 + c) * C + l] = m.vals[((size_t)(sb + j) * 9 + c) * C + r % C];
+                    } else {
+                        m.ov_cols[dq] = r;
+                    }
+                }
+            }
+        }
+    };
+    emit_range(0, m.n_bnd_slices);
+    m.ov_bnd_slices = (int64_t)m.ov_slice_ptr.size() - 1;
+    emit_range(m.n_bnd_slices, S);
+    m.ov_slices = (int64_t)m.ov_slice_ptr.size() - 1;
+    // compact the base arrays in place (a slice keeps its first wb block columns)
+    int64_t dst = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        const int64_t src = m.slice_ptr[s];
+        if (dst != src && wb[s] > 0) {
+            std::memmove(&m.cols[(size_t)dst * C], &m.cols[(size_t)src * C], sizeof(int32_t) * (size_t)wb[s] * C);
+            std::memmove(&m.vals[(size_t)dst * C * 9], &m.vals[(size_t)src * C * 9], sizeof(double) * (size_t)wb[s] * C * 9);
+        }
+        m.slice_ptr[s] = dst;
+        dst += wb[s];
+    }
+    m.slice_ptr[S] = dst;
+    m.cols.resize((size_t)dst * C);
+    m.vals.resize((size_t)dst * C * 9);
+    m.cols.shrink_to_fit();
+    m.vals.shrink_to_fit();
+    return true;
 }
 
 bool BlockKey::operator==(const BlockKey &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }

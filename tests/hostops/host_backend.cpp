@@ -184,9 +184,30 @@ public:
                         for (int b = 0; b < 3; ++b)
                             t[a] += (blk ? blk[a * 3 + b] : m_.vals[((size_t)(base + k) * 9 + a * 3 + b) * C + l]) * x[3 * j + b];
                 }
+                const bool final_here = m_.ov_slices == 0 || ((m_.ov_mask[s] >> l) & 1ull) == 0;
                 for (int a = 0; a < 3; ++a) {
                     y[3 * r + a] = t[a];
-                    if (with_dot && own_free(3 * r + a)) acc += x[3 * r + a] * t[a];
+                    if (with_dot && final_here && own_free(3 * r + a)) acc += x[3 * r + a] * t[a];
+                }
+            }
+        }
+        if (m_.ov_slices > 0) {                                         // split matrix: the longer rows continue (split_overflow)
+            int64_t olo, ohi;
+            if (lo == 0) olo = 0; else if (lo == m_.n_bnd_slices) olo = m_.ov_bnd_slices; else throw std::runtime_error("spmv: slice range does not match the overflow part");
+            if (hi == m_.n_slices) ohi = m_.ov_slices; else if (hi == m_.n_bnd_slices) ohi = m_.ov_bnd_slices; else throw std::runtime_error("spmv: slice range does not match the overflow part");
+            for (int64_t s = olo; s < ohi; ++s) {
+                const int64_t base = m_.ov_slice_ptr[s], w = m_.ov_slice_ptr[s + 1] - base;
+                for (int l = 0; l < C; ++l) {
+                    const int64_t r = m_.ov_rows[(size_t)s * C + l];
+                    if (r < 0) continue;
+                    double *t = y + 3 * r;
+                    for (int64_t k = 0; k < w; ++k) {
+                        const int64_t j = m_.ov_cols[(size_t)(base + k) * C + l];
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b) t[a] += m_.ov_vals[((size_t)(base + k) * 9 + a * 3 + b) * C + l] * x[3 * j + b];
+                    }
+                    for (int a = 0; a < 3; ++a)
+                        if (with_dot && own_free(3 * r + a)) acc += x[3 * r + a] * t[a];
                 }
             }
         }

@@ -1,0 +1,90 @@
+"""Split SELL format (csrc/sell.cpp split_overflow; round 3): on octree meshes a slice stores its typical row length and the longer
+rows continue in an overflow part.  The sum of a row keeps its order, so the operator is bit-identical to the single SELL matrix;
+checked on the CPU double (same planner, same slice ranges as the HIP back end), multi-rank with gloo, and on the GPU."""
+import copy
+
+import numpy as np
+import pytest
+
+import pcg_mi355x as pm
+from util import golden, relerr, run_dist, check_solution_against_golden
+
+
+def _mesh_part():
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    return make_octree_parts(GradedOctreeMesh((4, 4, 4), 3, band=1.2), 1)[0]
+
+
+def _apply_and_solve(P0, monkeypatch, split):
+    if split is None: monkeypatch.delenv("PCG_SELL_SPLIT", raising=False)
+    else: monkeypatch.setenv("PCG_SELL_SPLIT", split)
+    P = copy.deepcopy(P0)
+    pm.configure(comm=None, device=0, operator="sell")
+    op = pm.get_operator(P)
+    x = np.random.default_rng(2).standard_normal(op.n)
+    y = np.array(op.apply(x))
+    info = op.matrix_info()
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    return y, info, P["GlobData"]["TimeList_Flag"][1], P["GlobData"]["TimeList_Iter"][1], np.array(P["Un"]), np.array(P["InvDiagPreCondVector0"])
+
+
+def _check(P0, monkeypatch):
+    single = _apply_and_solve(P0, monkeypatch, "0")
+    split = _apply_and_solve(P0, monkeypatch, "1")
+    auto = _apply_and_solve(P0, monkeypatch, None)
+    assert split[1]["nnzb"] == single[1]["nnzb"]
+    assert split[1]["stored_blocks"] < 0.75 * single[1]["stored_blocks"]       # 1.6 x -> 1.06 x the true blocks on this mesh
+    assert auto[1]["stored_blocks"] == split[1]["stored_blocks"]               # saves > 10 %: split by default
+    for other in (split, auto):
+        assert np.array_equal(other[0], single[0])                             # the mat-vec, bit for bit
+        assert np.array_equal(other[5], single[5])                             # the preconditioner
+        assert other[2] == single[2] == 0 and abs(other[3] - single[3]) <= 1   # (the fused p.Ap groups its terms differently)
+        assert relerr(other[4], single[4]) < 1e-9
+
+
+def test_split_matrix_is_bit_identical_on_the_cpu_double(hostops, monkeypatch):
+    _check(_mesh_part(), monkeypatch)
+
+
+def test_brick_matrices_are_not_split(hostops, monkeypatch):
+    """A brick's rows are 8 ... 27 blocks in runs of equal length: nothing to gain, the single matrix stays."""
+    from pcg_mi355x.brick import Brick, make_parts
+    P = make_parts(Brick(13))[0]
+    monkeypatch.delenv("PCG_SELL_SPLIT", raising=False)
+    pm.configure(comm=None, device=0, operator="sell")
+    a = pm.get_operator(copy.deepcopy(P)).matrix_info()
+    monkeypatch.setenv("PCG_SELL_SPLIT", "0")
+    b = pm.get_operator(copy.deepcopy(P)).matrix_info()
+    assert a == b
+
+
+@pytest.mark.parametrize("case,nproc,port", [("goct_p4", 4, 29671), ("oct_p3", 3, 29672)])
+def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):
+    """Interface rows first, interior rows behind the exchange: the overflow part is split at the same row, every rank runs
+    base + overflow for each range (forced split: the fixtures are small)."""
+    import conftest
+    conftest.build_hostops()
+    monkeypatch.setenv("PCG_SELL_SPLIT", "1")
+    outs = run_dist(case, nproc, "gloo", "hostops", tmp_path, port)
+    g = golden(case)
+    n = len(g["Fext"])
+    U = np.zeros(n); Y = np.zeros(n)
+    for o in reversed(outs):
+        U[o["dofs"]] = o["Un"]; Y[o["dofs"]] = o["y_probe"]
+    assert relerr(Y, g["y_probe"]) < 1e-14
+    o0 = outs[0]
+    check_solution_against_golden(g, int(o0["flag"]), int(o0["iter"]), float(o0["relres"]), U, o0["history"], tol_u=1e-8)
+
+
+@pytest.mark.gpu
+def test_split_matrix_is_bit_identical_on_the_gpu(gpu_lib, monkeypatch):
+    _check(_mesh_part(), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["goct_p4", "oct_p3"])
+def test_split_matrix_multi_part_on_one_gpu(gpu_lib, monkeypatch, case):
+    """All parts of a fixture on one GPU through the thread communicator, split forced."""
+    import test_gpu_parity as T
+    monkeypatch.setenv("PCG_SELL_SPLIT", "1")
+    T.test_multi_part_kernels_on_one_gpu(gpu_lib, case, "sell")
