@@ -532,7 +532,10 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
 }
 
 // plain format: rows much longer than their slice's typical row continue in an overflow part (sell.cpp split_overflow; octree
-// meshes: 55 % of the stored blocks were padding).  PCG_SELL_SPLIT=0 keeps the single SELL matrix; =1 splits whenever any block goes.
+// meshes: a third of the stored blocks was padding).  Automatic for matrices of at least 65 536 block rows when it removes more than
+// 10 % of the stored blocks: below that size the operator is not bandwidth-bound, and y keeps its bits either way but the fused
+// p.Ap groups its terms differently - small cases keep the exact residual histories of the single matrix.
+// PCG_SELL_SPLIT=0 keeps the single SELL matrix; =1 splits whenever any block goes, whatever the size (tests).
 static void maybe_split(SellHost &m)
 {
     if (!m.bidx.empty() || m.bs != 3 || m.C != 64) return;
@@ -540,6 +543,8 @@ static void maybe_split(SellHost &m)
     if (const char *ev = std::getenv("PCG_SELL_SPLIT")) {
         if (std::atoi(ev) == 0) return;
         min_saving = 1e-9;
+    } else if (m.n_slices < 1024) {
+        return;
     }
     (void)split_overflow(m, min_saving, 16);
 }

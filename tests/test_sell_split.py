@@ -34,7 +34,7 @@ def _check(P0, monkeypatch):
     auto = _apply_and_solve(P0, monkeypatch, None)
     assert split[1]["nnzb"] == single[1]["nnzb"]
     assert split[1]["stored_blocks"] < 0.75 * single[1]["stored_blocks"]       # 1.6 x -> 1.06 x the true blocks on this mesh
-    assert auto[1]["stored_blocks"] == split[1]["stored_blocks"]               # saves > 10 %: split by default
+    assert auto[1]["stored_blocks"] == single[1]["stored_blocks"]              # below 65 536 rows: not split unless forced
     for other in (split, auto):
         assert np.array_equal(other[0], single[0])                             # the mat-vec, bit for bit
         assert np.array_equal(other[5], single[5])                             # the preconditioner
@@ -79,6 +79,25 @@ def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):
 @pytest.mark.gpu
 def test_split_matrix_is_bit_identical_on_the_gpu(gpu_lib, monkeypatch):
     _check(_mesh_part(), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch):
+    """At 1 M dof the automatic rule applies (>= 65 536 rows, a third of the stored blocks goes): 1.57 -> 1.05 x the true blocks,
+    and the mat-vec is still the single matrix's bit for bit."""
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    from pcg_mi355x.operator import from_refmeshpart
+    P = make_octree_parts(GradedOctreeMesh((12, 12, 12), 4, band=1.2), 1)[0]
+    res = {}
+    for tag, env in (("single", "0"), ("auto", None)):
+        if env is None: monkeypatch.delenv("PCG_SELL_SPLIT", raising=False)
+        else: monkeypatch.setenv("PCG_SELL_SPLIT", env)
+        op = from_refmeshpart(P, kind="sell")
+        x = np.random.default_rng(8).standard_normal(op.n)
+        res[tag] = (np.array(op.apply(x)), op.matrix_info())
+        op.close()
+    assert res["auto"][1]["stored_blocks"] < 1.08 * res["auto"][1]["nnzb"] < 1.08 * res["single"][1]["stored_blocks"] / 1.5
+    assert np.array_equal(res["auto"][0], res["single"][0])
 
 
 @pytest.mark.gpu
