@@ -694,8 +694,11 @@ def main():
         t_k = m["op_ms"] * 1e-3
         achieved = sell_bytes / t_k / 1e9
         alg_bytes = 12.0 * nnz_loc + 20.0 * n_loc                 # what scalar CSR (f64 value + i32 column per nnz) would move
-        col_bytes = int(round((sell_bytes - 16.0 * n_loc) / info["stored_blocks"] - 72.0))          # 4, or 2 (16-bit column offsets)
+        col_bytes = 2 if (sell_bytes - 16.0 * n_loc) / info["stored_blocks"] - 72.0 < 3.0 else 4     # 16-bit column offsets, or i32 (+ the per-row bytes of an overflow part)
         out["config"]["format"] = f"SELL-{info['slice_rows']} over 3x3 blocks, {8 * col_bytes}-bit block columns"
+        out["config"]["stored_over_true_blocks"] = info["stored_blocks"] / max(1, info["nnzb"])
+        if args.workload == "octree":
+            out["config"]["format"] += "; rows longer than their slice's base width continue in an overflow part (k_spmv_ovf; roofline.avg_launch_ms covers both launches)"
         out["config"]["spmv_achieved_GBps"] = achieved
         out["roofline"] = {
             "bound": "hbm", "kernel": f"k_spmv<{info['slice_rows'] // 64}, true, {'true' if col_bytes == 2 else 'false'}> (SELL-BSR3 SpMV + fused p.Ap)" + (" - this rank's part" if world > 1 else ""),
@@ -721,7 +724,7 @@ def main():
                 log(f"scalar-CSR point failed: {ex!r}")
         try:        # PMC traffic of an identical launch, collected by separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}" + ("_col16" if col_bytes == 2 else ""))
-            if pmc and world == 1:
+            if pmc and world == 1 and args.workload == "brick":
                 out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = ("from profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch "
                                                    "(gfx950-corrected), collected on another box in another session - not a measurement of this run")

@@ -143,6 +143,10 @@ bool split_overflow(SellHost &m, double min_saving, int n_threads)
             std::stable_sort(rows.begin() + a, rows.begin() + std::min(rows.size(), a + window), [](const Row &x, const Row &y) { return x.exc > y.exc; });
         for (size_t a = 0; a < rows.size(); a += C) {
             const size_t b = std::min(rows.size(), a + C);
+            // the 64 rows of a slice in ascending row order again: neighbouring lanes gather neighbouring x (the width of the
+            // slice is its longest row whatever the order of its lanes)
+            if (!std::getenv("PCG_SELL_SPLIT_KEEP_SORTED"))
+                std::sort(rows.begin() + a, rows.begin() + b, [](const Row &x, const Row &y) { return x.row < y.row; });
             int32_t w = 0;
             for (size_t q = a; q < b; ++q) w = std::max(w, rows[q].exc);
             const int64_t ob = m.ov_slice_ptr.back();

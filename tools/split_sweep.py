@@ -18,7 +18,10 @@ for cb in combos:
         os.environ["PCG_SELL_SPLIT"] = "0"
     else:
         os.environ.pop("PCG_SELL_SPLIT", None)
-        os.environ["PCG_SELL_SPLIT_F"], os.environ["PCG_SELL_SPLIT_WINDOW"] = cb.split(":")
+        parts = cb.split(":")                       # f:window[:s] - s = lanes of an overflow slice stay sorted by excess length
+        os.environ["PCG_SELL_SPLIT_F"], os.environ["PCG_SELL_SPLIT_WINDOW"] = parts[0], parts[1]
+        if len(parts) > 2: os.environ["PCG_SELL_SPLIT_KEEP_SORTED"] = "1"
+        else: os.environ.pop("PCG_SELL_SPLIT_KEEP_SORTED", None)
     op = from_refmeshpart(P, kind="sell")
     info = op.matrix_info()
     fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
