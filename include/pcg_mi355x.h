@@ -275,6 +275,8 @@ int pcg_operator_info(pcg_engine *e, int32_t *kind /* 0 assembled, 1 matrix-free
 /* What ONE local operator apply has to move (bytes of the stored operator + x in + y out, counted from the uploaded
  * structures) and compute (flops of the un-padded operator): the denominators of the roofline report (bench.py). */
 int pcg_operator_cost(pcg_engine *e, double *bytes_per_apply, double *flops_per_apply);
+/* nnzb = the matrix's 3x3 blocks; stored_blocks = what the SELL layout holds (padding included; for a matrix the engine split
+ * into a base part + an overflow part for its long rows - octree meshes, csrc/sell.cpp split_overflow, PCG_SELL_SPLIT - both parts). */
 int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_t *n_slices, int32_t *slice_rows);
 /* FNV-1a over the host-side operator arrays (slice pointers, columns, values or indices + table, diagonal), recorded at
  * creation when the environment has PCG_MATRIX_FINGERPRINT (0 otherwise): lets tests assert that two construction paths

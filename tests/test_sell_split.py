@@ -107,3 +107,33 @@ def test_split_matrix_multi_part_on_one_gpu(gpu_lib, monkeypatch, case):
     import test_gpu_parity as T
     monkeypatch.setenv("PCG_SELL_SPLIT", "1")
     T.test_multi_part_kernels_on_one_gpu(gpu_lib, case, "sell")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_split_on_random_block_matrices(hostops, monkeypatch, seed):
+    """Rows of 0 ... 200 blocks in random order (hub nodes, empty rows, explicit zero blocks at the end of a row) through
+    pcg_create_csr: split and single matrix give the same bits, both agree with scipy."""
+    import scipy.sparse as sp
+    from pcg_mi355x.operator import Operator
+    rng = np.random.default_rng(seed)
+    nn = 64 * 37 + 11
+    lens = rng.choice([0, 1, 3, 8, 27, 27, 27, 40, 99, 200], nn)
+    rows, cols = [], []
+    for i, ln in enumerate(lens):
+        c = np.unique(rng.integers(0, nn, ln))
+        rows.append(np.full(len(c), i)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    blocks = rng.standard_normal((len(rows), 3, 3))
+    blocks[rng.random(len(rows)) < 0.05] = 0.0                               # explicit zero blocks (some end a row)
+    A = sp.bsr_matrix((blocks, cols, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=nn))])), shape=(3 * nn, 3 * nn)).tocsr()
+    A.sort_indices()
+    x = rng.standard_normal(3 * nn)
+    ys = {}
+    for tag, env in (("single", "0"), ("split", "1")):
+        monkeypatch.setenv("PCG_SELL_SPLIT", env)
+        op = Operator.from_csr(A.indptr, A.indices, A.data)
+        ys[tag] = (np.array(op.apply(x)), op.matrix_info()["stored_blocks"])
+        op.close()
+    assert ys["split"][1] < 0.6 * ys["single"][1]
+    assert np.array_equal(ys["split"][0], ys["single"][0])
+    assert relerr(ys["split"][0], A @ x) < 1e-13
