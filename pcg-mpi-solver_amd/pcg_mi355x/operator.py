@@ -400,7 +400,9 @@ def from_refmeshpart(part, device=0, comm=None, rows_per_lane=0, n_threads=0, ki
     blocked = kind == "ebe" and xyz is not None and os.environ.get("PCG_EBE_BLOCKED_ORDER", "1") == "1"
     # (Round 3 measured SELL-C-sigma here - rows sorted by length inside 2048-row windows, which takes the padding of the octree
     #  mesh from 56.6 % to 2.1 % - and removed it again: lanes of a slice then hold rows from anywhere in the window, the x gather
-    #  loses its lane-to-lane locality and the SpMV gained 3 % for 35 % fewer bytes: profiles/r03_octree_ab_sessionG.log.)
+    #  loses its lane-to-lane locality and the SpMV gained 3 % for 35 % fewer bytes: profiles/r03_octree_ab_sessionG.log.  What the
+    #  engine does instead: rows stay where they are, the part of a row beyond its slice's base width continues in an overflow
+    #  matrix - csrc/sell.cpp split_overflow.)
     if len(nbr) or blocked:
         is_b = np.zeros(n_nodes, bool)
         for v in ovl:
