@@ -29,6 +29,7 @@ CASES = {
     # multi-level 2:1-balanced octree mesh around a sphere (round 3): 3 cell sizes, dozens of pattern types with 9-20 nodes
     "goct_p1":      dict(graded=((3, 3, 3), 2, 1.2), parts=1, sign_seed=None, tol=1e-7, max_iter=10000),
     "goct_p4":      dict(graded=((3, 3, 3), 2, 1.2), parts=4, sign_seed=9, tol=1e-7, max_iter=10000),      # recursive bisection
+    "goct_p3_ud":   dict(graded=((3, 3, 3), 2, 1.2), parts=3, sign_seed=5, tol=1e-7, max_iter=10000, ud=2e-3),   # + prescribed displacements (:234-237)
     "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
     "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
 }
@@ -48,7 +49,15 @@ def build_case(name, golden_dir=None):
         roots, levels, band = c["graded"]
         mesh = GradedOctreeMesh(roots, levels, band=band, seed=0)
         ep = bisect_elements(mesh, c["parts"]) if c["parts"] > 1 else None
-        return mesh, make_octree_parts(mesh, c["parts"], 0, c["tol"], c["max_iter"], c["sign_seed"], elem_part=ep)
+        parts = make_octree_parts(mesh, c["parts"], 0, c["tol"], c["max_iter"], c["sign_seed"], elem_part=ep)
+        for p in parts:
+            if c.get("ud", 0.0) != 0.0:                  # non-zero Dirichlet values on the fixed z-dofs, as for the brick cases
+                fixed = p["LocFixedDof"]
+                ud = np.zeros(p["NDOF"])
+                zf = fixed[fixed % 3 == 2]
+                ud[zf] = c["ud"] * (1.0 + 0.25 * np.sin(p["DofVector"][zf].astype(float)))
+                p["Ud"] = ud
+        return mesh, parts
     b = Brick(c["N"], seed=0, n_types=c["n_types"])
     parts = make_parts(b, block_partition(b, *c["grid"]), tol=c["tol"], max_iter=c["max_iter"])
     for p in parts:

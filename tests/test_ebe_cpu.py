@@ -83,7 +83,7 @@ def test_patterns_with_nd_36_and_mixed_groups(hostops, kind, N):
     assert relerr(P["Un"], R["Un"]) < 1e-8
 
 
-@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622), ("oct_p3", 3, 29623), ("goct_p4", 4, 29624)])
+@pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29621), ("n13_t3_p4_ud", 4, 29622), ("oct_p3", 3, 29623), ("goct_p4", 4, 29624), ("goct_p3_ud", 3, 29682)])
 def test_ebe_multi_rank(tmp_path, case, nproc, port):
     import conftest
     conftest.build_hostops()
