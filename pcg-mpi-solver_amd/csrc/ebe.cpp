@@ -44,6 +44,53 @@ bool node_blocked(const pcg_elem_group &g)
     return true;
 }
 
+
+// Pattern types of the mixed chunks (EbeMixedHost): the most populous 8-node type becomes the hex section, every other
+// node-blocked type a tile type with its A-operand fragments.  v_mfma_f64_16x16x4_f64: A lane (g, i) holds A[i][k = g], B lane
+// (g, e) holds B[k = g][e], D lane (g, e) register r holds D[i = g + 4 r][e] (g = lane >> 4).  Rows and columns of Ke are
+// PERMUTED so that lane group g owns whole nodes: k-step ks = 3 j + c carries dof 3 (4 j + g) + c, and permuted row
+// 16 mt + g + 4 r = g + 4 q (q = 4 mt + r = 3 j' + c') is dof 3 (4 j' + g) + c'.  Dofs of nodes >= nn are zero rows / columns.
+bool build_mixed_types(int32_t n_groups, const pcg_elem_group *gs, const std::vector<char> &chunkable, EbeChunkedHost &C)
+{
+    auto &M = C.mixed;
+    int64_t best = 0;
+    for (int g = 0; g < n_groups; ++g)
+        if (chunkable[g] && gs[g].nd == 24 && gs[g].ne > best) { best = gs[g].ne; M.hex_group = g; }
+    auto &K = C.cls[kMixedClass];
+    K.ke_col.assign(24 * 24, 0.0);
+    if (M.hex_group >= 0)
+        for (int b = 0; b < 24; ++b)
+            for (int a = 0; a < 24; ++a) K.ke_col[(size_t)b * 24 + a] = gs[M.hex_group].ke[(size_t)a * 24 + b];
+    bool any = M.hex_group >= 0;
+    int max_nn = 4, max_nd = 1;
+    for (int g = 0; g < n_groups; ++g) {
+        if (!chunkable[g] || g == M.hex_group || gs[g].ne == 0) continue;
+        EbeMixedType T;
+        T.group = g; T.nd = gs[g].nd; T.nn = gs[g].nd / 3; T.J = (T.nn + 3) / 4;
+        const int MT = (3 * T.J + 3) / 4, KS = 3 * T.J;
+        T.frag_off = (int64_t)M.frag.size();
+        M.frag.resize(M.frag.size() + (size_t)KS * MT * 64, 0.0);
+        double *F = M.frag.data() + T.frag_off;
+        for (int ks = 0; ks < KS; ++ks)
+            for (int mt = 0; mt < MT; ++mt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int gk = lane >> 4, i = lane & 15;
+                    const int col_node = 4 * (ks / 3) + gk, col_dof = 3 * col_node + ks % 3;
+                    const int q = 4 * mt + (i >> 2), row_node = 4 * (q / 3) + (i & 3), row_dof = 3 * row_node + q % 3;
+                    if (col_node < T.nn && row_node < T.nn && q < 3 * T.J)
+                        F[((size_t)ks * MT + mt) * 64 + lane] = gs[g].ke[(size_t)row_dof * T.nd + col_dof];
+                }
+        M.max_mt = std::max(M.max_mt, MT);
+        max_nn = std::max(max_nn, T.nn);
+        max_nd = std::max(max_nd, T.nd);
+        M.types.push_back(T);
+        any = true;
+    }
+    M.nnpt = (max_nn + 3) / 4 * 4;
+    M.words = (max_nd + 31) / 32;
+    return any;
+}
+
 }  // namespace
 
 void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, const int64_t *perm,
@@ -216,16 +263,29 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     bool any = false;
     for (int c = 0; c < kChunkClasses; ++c) {
         auto &K = C.cls[c];
-        K.nnp = c == 4 ? 8 : 8 * (c + 1);
+        K.nnp = (c == 4 || c == kMixedClass) ? 8 : 8 * (c + 1);
         K.full = c == 0;
         K.ept = c == 0 ? ept : 1;
-        K.ce = c == 0 ? kChunkThreads * ept : 64;
+        K.ce = c == 0 ? kChunkThreads * ept : (c == kMixedClass ? kMixedHexSlots : 64);
         K.words = 3 * K.nnp / 32 + 1;
         K.max_nodes = (c == 0 && ept == 1) ? 512 : kChunkMaxNodes;      // 8x8x4 hex cells -> 405 nodes: a 2-nodes-per-thread tile
         const char *dv = std::getenv("PCG_EBE_DIRECT");                              // =0: node tiles for every class (A/B)
         K.direct = c >= 1 && c <= 3 && !(dv && dv[0] == '0');
     }
-    for (int g = 0; g < n_groups; ++g)
+    // Mixed-type chunks (EbeMixedHost): the default as soon as two node-blocked pattern types have elements; PCG_EBE_MIXED=0 keeps
+    // one chunk list per type (the round-3 form, A/B), =1 forces the mixed form for a single type too (tests).
+    bool mixed_mode = false;
+    {
+        int populated = 0;
+        for (int g = 0; g < n_groups; ++g) populated += chunkable[g] && gs[g].ne > 0;
+        const char *mv = std::getenv("PCG_EBE_MIXED");
+        mixed_mode = mv ? (mv[0] != '0' && populated >= 1) : populated >= 2;
+    }
+    if (mixed_mode) {
+        any = build_mixed_types(n_groups, gs, chunkable, C);
+        for (int g = 0; g < n_groups; ++g) if (chunkable[g]) cls_of[g] = kMixedClass;
+    }
+    for (int g = 0; g < n_groups && !mixed_mode; ++g)
         if (chunkable[g]) {
             const int nn = gs[g].nd / 3, nd = gs[g].nd;
             const int c = nn == 8 ? 0 : (nn < 8 ? 4 : (nn + 7) / 8 - 1);
@@ -343,11 +403,181 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         o.elems.clear();
         o.nodes.clear();
     };
+
+    // ================= mixed-type chunks: greedy runs of the global Morton order ===========================
+    if (mixed_mode) {
+        auto &M = C.mixed;
+        auto &K = C.cls[kMixedClass];
+        const int hex_cap = kChunkThreads * ept, tile_cap = ept == 2 ? kMixedMaxTiles : kMixedMaxTiles / 2;
+        std::vector<int32_t> type_of(n_groups, -1);
+        for (size_t t = 0; t < M.types.size(); ++t) type_of[M.types[t].group] = (int32_t)t;
+        std::vector<ElemRef> L;
+        for (const auto &r : order)
+            if (chunkable[r.g]) L.push_back(r);
+        int32_t next_stamp = 0;
+        std::vector<std::pair<uint64_t, int32_t>> keyed;
+        std::vector<uint64_t> used;
+        std::vector<int> sc;
+        // emit the run [lo_, hi_) as one chunk; false (nothing emitted) when its hex section needs more than 63 sub-colours
+        auto emit = [&](size_t lo_, size_t hi_) -> bool {
+            const int32_t id = next_stamp++;
+            keyed.clear();
+            std::vector<size_t> hex_el;
+            std::vector<std::vector<size_t>> by_type(M.types.size());
+            bool bnd = false;
+            for (size_t k = lo_; k < hi_; ++k) {
+                const auto &in = gs[L[k].g];
+                for (int l = 0; l < in.nd / 3; ++l) {
+                    const int64_t orig = in.dof[(int64_t)(3 * l) * in.ne + L[k].e] / 3;
+                    const int64_t node = perm ? perm[orig] : orig;
+                    bnd |= node < n_boundary_nodes;
+                    if (stamp[node] != id) { stamp[node] = id; keyed.emplace_back(tile_key(orig, node), (int32_t)node); }
+                }
+                if (L[k].g == M.hex_group) hex_el.push_back(k); else by_type[type_of[L[k].g]].push_back(k);
+            }
+            std::sort(keyed.begin(), keyed.end());
+            const int nn = (int)keyed.size();
+            for (int k = 0; k < nn; ++k) local_of[keyed[k].second] = k;
+            auto lid_of = [&](const ElemRef &r, int l) {
+                const auto &in = gs[r.g];
+                return local_of[new_node(in.dof[(int64_t)(3 * l) * in.ne + r.e])];
+            };
+            // hex section: greedy sub-colours over its elements, slots sorted by colour (slot order = (pass, wave) order)
+            const int nh = (int)hex_el.size();
+            used.assign(nn, 0);
+            sc.assign(nh, 0);
+            int nsub = 0;
+            for (int t = 0; t < nh; ++t) {
+                uint64_t forb = 1ull << 63;
+                for (int l = 0; l < 8; ++l) forb |= used[lid_of(L[hex_el[t]], l)];
+                if (~forb == 0) return false;
+                const int c = __builtin_ctzll(~forb);
+                for (int l = 0; l < 8; ++l) used[lid_of(L[hex_el[t]], l)] |= 1ull << c;
+                sc[t] = c;
+                nsub = std::max(nsub, c + 1);
+            }
+            std::vector<int> lane_of(nh);
+            std::iota(lane_of.begin(), lane_of.end(), 0);
+            std::stable_sort(lane_of.begin(), lane_of.end(), [&](int a, int b) { return sc[a] < sc[b]; });
+            const int32_t cid = (int32_t)C.n_chunks++;
+            const int32_t kci = (int32_t)K.n_chunks++;
+            const int32_t tile0 = (int32_t)M.n_tiles;
+            const int CE = kMixedHexSlots;
+            K.ck.resize((size_t)(kci + 1) * CE, 0.0);
+            K.sgn.resize((size_t)(kci + 1) * CE, 0xff000000u);
+            K.lid.resize((size_t)(kci + 1) * 8 * CE, 0);
+            for (int k = 0; k < nh; ++k) {
+                const ElemRef &r = L[hex_el[lane_of[k]]];
+                const auto &in = gs[r.g];
+                K.ck[(size_t)kci * CE + k] = in.ck[r.e];
+                uint32_t bits = 0;
+                for (int a = 0; a < 24; ++a)
+                    if (in.sign[(int64_t)a * in.ne + r.e]) bits |= 1u << a;
+                K.sgn[(size_t)kci * CE + k] = bits | ((uint32_t)sc[lane_of[k]] << 24);
+                for (int l = 0; l < 8; ++l) K.lid[((size_t)kci * 8 + l) * CE + k] = (uint16_t)lid_of(r, l);
+            }
+            M.hex_elems += nh;
+            // tiles: 16 elements of one type, in run order; tile-local colours (the 16 elements add in ONE wave instruction per colour)
+            const int W = M.words, NP = M.nnpt;
+            for (size_t t = 0; t < by_type.size(); ++t) {
+                const auto &T = M.types[t];
+                const auto &in = gs[T.group];
+                for (size_t b0 = 0; b0 < by_type[t].size(); b0 += 16) {
+                    const int cnt = (int)std::min<size_t>(16, by_type[t].size() - b0);
+                    const size_t ti = (size_t)M.n_tiles++;
+                    M.tile_type.push_back((int32_t)t);
+                    M.tlid.resize((ti + 1) * NP * 16, 0);
+                    M.tck.resize((ti + 1) * 16, 0.0);
+                    M.tsgn.resize((ti + 1) * W * 16, 0u);
+                    M.tcol.resize((ti + 1) * 16, 255);
+                    int ncol = 0;
+                    std::vector<std::pair<int, uint32_t>> seen;       // (local slot, colour mask) of the nodes this tile has touched
+                    for (int e = 0; e < cnt; ++e) {
+                        const ElemRef &r = L[by_type[t][b0 + e]];
+                        uint32_t forb = 0;
+                        for (int l = 0; l < T.nn; ++l) {
+                            const int li = lid_of(r, l);
+                            M.tlid[(ti * NP + l) * 16 + e] = (uint16_t)li;
+                            for (const auto &sn : seen) if (sn.first == li) forb |= sn.second;
+                        }
+                        const int c = __builtin_ctz(~forb);            // at most 16 elements: a colour below 16 is always free
+                        for (int l = 0; l < T.nn; ++l) {
+                            const int li = lid_of(r, l);
+                            bool found = false;
+                            for (auto &sn : seen) if (sn.first == li) { sn.second |= 1u << c; found = true; break; }
+                            if (!found) seen.emplace_back(li, 1u << c);
+                        }
+                        M.tcol[ti * 16 + e] = (uint8_t)c;
+                        ncol = std::max(ncol, c + 1);
+                        M.tck[ti * 16 + e] = in.ck[r.e];
+                        for (int a = 0; a < T.nd; ++a)
+                            if (in.sign[(int64_t)a * in.ne + r.e]) M.tsgn[(ti * W + a / 32) * 16 + e] |= 1u << (a % 32);
+                    }
+                    M.tile_ncol.push_back(ncol);
+                    M.tile_elems += cnt;
+                }
+            }
+            C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, nh, kci, (int32_t)(M.n_tiles - tile0), kMixedClass, tile0});
+            {
+                std::vector<int32_t> by_id(nn);
+                for (int k = 0; k < nn; ++k) by_id[k] = keyed[k].second;
+                std::sort(by_id.begin(), by_id.end());
+                for (int32_t nd_ : by_id) { C.nodes.push_back(nd_); C.tslot.push_back((uint16_t)local_of[nd_]); }
+            }
+            C.max_subcolors = std::max(C.max_subcolors, nsub);
+            chunk_phase.push_back(bnd ? 0 : 1);
+            K.list[bnd ? 0 : 1].push_back(cid);
+            return true;
+        };
+        std::vector<std::pair<size_t, size_t>> todo;
+        auto emit_or_split = [&](size_t lo_, size_t hi_) {
+            todo.assign(1, {lo_, hi_});
+            while (!todo.empty()) {                                  // (a hub node of valence > 63 in the hex section: halve the run)
+                auto [a, b] = todo.back();
+                todo.pop_back();
+                if (emit(a, b)) continue;
+                if (b - a < 2) throw std::runtime_error("ebe: an element does not fit a mixed chunk");
+                todo.emplace_back(a + (b - a) / 2, b);
+                todo.emplace_back(a, a + (b - a) / 2);
+            }
+        };
+        std::vector<int32_t> cnt_type(M.types.size(), 0);
+        size_t lo_ = 0;
+        int n_run_nodes = 0, n_hex = 0, n_tl = 0;
+        int32_t run_id = next_stamp++;
+        for (size_t k = 0; k < L.size(); ++k) {
+            const auto &in = gs[L[k].g];
+            const bool is_hex = L[k].g == M.hex_group;
+            const int t = is_hex ? -1 : type_of[L[k].g];
+            auto stamp_new = [&](int32_t id, bool mark) {            // nodes of element k the run `id` does not hold yet
+                int fresh = 0;
+                for (int l = 0; l < in.nd / 3; ++l) {
+                    const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
+                    if (stamp[node] != id) { if (mark) stamp[node] = id; ++fresh; }
+                }
+                return fresh;
+            };
+            const int fresh = stamp_new(run_id, false);
+            const bool new_tile = !is_hex && cnt_type[t] % 16 == 0;
+            if (k > lo_ && (n_run_nodes + fresh > kChunkMaxNodes || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
+                emit_or_split(lo_, k);
+                lo_ = k;
+                run_id = next_stamp++;
+                n_run_nodes = n_hex = n_tl = 0;
+                std::fill(cnt_type.begin(), cnt_type.end(), 0);
+            }
+            n_run_nodes += stamp_new(run_id, true);
+            if (is_hex) ++n_hex;
+            else { if (cnt_type[t] % 16 == 0) ++n_tl; ++cnt_type[t]; }
+        }
+        if (lo_ < L.size()) emit_or_split(lo_, L.size());
+    }
+
     // Chunks = octree-like cells: the spatially sorted element list of a group is split recursively at
     // Morton-bit boundaries until a cell holds <= 256*ept elements, <= kChunkMaxNodes nodes and <= 63
     // sub-colours.  On a uniform region the cells form a regular lattice of full boxes.  Without coordinates
     // (keys = node ids) cells are plain runs of elements.
-    {
+    if (!mixed_mode) {
         int32_t next_stamp = 0;
         std::vector<std::vector<ElemRef>> per_group(n_groups);
         for (const auto &r : order)
@@ -545,6 +775,10 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     fprintf(stderr, "ebe plan: class %d (<= %d nodes, %d slots/chunk%s): %lld elements in %lld chunks, %lld %s (%lld to boundary slots)\n",
                             c, C.cls[c].nnp, C.cls[c].ce, C.cls[c].direct ? ", no node tile" : "", (long long)elems[c], (long long)C.cls[c].n_chunks, (long long)tile_nodes[c],
                             C.cls[c].direct ? "element-node incidences" : "tile nodes", (long long)shared_tile_nodes[c]);
+            if (C.mixed.n_tiles || C.mixed.hex_elems)
+                fprintf(stderr, "ebe plan: mixed chunks: %lld elements in the hex section, %lld in %lld tiles of 16 (%.0f %% full), %zu tile types, "
+                                "at most %d M-tiles\n", (long long)C.mixed.hex_elems, (long long)C.mixed.tile_elems, (long long)C.mixed.n_tiles,
+                        C.mixed.n_tiles ? 100.0 * C.mixed.tile_elems / (16.0 * C.mixed.n_tiles) : 0.0, C.mixed.types.size(), C.mixed.max_mt);
             fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots\n", (long long)n_nodes,
                     (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots);
         }

@@ -69,6 +69,11 @@ class HipBackend : public Backend {
         double *ck = nullptr, *ke = nullptr, *ke_rows = nullptr;
         unsigned *sgn = nullptr;
     } chc_[kChunkClasses];
+    // per-launch tables of the mixed-type chunks (k_ebe_mixed)
+    MixTab mix_tab_[2] = {};
+    int mix_mtm_ = 0;
+    std::vector<int> mix_nodes_host_[2];
+    std::vector<unsigned short> mix_tslot_host_[2];
     // per-launch tables of the hex8 class for k_ebe_hex (hex_mode_ > 0)
     HexTab hex_tab_[2] = {};
     std::vector<void *> hex_allocs_;
@@ -467,6 +472,16 @@ public:
                 auto &D = chc_[c];
                 D.nnp = K.nnp; D.ept = K.ept; D.full = K.full; D.direct = K.direct;
                 if (K.n_chunks == 0) continue;
+                if (c == kMixedClass) {                           // mixed-type chunks: per-launch tables (build_mixed_tables)
+                    up(D.ke, K.ke_col);
+                    for (int ph = 0; ph < 2; ++ph) {
+                        D.count[ph] = (int)K.list[ph].size();
+                        n_chunks_total_[ph] += D.count[ph];
+                        np += K.list[ph].size();
+                    }
+                    build_mixed_tables(C);
+                    continue;
+                }
                 up(D.lid, K.lid); up(D.ck, K.ck); up(D.sgn, K.sgn); up(D.ke, K.ke_col);
                 if (!K.ke_rows.empty()) up(D.ke_rows, K.ke_rows);
                 for (int ph = 0; ph < 2; ++ph) {
@@ -485,6 +500,67 @@ public:
             }
             d_part_ebe_ = (double *)alloc(sizeof(double) * np);
         }
+    }
+    // k_ebe_mixed: the mixed-type chunks laid out per launch (phase), block b's data at fixed strides of b; the tile arrays are
+    // shared by both phases (a chunk's header names its first tile)
+    void build_mixed_tables(const EbeChunkedHost &C)
+    {
+        const auto &K = C.cls[kMixedClass];
+        const auto &M = C.mixed;
+        const int CE = kMixedHexSlots, MAXN = kChunkMaxNodes;
+        auto up = [&](const auto &v) {
+            void *d = alloc(sizeof(v[0]) * std::max<size_t>(1, v.size()));
+            h2d(d, v.data(), sizeof(v[0]) * v.size());
+            hex_allocs_.push_back(d);
+            return d;
+        };
+        if (M.words > 3) throw std::runtime_error("k_ebe_mixed: more than 96 dofs per element");
+        std::vector<int> tinfo(2 * (size_t)std::max<int64_t>(1, M.n_tiles), 0);
+        for (int64_t t = 0; t < M.n_tiles; ++t) {
+            const auto &T = M.types[M.tile_type[t]];
+            tinfo[2 * t] = T.nn | (T.J << 8) | (M.tile_ncol[t] << 16);
+            tinfo[2 * t + 1] = (int)(T.frag_off / 64);
+        }
+        const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgn = up(M.tsgn), *d_tcol = up(M.tcol), *d_frag = up(M.frag);
+        mix_mtm_ = std::max(2, M.max_mt);
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t n = K.list[ph].size();
+            if (!n) continue;
+            std::vector<int> hdr(8 * n, 0), nodes(n * MAXN, -1), dst(n * MAXN, 0);
+            std::vector<unsigned short> tslot(n * MAXN, 0), lid(n * 8 * CE, 0);
+            std::vector<double> ck(n * CE, 0.0);
+            std::vector<unsigned> sgn(n * CE, 0xff000000u);
+            for (size_t b = 0; b < n; ++b) {
+                const int32_t *h = &C.hdr[(size_t)K.list[ph][b] * 8];
+                const int32_t off = h[0], nn = h[1], nh = h[3], kci = h[4];
+                int any_sign = 0;
+                for (int e = 0; e < nh; ++e) any_sign |= (K.sgn[(size_t)kci * CE + e] & 0x00ffffffu) != 0;
+                hdr[8 * b] = nn; hdr[8 * b + 1] = h[2]; hdr[8 * b + 2] = nh; hdr[8 * b + 3] = any_sign;
+                hdr[8 * b + 4] = h[5]; hdr[8 * b + 5] = h[7];
+                for (int k = 0; k < nn; ++k) {
+                    nodes[b * MAXN + k] = C.nodes[off + k]; dst[b * MAXN + k] = C.dst[off + k]; tslot[b * MAXN + k] = C.tslot[off + k];
+                }
+                std::copy(&K.ck[(size_t)kci * CE], &K.ck[(size_t)kci * CE] + CE, &ck[b * CE]);
+                std::copy(&K.sgn[(size_t)kci * CE], &K.sgn[(size_t)kci * CE] + CE, &sgn[b * CE]);
+                std::copy(&K.lid[(size_t)kci * 8 * CE], &K.lid[(size_t)kci * 8 * CE] + 8 * CE, &lid[b * 8 * CE]);
+            }
+            MixTab T{};
+            T.hdr = (const int4 *)up(hdr); T.nodes = (const int *)up(nodes); T.dst = (const int *)up(dst);
+            T.tslot = (const unsigned short *)up(tslot); T.lid = (const unsigned short *)up(lid); T.ck = (const double *)up(ck);
+            T.sgn = (const unsigned *)up(sgn);
+            T.tinfo = (const int2 *)d_tinfo; T.tlid = (const unsigned short *)d_tlid; T.tck = (const double *)d_tck;
+            T.tsgn = (const unsigned *)d_tsgn; T.tcol = (const unsigned char *)d_tcol; T.frag = (const double *)d_frag;
+            T.np = M.nnpt; T.words = M.words; T.xcd = ebe_xcd_;
+            mix_tab_[ph] = T;
+            mix_nodes_host_[ph] = nodes;
+            mix_tslot_host_[ph] = tslot;
+        }
+    }
+    template <int MTM>
+    void launch_mixed(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
+    {
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], ke, x, y, d_ch_buf_, part, dot_lo); };
+        if (dot) go(k_ebe_mixed<MTM, true>); else go(k_ebe_mixed<MTM, false>);
     }
     // k_ebe_hex: the hex8 class laid out per launch (phase): block b's data at fixed strides of b
     void build_hex_tables(const EbeChunkedHost &C)
@@ -609,6 +685,17 @@ public:
     // -> number of dot partials the launch writes
     int launch_class(const ChunkClassDev &D, int ph, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
+        if (&D == &chc_[kMixedClass]) {                          // mixed-type chunks
+            switch (mix_mtm_) {
+            case 2: launch_mixed<2>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo); break;
+            case 3: launch_mixed<3>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo); break;
+            case 4: launch_mixed<4>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo); break;
+            case 5: launch_mixed<5>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo); break;
+            case 6: launch_mixed<6>(ph, D.count[ph], D.ke, x, y, dot, part, dot_lo); break;
+            default: throw std::runtime_error("k_ebe_mixed: unexpected tile size");
+            }
+            return D.count[ph];
+        }
         switch (D.nnp) {
         case 8:
             if (D.full && hex_tab_[ph].hdr) {                     // hex8 class through the per-launch tables
@@ -679,6 +766,19 @@ public:
     void upload_masks(const uint8_t *f, int64_t n) override
     {
         h2d(d_flags_, f, (size_t)n);
+        for (int ph = 0; ph < 2; ++ph) {                     // k_ebe_mixed: the same weights in its slot table
+            if (!mix_tab_[ph].tslot) continue;
+            std::vector<unsigned short> t(mix_tslot_host_[ph]);
+            for (size_t k = 0; k < t.size(); ++k) {
+                const int g = mix_nodes_host_[ph][k];
+                if (g < 0) continue;
+                unsigned m = 0;
+                for (int d = 0; d < 3; ++d)
+                    if ((f[3 * (size_t)g + d] & 3) == 3) m |= 1u << d;
+                t[k] = (unsigned short)((t[k] & 0x3ff) | (m << 12));
+            }
+            h2d((void *)mix_tab_[ph].tslot, t.data(), sizeof(unsigned short) * t.size());
+        }
         for (int ph = 0; ph < 2; ++ph) {                     // k_ebe_hex reads the dot weights from its slot table
             if (!hex_tab_[ph].tslot) continue;
             std::vector<unsigned short> t(hex_tslot_host_[ph]);

@@ -608,6 +608,234 @@ __global__ __launch_bounds__(kChunkThreads, (NNP <= 16 ? 4 : NNP <= 24 ? 3 : 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mixed-type chunks (round 4; EbeMixedHost in pcg_internal.hpp): k_ebe_mixed.
+// A chunk is a run of the GLOBAL Morton order of the elements - every node-blocked pattern type together - so the elements
+// around a node sit in one workgroup whatever their type, the node is summed in the chunk's LDS tile and only the nodes on the
+// surface of the run go through boundary slots (1 M-dof graded octree mesh: 816 k -> 314 k slots, 68 % -> 41 % of the nodes
+// shared; the per-type chunks of round 3 sent EVERY node incidence of a hanging-node element through a slot).
+//   [stage]  the chunk's nodes: x tile in, y tile zeroed (as k_ebe_hexs: per-launch tables at fixed strides of the workgroup)
+//   [hex]    the elements of the mesh's main 8-node type: k_ebe_hexs' two passes of one element per thread, Ke as SGPR operands
+//   [tiles]  every other element sits in a 16-element tile of ONE pattern type; a wave takes a tile:
+//            Y(nd x 16) = Ke(nd x nd) . U(nd x 16) on v_mfma_f64_16x16x4_f64 with the A operand streamed from the type's
+//            pre-permuted fragments (one coalesced 512-B load per instruction, L2-resident: 46 KB per 24-node type).  The
+//            permutation (ebe.cpp build_mixed_types) makes lane (g, e) gather and scatter WHOLE nodes g, g + 4, ... of element e.
+//            Four tiles are contracted side by side, then added into the y tile wave after wave (tile order), inside a tile
+//            colour by colour (ds_add_f64): one order of additions per node, bit-reproducible.
+//   [out]    exclusive nodes -> y, shared nodes -> their boundary slot (k_ebe_shared), fused p.Ap
+// MTM: M-tiles the largest pattern type needs (3 J / 4 rounded up, J = node quartets): sizes the accumulators.
+// ------------------------------------------------------------------------------------------------
+struct MixTab {
+    const int4 *hdr;              // per chunk 2 x int4: {n_nodes, hex sub-colours, hex slots in use, any hex sign bit}, {tiles, first tile, -, -}
+    const int *nodes;             // [n][768]   node id, -1 = padding
+    const int *dst;               // [n][768]   >= 0: y offset (exclusive node); < 0: -(boundary slot + 1)
+    const unsigned short *tslot;  // [n][768]   bits 0..9 slot in the LDS tile; bits 12..14: dot weights (upload_masks)
+    const unsigned short *lid;    // [n][8][512]
+    const double *ck;             // [n][512]
+    const unsigned *sgn;          // [n][512]   24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
+    const int2 *tinfo;            // per tile: nodes | node quartets << 8 | colours << 16 ; fragment offset / 64
+    const unsigned short *tlid;   // [tiles][np][16]
+    const double *tck;            // [tiles][16]
+    const unsigned *tsgn;         // [tiles][words][16]
+    const unsigned char *tcol;    // [tiles][16]   tile-local colour, 255 = padding slot
+    const double *frag;
+    int np, words, xcd;
+};
+
+typedef double d4m_t __attribute__((ext_vector_type(4)));
+
+// one tile, J node quartets (compile time): acc[mt] = sum over the k-steps of A(ks, mt) . U(ks)
+template <int J, int MTM>
+__device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F, const double *xs, const int (&l3)[(4 * MTM) / 3], double c,
+                                                    const unsigned (&sg)[3], int g, int nn, d4m_t (&acc)[MTM])
+{
+    constexpr int MT = (3 * J + 3) / 4;
+    static_assert(MT <= MTM, "tile type larger than the kernel instantiation");
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int node = 4 * j + g;
+        const bool live = node < nn;
+        const double x0 = xs[l3[j]], x1 = xs[l3[j] + 1], x2 = xs[l3[j] + 2];
+        const double xv[3] = {x0, x1, x2};
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int d = 3 * node + cc;
+            unsigned word = sg[0];
+            word = (d >> 5) == 1 ? sg[1] : word;
+            word = (d >> 5) == 2 ? sg[2] : word;
+            const double sx = ((word >> (d & 31)) & 1u) ? -xv[cc] : xv[cc];                                 // :278
+            const double u = live ? c * sx : 0.0;                                                           // :279 Ck * U
+            const int ks = 3 * j + cc;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[(size_t)(ks * MT + mt) * 64], u, acc[mt], 0, 0, 0);   // :279 Ke @ (.)
+        }
+    }
+}
+
+template <int MTM, bool DOT>
+__global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed(MixTab T, const double *__restrict__ ke_col,
+                                                                                   const double *__restrict__ x, double *__restrict__ y,
+                                                                                   double *__restrict__ buf, double *__restrict__ partials,
+                                                                                   long long dot_lo)
+{
+    constexpr int NPT = 3, MAXN = kChunkThreads * NPT, CE = kMixedHexSlots, ND = 24, JM = (4 * MTM) / 3;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
+    const int4 h = T.hdr[2 * b], h2 = T.hdr[2 * b + 1];
+    const int n_hex = h.z;
+    unsigned sg = 0xff000000u;
+    double c = 0.0;
+    int l3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_elem = [&](int ps) {
+        const size_t slot = (size_t)b * CE + ps * kChunkThreads + threadIdx.x;
+        sg = ntload(T.sgn + slot);
+        c = ntload(T.ck + slot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + ps * kChunkThreads + threadIdx.x);
+    };
+    if (n_hex > 0) load_elem(0);
+    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+        g[j] = ntload(T.nodes + n);
+        dst[j] = ntload(T.dst + n);
+        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
+        sl3[j] = 3 * (ts & 0x3ff);
+        wmask[j] = ts >> 12;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            const double *xp = x + 3 * (size_t)g[j];
+            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
+            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        }
+    __syncthreads();
+    // ---- hex section: two passes of one element per thread (k_ebe_hexs), skipped when empty ----------------------------------
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        if (n_hex > ps * kChunkThreads) {                        // block-uniform
+            double acc[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) acc[a] = 0.0;
+            auto contract = [&](auto with_signs) {
+                constexpr bool SIG = decltype(with_signs)::value;
+#pragma unroll
+                for (int bb = 0; bb < ND; ++bb) {
+                    const double xv = xs[l3[bb / 3] + bb % 3];                                               // :277 gather
+                    const double u = c * (SIG ? flip_sign(xv, sg, bb) : xv);                                 // :278-279 sign, Ck
+#pragma unroll
+                    for (int a = 0; a < ND; ++a) acc[a] = fma(ke_col[bb * ND + a], u, acc[a]);               // :279 Ke @ (.)
+                }
+                if constexpr (SIG) {
+#pragma unroll
+                    for (int a = 0; a < ND; ++a) acc[a] = flip_sign(acc[a], sg, a);                          // :280
+                }
+            };
+            if (h.w) contract(std::true_type());
+            else contract(std::false_type());
+            const unsigned my_colour = sg >> 24;
+            const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
+            if (ps == 0 && n_hex > kChunkThreads) load_elem(1);  // the other half's slots arrive under this accumulation
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                if (wave == w)
+                    for (int s = 0; s < h.y; ++s)
+                        if ((int)my_colour == s) {
+#pragma unroll
+                            for (int a = 0; a < ND; ++a)                                                     // :300, added by the LDS unit
+                                __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- tiles: four at a time (one per wave) on the matrix cores, added wave after wave ----------------------------------------
+    const int n_tiles = h2.x, lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
+    for (int t0 = 0; t0 < n_tiles; t0 += kWavesPerBlock) {       // block-uniform
+        const int ti = t0 + wave;
+        const bool have = ti < n_tiles;                          // wave-uniform
+        d4m_t acc[MTM];
+        int tl3[JM];
+        unsigned tsg[3] = {0u, 0u, 0u};
+        int nn = 0, ncol = 0, mycol = 255;
+#pragma unroll
+        for (int mt = 0; mt < MTM; ++mt) acc[mt] = d4m_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < JM; ++j) tl3[j] = 0;
+        if (have) {
+            const size_t tg = (size_t)h2.y + ti;
+            const int2 info = T.tinfo[tg];
+            nn = __builtin_amdgcn_readfirstlane(info.x & 255);
+            const int J = __builtin_amdgcn_readfirstlane((info.x >> 8) & 255);
+            ncol = __builtin_amdgcn_readfirstlane(info.x >> 16);
+            const double *F = T.frag + (size_t)__builtin_amdgcn_readfirstlane(info.y) * 64 + lane;
+            const double tc = T.tck[tg * 16 + le];
+            mycol = (int)T.tcol[tg * 16 + le];
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+                if (w < T.words) tsg[w] = T.tsgn[(tg * T.words + w) * 16 + le];
+#pragma unroll
+            for (int j = 0; j < JM; ++j)
+                if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
+            switch (J) {                                         // wave-uniform: straight-line code per size
+            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            default: break;
+            }
+        }
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (wave == w && have)
+                for (int s = 0; s < ncol; ++s)
+                    if (mycol == s) {
+#pragma unroll
+                        for (int j = 0; j < JM; ++j)
+                            if (4 * j + lg < nn) {
+#pragma unroll
+                                for (int cc = 0; cc < 3; ++cc) {
+                                    const int q = 3 * j + cc, d = 3 * (4 * j + lg) + cc;
+                                    unsigned word = tsg[0];
+                                    word = (d >> 5) == 1 ? tsg[1] : word;
+                                    word = (d >> 5) == 2 ? tsg[2] : word;
+                                    const double a = acc[q / 4][q % 4];
+                                    const double o = ((word >> (d & 31)) & 1u) ? -a : a;                      // :280
+                                    __hip_atomic_fetch_add(&ys[tl3[j] + cc], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                                }
+                            }
+                    }
+            __syncthreads();
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (g[j] >= 0) {
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {        // fused p.Ap.w (:487) on the dofs this chunk finalises
+                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
+                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
+                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
+            }
+        }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void k_ebe_shared(const int *__restrict__ sh_node, const int *__restrict__ sh_ptr,
                                                        int slot0, const double *__restrict__ buf,

@@ -701,8 +701,19 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
             b += 34.0 * (double)(Ch.nodes.size() - Ch.direct_entries);   // per tile node: id 4 + dst 4 + slot 2, x tile in 24
             b += 32.0 * (double)Ch.direct_entries;           // per incidence of a chunk without a tile: id 4 + dst 4, x in 24
             b += 24.0 * (double)Ch.nodes.size();             //                y (exclusive) or boundary slot out 24
-            for (const auto &K : Ch.cls)                     // per element slot: local node ids (tile classes), Ck, sign words
+            for (int c = 0; c < kChunkClasses; ++c) {        // per element slot: local node ids (tile classes), Ck, sign words
+                const auto &K = Ch.cls[c];
+                if (c == kMixedClass) continue;
                 b += (double)K.n_chunks * K.ce * ((K.direct ? 0.0 : 2.0 * K.nnp) + 8.0 + 4.0 * K.words);
+            }
+            {                                                // mixed-type chunks: hex section 28 B per element; tiles: 16 slots of
+                const auto &M = Ch.mixed;                    // (2 B per local node + Ck + sign words + colour) + the tile's A fragments
+                b += 28.0 * (double)M.hex_elems;             // (fragments: L2-resident, counted once per tile as the kernel reads them)
+                for (int64_t t = 0; t < M.n_tiles; ++t) {
+                    const auto &T = M.types[M.tile_type[t]];
+                    b += 16.0 * (2.0 * 4 * T.J + 8.0 + 4.0 * M.words + 1.0) + 8.0;
+                }
+            }
             b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
             for (int ph = 0; ph < 2; ++ph) b += 32.0 * (double)Ch.sh_node[ph].size();   // ... y out 24 + node id + run pointer
             b += 32.0 * (double)Ch.n_chunks;                 // chunk headers

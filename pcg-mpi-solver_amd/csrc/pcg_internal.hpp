@@ -126,8 +126,11 @@ struct EbeRange { int32_t group; int64_t lo, hi; };      // elements [lo,hi) of 
 // in chunk order (deterministic, no atomics, no colour-by-colour launches, no read-modify-write of y).
 constexpr int kChunkThreads = 256;                 // workgroup size
 constexpr int kChunkMaxNodes = 768;                // 8x8x8 hex cells -> 729 nodes (LDS x + y tiles = 36.9 KB)
-constexpr int kChunkClasses = 5;                   // 0: exactly 8 nodes (hex8, unguarded kernel); 1..3: <= 16 / 24 / 32 nodes;
-                                                   // 4: fewer than 8 nodes (padded to 8)
+constexpr int kChunkClasses = 6;                   // 0: exactly 8 nodes (hex8, unguarded kernel); 1..3: <= 16 / 24 / 32 nodes;
+                                                   // 4: fewer than 8 nodes (padded to 8); 5: mixed-type chunks (EbeMixedHost)
+constexpr int kMixedClass = 5;
+constexpr int kMixedHexSlots = 512;                // hex8 element slots of a mixed chunk (two passes of 256 threads)
+constexpr int kMixedMaxTiles = 24;                 // 16-element tiles of the other pattern types per mixed chunk
 struct EbeClassHost {
     int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
     bool full = false;                 // every element of the class has exactly nnp nodes (no padding guards needed)
@@ -147,10 +150,44 @@ struct EbeClassHost {
     std::vector<double> ke_rows;       // 64-slot classes: (groups, 4 waves, NDP b, NDP/4 a): the rows of one wave contiguous per column
     std::vector<int32_t> list[2];      // per phase: global chunk ids of this class (one launch each)
 };
+// Mixed-type chunks (round 4; class kMixedClass): a chunk is a run of the GLOBAL Morton order of the elements - every node-blocked
+// pattern type together - so the elements around a node sit in ONE workgroup whatever their type and the node is summed in the
+// chunk's LDS tile; only nodes on the surface of the run go through boundary slots.  Inside a chunk:
+//   * the elements of the mesh's most populous 8-node type (`hex_group`) fill the hex section - one element per thread in two
+//     passes of 256, the element matrix as SGPR operands (k_ebe_hexs' contraction) - EbeClassHost lid / ck / sgn of class 5;
+//   * every other element sits in a 16-element TILE of ONE pattern type: Y(nd x 16) = Ke(nd x nd) . U(nd x 16) on
+//     v_mfma_f64_16x16x4_f64, the A operand streamed from `frag` (L2-resident, pre-permuted so that a lane gathers and scatters
+//     WHOLE nodes: lane (g, e) of the wave handles the local nodes g, g + 4, g + 8, ... of element e).
+// The sums a chunk forms for a node are ordered: hex section (pass, wave, sub-colour), then the tiles in ascending order, the
+// elements of a tile by their tile-local colour - bit-reproducible.
+struct EbeMixedType {                  // a pattern type that occurs in tiles
+    int32_t group = 0, nn = 0, nd = 0; // element group, nodes, dofs
+    int32_t J = 0;                     // node quartets: ceil(nn / 4); k-steps = 3 J, M-tiles = ceil(3 J / 4)
+    int64_t frag_off = 0;              // offset (doubles) of its fragments: frag[frag_off + ((3 j + c) * MT + mt) * 64 + lane]
+};
+struct EbeMixedHost {
+    int32_t hex_group = -1;            // element group of the hex section, -1 = none
+    int32_t nnpt = 8;                  // local-node stride of tlid (max nn over the tile types, rounded up to a multiple of 4)
+    int32_t words = 1;                 // sign words per tile element
+    int32_t max_mt = 0;                // max M-tiles of any type (selects the kernel instantiation)
+    std::vector<EbeMixedType> types;
+    std::vector<double> frag;
+    int64_t n_tiles = 0;
+    std::vector<int32_t> tile_type;    // (n_tiles) index into types
+    std::vector<int32_t> tile_ncol;    // (n_tiles) tile-local colours in use
+    std::vector<uint16_t> tlid;        // (n_tiles, nnpt, 16) slot in the chunk's LDS tile of local node l of element e (0 padding)
+    std::vector<double> tck;           // (n_tiles, 16), 0 in padding slots
+    std::vector<uint32_t> tsgn;        // (n_tiles, words, 16) sign bits of the element's dofs
+    std::vector<uint8_t> tcol;         // (n_tiles, 16) tile-local colour, 255 = padding slot
+    int64_t hex_elems = 0, tile_elems = 0;
+};
+
 struct EbeChunkedHost {
     int64_t n_chunks = 0;
     std::vector<int32_t> hdr;          // (n_chunks, 8): node_off, n_nodes, n_subcolours, ke index in class,
                                        //                chunk index in class, nd, class, 16-element tiles in use (hex8 class)
+                                       // mixed chunks:  node_off, n_nodes, sub-colours of the hex section, hex slots in use,
+                                       //                chunk index in class, tiles, class (5), first tile
     std::vector<int32_t> nodes;        // concatenated unique node ids (engine numbering, ascending per chunk: the global
                                        // loads / stores of a chunk walk memory in address order)
     std::vector<uint16_t> tslot;       // same shape: slot of the node in the chunk's LDS tile (what `lid` refers to); the
@@ -164,6 +201,7 @@ struct EbeChunkedHost {
                                        //            (ph ? sh_ptr[0].back() : 0) + q, so a device kernel needs no slot list
     bool needs_zero = false;           // some node is touched by no chunk (isolated, or only by non-chunked groups)
     EbeClassHost cls[kChunkClasses];
+    EbeMixedHost mixed;
     int32_t max_subcolors = 0;
 };
 struct EbeHost {

@@ -58,6 +58,71 @@ public:
                 const int32_t off = h[0], nn = h[1], nsub = h[2], kci = h[4], nd = h[5];
                 const int CE = K.ce, W = K.words, ndp = 3 * K.nnp;
                 const double *Kc = &K.ke_col[(size_t)h[3] * ndp * ndp];
+                if (&K == &C.cls[kMixedClass]) {                        // mixed-type chunk: hex section, then 16-element tiles
+                    const auto &M = C.mixed;
+                    const int nh = h[3], ntl = h[5], tile0 = h[7];
+                    for (int n = 0; n < nn; ++n)
+                        for (int d = 0; d < 3; ++d) { xs[3 * C.tslot[off + n] + d] = x[3 * (int64_t)C.nodes[off + n] + d]; ys[3 * n + d] = 0.0; }
+                    double a24[24];
+                    for (int slot = 0; slot < nh; ++slot) {              // slot order = (pass, wave, sub-colour) order of the kernel
+                        const unsigned sg = K.sgn[(size_t)kci * CE + slot];
+                        const double c = K.ck[(size_t)kci * CE + slot];
+                        for (int k = 0; k < 24; ++k) a24[k] = 0.0;
+                        for (int b = 0; b < 24; ++b) {
+                            double v = xs[3 * K.lid[((size_t)kci * 8 + b / 3) * CE + slot] + b % 3];
+                            if ((sg >> b) & 1u) v = -v;
+                            v = c * v;
+                            for (int k = 0; k < 24; ++k) a24[k] += K.ke_col[(size_t)b * 24 + k] * v;
+                        }
+                        for (int k = 0; k < 24; ++k)
+                            ys[3 * K.lid[((size_t)kci * 8 + k / 3) * CE + slot] + k % 3] += ((sg >> k) & 1u) ? -a24[k] : a24[k];
+                    }
+                    const int W = M.words, NP = M.nnpt;
+                    std::vector<double> uu, out;
+                    for (int ti = tile0; ti < tile0 + ntl; ++ti) {
+                        const auto &T = M.types[M.tile_type[ti]];
+                        const int MT = (3 * T.J + 3) / 4, KS = 3 * T.J;
+                        const double *F = M.frag.data() + T.frag_off;
+                        out.assign((size_t)16 * T.nd, 0.0);
+                        auto sb = [&](int e, int a) { return (M.tsgn[((size_t)ti * W + a / 32) * 16 + e] >> (a % 32)) & 1u; };
+                        for (int e = 0; e < 16; ++e) {
+                            if (M.tcol[(size_t)ti * 16 + e] == 255) continue;
+                            uu.assign(T.nd, 0.0);
+                            for (int b = 0; b < T.nd; ++b) {
+                                double v = xs[3 * M.tlid[((size_t)ti * NP + b / 3) * 16 + e] + b % 3];
+                                uu[b] = M.tck[(size_t)ti * 16 + e] * (sb(e, b) ? -v : v);
+                            }
+                            for (int g = 0; g < 4; ++g)                  // the data flow of the matrix-core tile (fragments as uploaded)
+                                for (int q = 0; q < 3 * T.J; ++q) {
+                                    const int row_node = 4 * (q / 3) + g;
+                                    if (row_node >= T.nn) continue;
+                                    const int mt = q / 4, i = g + 4 * (q % 4);
+                                    double a = 0.0;
+                                    for (int ks = 0; ks < KS; ++ks)
+                                        for (int gk = 0; gk < 4; ++gk) {
+                                            const int col_node = 4 * (ks / 3) + gk;
+                                            if (col_node < T.nn) a += F[((size_t)ks * MT + mt) * 64 + gk * 16 + i] * uu[3 * col_node + ks % 3];
+                                        }
+                                    const int dof = 3 * row_node + q % 3;
+                                    out[(size_t)e * T.nd + dof] = sb(e, dof) ? -a : a;
+                                }
+                        }
+                        for (int col = 0; col < M.tile_ncol[ti]; ++col)
+                            for (int e = 0; e < 16; ++e)
+                                if (M.tcol[(size_t)ti * 16 + e] == col)
+                                    for (int k = 0; k < T.nd; ++k) ys[3 * M.tlid[((size_t)ti * NP + k / 3) * 16 + e] + k % 3] += out[(size_t)e * T.nd + k];
+                    }
+                    for (int n = 0; n < nn; ++n) {
+                        const int32_t dst = C.dst[off + n];
+                        double *o = dst >= 0 ? y + dst : &ebuf_[(size_t)(-dst - 1) * 3];
+                        const int sl = C.tslot[off + n];
+                        for (int d = 0; d < 3; ++d) {
+                            o[d] = ys[3 * sl + d];
+                            if (fuse && dst >= 0 && dst + d >= dot_lo && own_free(dst + d)) dot_spmv_ += xs[3 * sl + d] * ys[3 * sl + d];
+                        }
+                    }
+                    continue;
+                }
                 acc.assign((size_t)nd * CE, 0.0);
                 if (K.direct) {                                        // no node tile: one entry of nodes / dst per element-node incidence
                     for (int lane = 0; lane < CE; ++lane) {

@@ -67,6 +67,53 @@ def test_chunked_and_per_colour_forms_agree_with_oracle(hostops, chunked, ept, m
     pm.configure(comm=None, operator="sell")
 
 
+def mixed_chunk_cases():
+    """(name, part) pairs for the mixed-type chunk tests (CPU double and GPU): several hex8 types with sign frames, hanging-node
+    patterns of 9-20 nodes, a 13-node transition pattern, and a single-type mesh (mixed form forced)."""
+    from pcg_mi355x.brick import Brick, make_parts
+    from pcg_mi355x.octree import GradedOctreeMesh, TwoLevelMesh, make_octree_parts
+    yield "brick_3_types", make_parts(Brick(12, n_types=3))[0]
+    yield "graded_octree", make_octree_parts(GradedOctreeMesh((4, 4, 4), 3, band=1.2), 1)[0]
+    yield "two_level_octree", make_octree_parts(TwoLevelMesh(8, 8, 4, 3), 1)[0]
+    yield "brick_1_type", make_parts(Brick(11))[0]
+
+
+@pytest.mark.parametrize("ept", ["1", "2"])
+def test_mixed_type_chunks_agree_with_oracle_and_with_per_type_chunks(hostops, ept, monkeypatch):
+    """Round 4: chunks that hold the elements of EVERY pattern type of a run of the Morton order (hex section + 16-element
+    matrix-core tiles; csrc/ebe.cpp mixed planner, k_ebe_mixed / its CPU double) against the oracle's mat-vec and against the
+    per-type chunks of round 3 (PCG_EBE_MIXED=0); fewer boundary slots; the fused p.Ap; a whole solve."""
+    import ctypes as C
+    from pcg_mi355x._lib import check
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_EBE_EPT", ept)
+    for name, P in mixed_chunk_cases():
+        ys = {}
+        for mixed in ("1", "0"):
+            monkeypatch.setenv("PCG_EBE_MIXED", mixed)
+            op = from_refmeshpart(copy.deepcopy(P), kind="ebe")
+            x = np.random.default_rng(5).standard_normal(op.n)
+            y = np.empty(op.n); pxy = C.c_double()
+            xe = op.to_engine(x)
+            check(op._L.pcg_k_spmv_local(op._h, xe.ctypes.data, y.ctypes.data, C.byref(pxy)))
+            ys[mixed] = op.from_engine(y)
+            ref = pcg_oracle.matvec_local(P, x)
+            assert relerr(ys[mixed], ref) < 1e-14, (name, mixed)
+            w = np.zeros(op.n); w[P["LocDofEff"]] = 1.0
+            assert abs(pxy.value - np.dot(x, ref * w)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref)), (name, mixed)
+            assert op.operator_info()["n_colors"] <= (1 if mixed == "1" else 4)         # launches per phase
+            op.close()
+        assert relerr(ys["1"], ys["0"]) < 1e-14
+    monkeypatch.setenv("PCG_EBE_MIXED", "1")
+    P = dict(mixed_chunk_cases())["graded_octree"]
+    R = copy.deepcopy(P)
+    pm.configure(comm=None, operator="ebe")
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    out = pcg_oracle.solve_step([R])
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0 and abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= 1
+    assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
 @pytest.mark.parametrize("kind", ["ebe", "sell"])
 @pytest.mark.parametrize("N", [7, 8])
 def test_patterns_with_nd_36_and_mixed_groups(hostops, kind, N):

@@ -597,6 +597,48 @@ def test_graded_octree_1m_dof(gpu_lib, oracle_c, kind):
         print("graded octree 1 M dof, matrix-free:", op.operator_info())
 
 
+def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
+    """Round 4, k_ebe_mixed: chunks that hold the elements of every pattern type of a run of the Morton order (hex section on the
+    vector FMAs, 16-element tiles of the other types on the f64 matrix cores, node sums in LDS) against the oracle's mat-vec
+    (<= 1e-13) and the per-type kernels of round 3 (PCG_EBE_MIXED=0), the fused p.Ap, bit-reproducible from launch to launch,
+    and a whole solve - on bricks with three sign-framed hex8 types, graded / two-level octree meshes, one and two passes."""
+    from pcg_mi355x._lib import check
+    from pcg_mi355x.operator import from_refmeshpart
+    from test_ebe_cpu import mixed_chunk_cases
+    for ept in ("1", "2"):
+        monkeypatch.setenv("PCG_EBE_EPT", ept)
+        for name, P in mixed_chunk_cases():
+            ys = {}
+            for mixed in ("1", "0"):
+                monkeypatch.setenv("PCG_EBE_MIXED", mixed)
+                op = from_refmeshpart(copy.deepcopy(P), kind="ebe")
+                x = np.random.default_rng(5).standard_normal(op.n)
+                xe = op.to_engine(x)
+                y = np.empty(op.n); y2 = np.empty(op.n); pxy = C.c_double()
+                check(op._L.pcg_k_spmv_local(op._h, xe.ctypes.data, y.ctypes.data, C.byref(pxy)))
+                check(op._L.pcg_k_spmv_local(op._h, xe.ctypes.data, y2.ctypes.data, None))
+                assert np.array_equal(y, y2), (name, mixed)                          # same bits from launch to launch, with / without the dot
+                ys[mixed] = op.from_engine(y)
+                ref = pcg_oracle.matvec_local(P, x)
+                assert relerr(ys[mixed], ref) < 1e-13, (name, mixed, ept)
+                w = np.zeros(op.n); w[P["LocDofEff"]] = 1.0
+                assert abs(pxy.value - np.dot(x, ref * w)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref)), (name, mixed)
+                op.close()
+            assert relerr(ys["1"], ys["0"]) < 1e-13
+    monkeypatch.setenv("PCG_EBE_MIXED", "1")
+    monkeypatch.delenv("PCG_EBE_EPT")
+    P = dict(mixed_chunk_cases())["graded_octree"]
+    R = copy.deepcopy(P)
+    pm.configure(comm=None, device=0, operator="ebe")
+    try:
+        pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    finally:
+        pm.configure(comm=None, device=0, operator="sell")
+    out = pcg_oracle.solve_step([R])
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0 and abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= 1
+    assert relerr(P["Un"], R["Un"]) < 1e-8
+
+
 @pytest.mark.gpu
 def test_hanging_node_kernels_with_and_without_node_tile_agree(gpu_lib, monkeypatch):
     """The 16- / 24-node pattern classes run k_ebe_direct (no node tile, f64 matrix cores) by default and k_ebe_rows (LDS node
@@ -607,6 +649,7 @@ def test_hanging_node_kernels_with_and_without_node_tile_agree(gpu_lib, monkeypa
     P0 = make_octree_parts(GradedOctreeMesh((4, 4, 4), 3, band=1.2), 1)[0]
     x = None
     res = {}
+    monkeypatch.setenv("PCG_EBE_MIXED", "0")                               # the per-type chunk kernels (round 3)
     for tag, kind, direct in (("sell", "sell", None), ("tile", "ebe", "0"), ("direct", "ebe", "1")):
         if direct is None: monkeypatch.delenv("PCG_EBE_DIRECT", raising=False)
         else: monkeypatch.setenv("PCG_EBE_DIRECT", direct)
