@@ -39,6 +39,7 @@ int main(int argc, char **argv)
                 b[r] = sin(0.1 * (double)r) + 1.0;
             }
     rowptr[n] = nnz;
+    if (pcg_abi_version() != PCG_ABI_VERSION) { fprintf(stderr, "libpcg_mi355x ABI version %d, this program was compiled for %d\n", pcg_abi_version(), PCG_ABI_VERSION); return 2; }
     if (pcg_device_count() < 1) { fprintf(stderr, "no HIP device visible (the engine has no CPU fallback)\n"); return 2; }
     pcg_engine *e = NULL;
     CHECK(pcg_create_csr(0, n, rowptr, col, val, 0, /*block=*/1, &e));

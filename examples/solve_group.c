@@ -29,6 +29,7 @@ static double spring(int e) { return 1.0 + e % 3; }
 
 int main(int argc, char **argv)
 {
+    if (pcg_abi_version() != PCG_ABI_VERSION) { fprintf(stderr, "libpcg_mi355x ABI version %d, this program was compiled for %d\n", pcg_abi_version(), PCG_ABI_VERSION); return 2; }
     const int have = pcg_device_count();
     const int is_double = strcmp(pcg_backend_name(), "hip-gfx950") != 0;   /* tests/hostops: the CPU test double also runs this program */
     if (have < 1 && !is_double) { fprintf(stderr, "no HIP device visible (the engine has no CPU fallback)\n"); return 2; }

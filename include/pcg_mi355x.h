@@ -43,6 +43,15 @@ typedef struct pcg_engine pcg_engine;
 typedef struct pcg_asm pcg_asm;
 
 /* ---- library ------------------------------------------------------------------------------ */
+/* Version of the structs and entry points below.  The structs carry no size field: a caller compiled against another
+ * header version passes structs of another size, so check ONCE after loading the library -
+ *     if (pcg_abi_version() != PCG_ABI_VERSION) refuse to run
+ * (pcg_mi355x/_lib.py and the C examples do).  History: 1 = round 1; 2 = pcg_group_*, pcg_comm_* (round 2);
+ * 3 = pcg_comm_hooks.collective_exchange, pcg_result.vec_ms_sum / vec_count (round 3; a library of version < 3 called the
+ * hooks of a part without neighbours unconditionally - since 3 only with collective_exchange != 0);
+ * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4). */
+#define PCG_ABI_VERSION 4
+int pcg_abi_version(void);
 const char *pcg_last_error(void);
 const char *pcg_backend_name(void);          /* "hip-gfx950" for the product library */
 int pcg_device_count(void);
@@ -211,6 +220,9 @@ typedef struct {
                               were dropped because their predecessor ended the loop or replaced r (:527-549)  */
     double vec_ms_sum;     /* HIP-event time of the vector-phase launches (k_vec) when profiling is on      */
     int64_t vec_count;
+    int64_t fused_fallbacks; /* single part: fused vector launches whose grid barrier timed out (a workgroup of the grid was not
+                                resident: CU mask, compute partition, a second process on the device); such an iteration is
+                                finished in the split form with the same bits, and the engine keeps to the split form afterwards */
 } pcg_result;
 
 /* inv_diag may be NULL: use the Jacobi vector built by pcg_build_jacobi().

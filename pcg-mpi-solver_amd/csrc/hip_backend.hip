@@ -993,10 +993,14 @@ public:
     {
         vec_nt_ = 5;
         if (const char *e = getenv("PCG_VEC_NT")) vec_nt_ = atoi(e);          // bit 0: p / r' / x' stores, bit 1: SpMV y stores, bit 2: vector loads
-        vec_fused_ok_ = vec_fused_hw_;
+        vec_fused_ok_ = vec_fused_hw_ && !vec_fused_broken_;
+        if (h_mirror_)                                   // (called at solve_begin, nothing in flight) no stale time-out report in the ring
+            for (int s = 0; s < kStatusSlots; ++s) h_mirror_[(size_t)s * ST_COUNT + ST_ERR] = 0.0;
+        vec_spin_limit_ = 1u << 22;
+        if (const char *e = getenv("PCG_TEST_VEC_SPINS")) vec_spin_limit_ = (unsigned)std::max(0, atoi(e));   // tests: force the time-out path
         vec_kreg_ = kVecKreg;
         if (const char *e = getenv("PCG_VEC_KREG")) vec_kreg_ = std::max(0, std::min(kVecKreg, atoi(e)));
-        if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_hw_ && atoi(e) != 0;
+        if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_ok_ && atoi(e) != 0;
     }
     void publish_status(bool copy_block) override
     {
@@ -1023,6 +1027,17 @@ public:
     unsigned long long vec_seq_ = 0;               // fused launches so far
     int vec_kreg_ = kVecKreg;
     bool vec_fused_hw_ = false, vec_fused_ok_ = false;   // the device admits the grid / and PCG_VEC_FUSED does not say 0
+    bool vec_fused_broken_ = false;                      // a launch timed out at its grid barrier: split form for the rest of this engine's life
+    unsigned vec_spin_limit_ = 1u << 22;
+    void vec_fused_failed() override
+    {
+        vec_fused_broken_ = true;
+        vec_fused_ok_ = false;
+        HIP_CHECK(hipMemsetAsync(d_st_base_ + ST_ERR, 0, sizeof(double), st_));
+        HIP_CHECK(hipStreamSynchronize(st_));            // nothing queued may still mirror its report
+        if (h_mirror_)
+            for (int s = 0; s < kStatusSlots; ++s) h_mirror_[(size_t)s * ST_COUNT + ST_ERR] = 0.0;
+    }
     int vec_blocks(int64_t n) const
     {
         const int64_t g = ((n >> 1) + kVecBlock - 1) / kVecBlock;
@@ -1044,7 +1059,7 @@ public:
             else { a.pa = d_part_spmv_; a.count_a = cnt_spmv_; }
             a.pb = cnt_fix_ ? d_part_fix_ : nullptr; a.count_b = cnt_fix_;
         }
-        a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_;
+        a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_; a.spin_limit = vec_spin_limit_;
         const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {

@@ -184,6 +184,7 @@ struct VecArgs {
     unsigned long long seq;               // FUSED: number of this launch (1, 2, ...): targets = arrivals per launch x seq
     int pq_src, nt;
     int kreg;                             // FUSED: chunks of z kept in registers, <= kVecKreg (tests lower it: PCG_VEC_KREG)
+    unsigned spin_limit;                  // FUSED: polls of the grid barrier before a workgroup gives up (2^22 = seconds; tests: PCG_TEST_VEC_SPINS)
     int64_t n;
 };
 
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
                     const unsigned long long got = tid < ns ? __hip_atomic_load(a.sync + 16 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                     if (__all(got >= want)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) { ok = false; break; }   // seconds: a workgroup of the grid is not resident
+                    if (++spins > a.spin_limit) { ok = false; break; }   // seconds: a workgroup of the grid is not resident
                 }
             }
             if (tid == 0) lds[5 * kVecWaves] = ok ? 1.0 : 0.0;
@@ -303,11 +304,14 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
         const bool ok = lds[5 * kVecWaves] != 0.0;
         __syncthreads();
         if (stop != 0.0 || !ok) {                                  // uniform over the grid (frozen) or reported (time-out)
-            if (blockIdx.x == 0 && tid == 0) {
+            if (blockIdx.x == 0 && tid == 0 && stop != 0.0) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { a.st[ST_SQP + k] = 0.0; if (a.mirror) a.mirror[ST_SQP + k] = 0.0; }
-                if (!ok) { a.st[ST_ERR] = 1.0; if (a.mirror) a.mirror[ST_ERR] = 1.0; }
             }
+            // EVERY workgroup that gives up says so (the store is idempotent): one that starts late may find all arrivals counted and
+            // pass while others left without their part of p'.  r', x' and the partial sums of every workgroup are complete either
+            // way (written before the barrier); the host recovers from them in the split form (pcg_driver.cpp iterate_once).
+            if (!ok && tid == 0) { a.st[ST_ERR] = 1.0; if (a.mirror) a.mirror[ST_ERR] = 1.0; }
             return;
         }
         // ---- every workgroup: rho' from the G partials, same order everywhere -> same beta everywhere (:462, :475);

@@ -111,6 +111,7 @@ struct pcg_engine {
         bool ahead = false;       // iteration `i` is already enqueued (look-ahead from the previous pass)
         int ahead_nx = -1;        // ... writing its new x into this buffer
         int64_t n_enqueued = 0;   // iterations whose device work was enqueued (those not consumed were look-aheads dropped)
+        int64_t fused_fallbacks = 0;   // fused vector launches that timed out at their grid barrier and were finished in the split form
         const double *minv = nullptr;
         double t_total = 0.0, t_comm0 = 0.0;
     } s;
@@ -353,8 +354,27 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     }
     e->be->wait_status(slot, e->h_st);
     const double *st = e->h_st;
-    if (st[ST_ERR] != 0) throw std::runtime_error("the fused vector kernel's grid barrier timed out (a workgroup of its grid was "
-                                                  "not resident - another kernel on the device?); PCG_VEC_FUSED=0 selects the split form");
+    bool fused_done = fused;
+    if (st[ST_ERR] != 0) {
+        // The fused vector launch gave up at its grid barrier (a workgroup of its grid was not resident: a CU mask, a compute
+        // partition, another process on the device).  Everything it does BEFORE the barrier is complete - r', x' in their buffers -
+        // so the iteration is finished in the split form: the five sums again from p, x, r' (k_vec<false> with alpha = 0 leaves
+        // r' and x as they are and forms the partial sums of the SAME chunks in the same order: the bits of an undisturbed run),
+        // p of the next iteration by k_update_p, and this engine keeps to the split form from now on.
+        if (!fused) throw std::runtime_error("status block reports a grid-barrier time-out but the fused launch was not used");
+        const double alpha_i = st[ST_ALPHA], rho_i = st[ST_RHO], pq_i = st[ST_PQ];
+        s.ahead = false;                                       // its p came from an incomplete p': void (buffers nobody reads)
+        e->be->vec_fused_failed();                             // clears the report, synchronises
+        e->be->zero(e->d_st + ST_ALPHA, 2 * sizeof(double));   // ALPHA := 0 and STOP (the void look-ahead may have raised it)
+        e->be->set_status_slot(slot);
+        (void)e->be->vec_update(e->d_st, 0, p_cur, r_out, r_out, e->scratch(0), e->v_x[s.cur], e->scratch(1), s.minv, nullptr);
+        e->be->reduce_update(e->d_st + ST_SQP);
+        e->be->publish_status(false);
+        e->be->wait_status(slot, e->h_st);
+        e->h_st[ST_ALPHA] = alpha_i; e->h_st[ST_RHO] = rho_i; e->h_st[ST_PQ] = pq_i; e->h_st[ST_STOP] = 0.0;
+        fused_done = false;                                    // p of iteration i + 1 is still to be formed
+        s.fused_fallbacks++;
+    }
     if (st[ST_STOP] != 0) { s.flag = 4; return true; }         // pq<=0 / inf / alpha inf: nothing was updated
     const double alpha = st[ST_ALPHA];
     const double normp = std::sqrt(st[ST_SQP]), normx = std::sqrt(st[ST_SQX]);
@@ -367,7 +387,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     s.cur = nx;                                                // :516
     s.rcur ^= 1;
     s.pcur = (s.pcur + 1) % 3;
-    s.p_ready = fused;                                         // the vector launch left p of iteration i + 1 behind
+    s.p_ready = fused_done;                                    // the vector launch left p of iteration i + 1 behind
     s.normr_act = normr;                                       // :518
     s.i = i + 1;
     if (normr <= s.tolb || s.stag >= 3 || s.more > 0) {        // :527
@@ -434,6 +454,7 @@ void fill_result(pcg_engine *e, pcg_result *res)
     res->spmv_count = cnt;
     if (e->profiling) e->be->collect_profile_vec(&res->vec_ms_sum, &res->vec_count);
     res->iters_enqueued = s.n_enqueued;
+    res->fused_fallbacks = s.fused_fallbacks;
 }
 
 template <class F>
@@ -465,6 +486,7 @@ int guarded(const char *where, pcg_engine *e, F f)
 extern "C" {
 
 const char *pcg_last_error(void) { return last_error_string().c_str(); }
+int pcg_abi_version(void) { return PCG_ABI_VERSION; }
 const char *pcg_backend_name(void) { return backend_static_name(); }
 int pcg_device_count(void) { return backend_device_count(); }
 

@@ -310,6 +310,9 @@ public:
     virtual bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r_old, double *r_new,
                             const double *x_old, double *x_new, const double *minv, double *p_next) = 0;
     virtual bool vec_fused_available() const { return false; }
+    // the fused launch reported a grid-barrier time-out (st[ERR]): clear the report (block and host mirror) and keep to the split
+    // form from now on (this engine; reload_tuning() does not bring the fused form back)
+    virtual void vec_fused_failed() {}
     virtual void reduce_update(double *red5) = 0;
     // r = b - ax ; sums r^2 w, (M^-1 r) r w, inf count                      (:413-416,:530-533)
     virtual void residual(const double *b, const double *ax, double *r, const double *minv) = 0;

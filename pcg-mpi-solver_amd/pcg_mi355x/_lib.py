@@ -45,7 +45,7 @@ class Result(C.Structure):
                 ("n_matvec", C.c_int64), ("relres", C.c_double), ("norm_b", C.c_double),
                 ("normr_act", C.c_double), ("t_total_s", C.c_double), ("t_comm_s", C.c_double),
                 ("spmv_ms_sum", C.c_double), ("spmv_count", C.c_int64), ("iters_enqueued", C.c_int64),
-                ("vec_ms_sum", C.c_double), ("vec_count", C.c_int64)]
+                ("vec_ms_sum", C.c_double), ("vec_count", C.c_int64), ("fused_fallbacks", C.c_int64)]
 
 
 class CommStats(C.Structure):
@@ -53,6 +53,7 @@ class CommStats(C.Structure):
                 ("n_allreduce", C.c_int64), ("n_halo_timed", C.c_int64), ("n_allreduce_timed", C.c_int64)]
 
 
+ABI_VERSION = 4            # include/pcg_mi355x.h PCG_ABI_VERSION: the struct layouts above belong to this version
 RCCL_ID_BYTES = 256
 FORMAT_DICTIONARY = 0x100
 
@@ -60,6 +61,7 @@ STATUS_NORMAL, STATUS_ZERO_RHS, STATUS_GOOD_X0, STATUS_TOO_SMALL_TOL, STATUS_RUN
 
 _P = C.c_void_p
 _SIGS = {
+    "pcg_abi_version": (C.c_int, []),
     "pcg_last_error": (C.c_char_p, []),
     "pcg_backend_name": (C.c_char_p, []),
     "pcg_device_count": (C.c_int, []),
@@ -140,6 +142,8 @@ def use_library(path: str | None):
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    if lib.pcg_abi_version() != ABI_VERSION:         # the structs carry no size field: refuse a library of another header version
+        raise PcgError(f"{p} has ABI version {lib.pcg_abi_version()}, this binding is written for {ABI_VERSION} (include/pcg_mi355x.h)")
     _lib, _path = lib, p
     return lib
 

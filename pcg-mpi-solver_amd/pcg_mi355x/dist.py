@@ -69,12 +69,21 @@ class RcclComm:
         return self
 
     @classmethod
-    def from_file(cls, rank, world, device, path, timeout_s=120.0, launch_id=None, max_age_s=300.0):
+    def from_file(cls, rank, world, device, path, timeout_s=120.0, launch_id=None):
         """Bootstrap without torch.distributed: rank 0 writes the id to `path` (atomically), the others wait for it.
-        A file left behind by an EARLIER launch must not be taken for this one's: rank 0 removes it before anything else, the
-        file carries `launch_id` (any string every rank of this launch knows - the launcher's job id, MASTER_PORT, ...) and
-        the other ranks accept only a file with their own launch_id; without one they refuse files older than max_age_s."""
+        A file left behind by an EARLIER launch must not be taken for this one's (mismatched ids make ncclCommInitRank hang
+        instead of failing): the file carries `launch_id` - any string every rank of THIS launch knows and no other launch
+        shares - and a rank accepts only a file with its own.  Default: PCG_LAUNCH_ID, else the launcher's job id
+        (TORCHELASTIC_RUN_ID, SLURM_JOB_ID + step), else MASTER_ADDR:MASTER_PORT; with none of them in the environment the
+        caller has to pass one (round 4, ADVICE r3: an age limit on the file cannot tell a quick relaunch apart)."""
         import os
+        if launch_id is None:
+            env = os.environ
+            launch_id = env.get("PCG_LAUNCH_ID") or env.get("TORCHELASTIC_RUN_ID") or \
+                (f"slurm-{env['SLURM_JOB_ID']}.{env.get('SLURM_STEP_ID', '0')}" if "SLURM_JOB_ID" in env else None) or \
+                (f"{env.get('MASTER_ADDR', '')}:{env['MASTER_PORT']}" if "MASTER_PORT" in env else None)
+        if launch_id is None and world > 1:
+            raise ValueError("RcclComm.from_file: pass launch_id (or set PCG_LAUNCH_ID): nothing in the environment identifies this launch")
         tag = (launch_id if launch_id is not None else "").encode()
         if rank == 0:
             try:
@@ -92,11 +101,10 @@ class RcclComm:
                 if time.time() - t0 > timeout_s:
                     raise TimeoutError(f"no RCCL unique id of this launch at {path}")
                 try:
-                    fresh = launch_id is not None or time.time() - os.path.getmtime(path) <= max_age_s
                     with open(path, "rb") as f:
                         raw = f.read()
                     n = int.from_bytes(raw[:4], "little")
-                    if fresh and raw[4:4 + n] == tag and len(raw) == 4 + n + _lib.RCCL_ID_BYTES:
+                    if raw[4:4 + n] == tag and len(raw) == 4 + n + _lib.RCCL_ID_BYTES:
                         uid = raw[4 + n:]
                         break
                 except OSError:

@@ -155,13 +155,10 @@ def partition_model(model, ele_part, only=None, glob_data=None, device=None):
         contiguous = E and node_off[0, 0] == 0 and np.all(node_off[1:, 0] == node_off[:-1, 1] + 1) and node_off[-1, 1] + 1 == len(node_flat)
         flat_nodes = node_flat if contiguous else _ragged_take(node_flat, node_off, np.arange(E))[0]
     if n_total > 1 and device is not None:
-        try:
-            if_node, if_part = _gpu_interface(device, n_dof_glob // 3 + 1, np.concatenate([[0], np.cumsum(n_per)]), flat_nodes, ele_part, n_total)
-        except Exception as ex:                                  # noqa: BLE001 - the host path below is always available
-            import warnings
-            warnings.warn(f"device interface pass failed ({ex}); using the NumPy path for the partition set-up")
-            device = None
-    if n_total > 1 and device is None and len(if_node) == 0:
+        # (round 4, ADVICE r3: no blanket fallback - a failing device pass is an error of the run, not a warning; callers whose
+        #  library has no device side, i.e. the CPU test double, pass device=None: pcg_mi355x.run does)
+        if_node, if_part = _gpu_interface(device, n_dof_glob // 3 + 1, np.concatenate([[0], np.cumsum(n_per)]), flat_nodes, ele_part, n_total)
+    if n_total > 1 and device is None:
         part_of_flat = np.repeat(ele_part.astype(np.int32), n_per)
         rec = np.full(n_dof_glob // 3 + 1, -1, np.int32)
         rec[flat_nodes] = part_of_flat
@@ -195,19 +192,15 @@ def partition_model(model, ele_part, only=None, glob_data=None, device=None):
         on_device = device is not None
         if on_device:
             # the dof list is the node list times three (dof = 3 * node + dir, :688-690,:826): checked, then derived; a model
-            # numbered differently, or a failing device pass, takes the NumPy branch (any numbering) with a warning
+            # numbered differently takes the NumPy branch (any numbering) with a warning; a failing device pass raises
             import warnings
             if not np.array_equal(cum_dof.reshape(-1, 3), 3 * cum_node[:, None] + np.arange(3)[None, :]):
                 warnings.warn("dof ids are not node-blocked (dof = 3 * node + dir): partition set-up on the host")
                 on_device = False
             else:
-                try:
-                    nodes, loc_node = _gpu_local_numbering(device, n_dof_glob // 3 + 1, cum_node)   # :252, getIndices :58-67
-                    dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()                     # :256
-                    loc_dof = (3 * loc_node[:, None] + np.arange(3)[None, :]).ravel()
-                except Exception as ex:                          # noqa: BLE001
-                    warnings.warn(f"device numbering pass failed ({ex}); using the NumPy path for this part")
-                    on_device = False
+                nodes, loc_node = _gpu_local_numbering(device, n_dof_glob // 3 + 1, cum_node)   # :252, getIndices :58-67
+                dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()                     # :256
+                loc_dof = (3 * loc_node[:, None] + np.arange(3)[None, :]).ravel()
         if not on_device:
             nodes = np.unique(cum_node)                                                    # :252
             dofs = np.unique(cum_dof)                                                      # :256

@@ -130,7 +130,7 @@ def _main_group(args, n_parts):
             ele_part = mdf_mod.read_mesh_part(args.mdf, n_parts)
         except FileNotFoundError:
             ele_part = geometric_partition(model, n_parts)
-        parts = partition_model(model, ele_part, device=0)
+        parts = partition_model(model, ele_part, device=0 if _lib.backend_name() == "hip-gfx950" else None)   # index passes on the GPU
         for P, gd in zip(parts, gds):
             gd.update(P["GlobData"])
             P["GlobData"] = gd
@@ -227,7 +227,8 @@ def main(argv=None):
             ele_part = mdf_mod.read_mesh_part(args.mdf, n_parts)
         except FileNotFoundError:
             ele_part = geometric_partition(model, n_parts)            # deterministic: every rank computes the same vector
-        part = partition_model(model, ele_part, only=[rank], device=dev)[0]   # index passes on the GPU (csrc/part_setup.hip)
+        from . import _lib as _l
+        part = partition_model(model, ele_part, only=[rank], device=dev if _l.backend_name() == "hip-gfx950" else None)[0]   # index passes on the GPU (csrc/part_setup.hip); the CPU test double has none
         gd.update(part["GlobData"])                                   # readModelData :107-108
         part["GlobData"] = gd
         del model

@@ -332,7 +332,13 @@ public:
         }
     }
     // PCG_VEC_FUSED=0 keeps the driver on the split form, like the product
-    bool vec_fused_available() const override { const char *e = std::getenv("PCG_VEC_FUSED"); return !(e && std::atoi(e) == 0); }
+    bool vec_fused_available() const override { const char *e = std::getenv("PCG_VEC_FUSED"); return !fused_broken_ && !(e && std::atoi(e) == 0); }
+    // Fault injection: the PCG_TEST_VEC_ERR_AT-th fused vector "launch" of this engine behaves like a k_vec<true> whose grid barrier
+    // timed out: r', x' written, no sums, no p', st[ERR] raised - the driver has to finish the iteration in the split form.
+    bool fused_broken_ = false;
+    int64_t n_fused_ = 0;
+    const int64_t vec_err_at_ = std::getenv("PCG_TEST_VEC_ERR_AT") ? std::atoll(std::getenv("PCG_TEST_VEC_ERR_AT")) : -1;
+    void vec_fused_failed() override { fused_broken_ = true; st_[ST_ERR] = 0.0; }
     bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rnew, const double *xo,
                     double *xn, const double *minv, double *p_next) override
     {
@@ -357,6 +363,11 @@ public:
             if (w) { up_[2] += rn * rn; up_[3] += z * rn; }
         }
         if (!fused) return false;
+        if (++n_fused_ == vec_err_at_) {
+            st[ST_ERR] = 1.0;
+            for (int64_t i = 0; i < n_; ++i) p_next[i] = std::nan("");
+            return true;
+        }
         for (int k = 0; k < 5; ++k) st[ST_SQP + k] = up_[k];
         const double beta = up_[3] / rho;                                // :475
         for (int64_t i = 0; i < n_; ++i) p_next[i] = minv[i] * rnew[i] + beta * p[i];   // :447, :479

@@ -132,7 +132,7 @@ def main():
         device = int(sys.argv[8]) if len(sys.argv) > 8 else 0
         parts, probe = build(case)
         assert len(parts) == world
-        comm = RcclComm.from_file(rank, world, device, idfile)
+        comm = RcclComm.from_file(rank, world, device, idfile, launch_id=os.path.basename(idfile))    # (a fresh file name per test launch)
         P = parts[rank]
         o = run_rank(P, probe[P["DofVector"]], comm, kind, device, timing)
         np.savez(os.path.join(outdir, f"{case}_{kind}_rank{rank}.npz"), **o)

@@ -26,6 +26,34 @@ def test_header_symbols_exported(product_lib):
     assert set(_lib.EXPORTED_SYMBOLS) == declared
 
 
+def test_clean_clone_builds_with_hipcc_for_gfx950(tmp_path):
+    """Round 3 verdict: the in-tree build is digest-gated and its objects travel with the tree, so `build()` may link nothing.  Here
+    the SOURCES alone (csrc/, include/, __graft_entry__.py - what a fresh clone holds) are copied to an empty directory and compiled
+    from scratch with hipcc --offload-arch=gfx950; the result must export every symbol include/pcg_mi355x.h declares, carry gfx950
+    code objects, and be a different file from the in-tree library."""
+    import importlib.util
+    import shutil
+    pkg = tmp_path / "pcg-mpi-solver_amd"
+    shutil.copytree(os.path.join(ROOT, "pcg-mpi-solver_amd", "csrc"), pkg / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    shutil.copy(os.path.join(ROOT, "__graft_entry__.py"), tmp_path / "__graft_entry__.py")
+    assert not (pkg / "build").exists() and not (pkg / "lib").exists()
+    spec = importlib.util.spec_from_file_location("graft_entry_clean_clone", tmp_path / "__graft_entry__.py")
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    assert ge.ROOT == str(tmp_path)
+    lib_path = ge.build_engine(force=True)
+    assert lib_path.startswith(str(tmp_path)) and os.path.getsize(lib_path) > 1_000_000
+    assert sorted(os.listdir(pkg / "build")) == sorted([s + ext for s in ge.SOURCES for ext in (".o", ".o.sha")])
+    hdr = open(os.path.join(ROOT, "include", "pcg_mi355x.h")).read()
+    declared = set(re.findall(r"\b(pcg_[a-z0-9_]+)\s*\(", hdr)) - {"pcg_comm_hooks"}
+    lib = ctypes.CDLL(lib_path)
+    assert not [s for s in sorted(declared) if not hasattr(lib, s)]
+    lib.pcg_abi_version.restype = ctypes.c_int
+    assert lib.pcg_abi_version() == int(re.search(r"#define PCG_ABI_VERSION (\d+)", hdr).group(1))
+    assert "gfx950" in subprocess.run(["strings", lib_path], capture_output=True, text=True).stdout
+
+
 def test_product_has_only_the_hip_backend(product_lib):
     lib = ctypes.CDLL(product_lib)
     lib.pcg_backend_name.restype = ctypes.c_char_p

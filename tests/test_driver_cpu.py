@@ -175,6 +175,36 @@ def test_fused_vector_launch_changes_nothing(hostops, monkeypatch, case, la):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("la", ["1", "0"])
+@pytest.mark.parametrize("at", [1, 2, 17])
+@pytest.mark.parametrize("case", ["n9_p1", "n9_stagnate", "oct_p1"])
+def test_fused_launch_time_out_is_finished_in_the_split_form(hostops, monkeypatch, case, at, la):
+    """a fused vector launch whose grid barrier times out (a workgroup of its grid not resident) no longer ends the
+    solve.  The test double injects the failure into the `at`-th fused launch (r', x' written; no sums, no p', st[ERR] raised, p'
+    filled with NaN): the driver finishes that iteration in the split form - the bits of an undisturbed solve - keeps to the
+    split form afterwards and counts the event in pcg_result.fused_fallbacks."""
+    from pcg_mi355x.operator import from_refmeshpart
+    monkeypatch.setenv("PCG_LOOK_AHEAD", la)
+    out = []
+    for inject in (None, str(at)):
+        if inject is None: monkeypatch.delenv("PCG_TEST_VEC_ERR_AT", raising=False)
+        else: monkeypatch.setenv("PCG_TEST_VEC_ERR_AT", inject)
+        _, parts = golden_cases.build_case(case)
+        P = parts[0]
+        op = from_refmeshpart(P)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, res, hist = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"],
+                                P["GlobData"]["GlobNDofEff"], history=True)
+        out.append((x, (res.flag, res.iter, res.relres, res.iters_done), hist, res.fused_fallbacks))
+        if inject is not None:                                     # the engine stays usable, in the split form
+            x2, res2, _ = op.solve(fext, P["Un"], op.build_jacobi(), P["GlobData"]["Tol"], P["GlobData"]["MaxIter"], P["GlobData"]["GlobNDofEff"])
+            assert res2.fused_fallbacks == 0 and np.array_equal(x2, x)
+        op.close()
+    assert out[0][3] == 0 and out[1][3] == 1
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+
+
 def test_dropped_look_ahead_leaves_no_stop_flag_behind(hostops, monkeypatch):
     """the device stop flag is sticky within a solve.  A look-ahead iteration that is DROPPED because its
     predecessor entered the true-residual branch (:527) and the loop goes on (:544-546) may have raised it (p.Ap <= 0

@@ -249,6 +249,33 @@ def test_solve_is_bit_identical_with_and_without_the_fused_vector_launch(gpu_lib
     op.close()
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_fused_launch_time_out_is_finished_in_the_split_form_on_gpu(gpu_lib, monkeypatch, kind):
+    """with a spin limit of zero (PCG_TEST_VEC_SPINS) every workgroup of k_vec<true> that is not the last to arrive gives
+    up at the grid barrier - what a non-resident workgroup causes in production.  Every such workgroup reports (st[ERR]), the host
+    finishes the iteration in the split form from r', x' (complete before the barrier) and keeps to the split form: the same
+    bits as an undisturbed solve, pcg_result.fused_fallbacks == 1, and the engine stays usable."""
+    from pcg_mi355x.operator import from_refmeshpart
+    b = Brick(24)
+    P = make_parts(b)[0]
+    res = {}
+    for spins in (None, "0"):
+        if spins is None: monkeypatch.delenv("PCG_TEST_VEC_SPINS", raising=False)
+        else: monkeypatch.setenv("PCG_TEST_VEC_SPINS", spins)
+        op = from_refmeshpart(P, kind=kind)
+        fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+        x, r, hist = op.solve(fext, None, op.build_jacobi(), 1e-9, 10000, P["GlobData"]["GlobNDofEff"], history=True)
+        res[spins] = (x, r.flag, r.iter, r.relres, hist, r.fused_fallbacks)
+        if spins is not None:
+            monkeypatch.delenv("PCG_TEST_VEC_SPINS")
+            x2, r2, _ = op.solve(fext, None, op.build_jacobi(), 1e-9, 10000, P["GlobData"]["GlobNDofEff"])
+            assert r2.fused_fallbacks == 0 and np.array_equal(x2, x)               # split form from now on, same bits
+        op.close()
+    assert res[None][5] == 0 and res["0"][5] == 1
+    assert res[None][1:4] == res["0"][1:4]
+    assert np.array_equal(res[None][4], res["0"][4]) and np.array_equal(res[None][0], res["0"][0])
+
+
 @pytest.mark.parametrize("name", SINGLE)
 def test_solve_matches_reference_fixture(gpu_lib, name):
     brick, parts = golden_cases.build_case(name)
