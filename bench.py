@@ -260,39 +260,65 @@ def scalar_csr_point(dev, n_side=100):
             "GBps_12nnz_20n": (12.0 * nnz + 20.0 * n) / t / 1e9, "frac_of_peak": (12.0 * nnz + 20.0 * n) / t / 1e9 / HBM_PEAK_GBS}
 
 
-def cpu_baseline(part, N, ranks=0, workload="brick"):
-    """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core."""
+def cpu_baseline(part, N, ranks=0, workload="brick", quick=False):
+    """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core.
+    `value` (round 4) = the reference's OWN NumPy arithmetic per rank (pcg_oracle with use_c=False: bit-identical to the unmodified
+    pcg_solver.py on every fixture); the C port of the mat-vec - ~2x slower per dof, round 3's `value` - stays as `c_port`.
+    N: nodes per side of the brick, or "octree:<size>" (parts by recursive bisection, mp_baseline.worker).  quick: the NumPy
+    R-process run only (the `octree` object of the default line)."""
     import mp_baseline
     avail = mp_baseline.available_cores()
-    single = cpu_baseline_single(part)
     out = {"kind": "port", "unit": "iterations/s", "host_cpu": _cpu_model(), "host_cores_available": avail,
-           "single_core": single}
+           "arithmetic": "oracle/pcg_oracle.py with the reference's NumPy expressions (use_c=False; bit-identical to src/solver/pcg_solver.py, "
+                         "oracle/make_golden.py), BLAS pinned to 1 thread per rank like pcg_solver.py:10-15"}
+    single = None
     try:
-        out["numpy_reference_path"] = numpy_reference_point(part)
+        out["numpy_reference_path"] = single = numpy_reference_point(part)
     except Exception as ex:      # noqa: BLE001 - the line must survive
         log(f"NumPy reference-path point failed: {ex!r}")
-    try:
-        out["scipy_csr_spmv"] = scipy_csr_spmv_point()
-    except Exception as ex:      # noqa: BLE001 - informational only
-        log(f"scipy CSR SpMV point failed: {ex!r}")
+    if not quick:
+        try:
+            out["single_core_c_port"] = cpu_baseline_single(part)
+        except Exception as ex:  # noqa: BLE001
+            log(f"single-core C-port point failed: {ex!r}")
+        try:
+            out["scipy_csr_spmv"] = scipy_csr_spmv_point()
+        except Exception as ex:      # noqa: BLE001 - informational only
+            log(f"scipy CSR SpMV point failed: {ex!r}")
     R = ranks or min(avail, 64)
-    if workload != "brick" or R < 2:
+    if single is not None:
         out.update(value=single["value"], cores=1, sample=single["sample"])
+    if R < 2:
         return out
-    iters = int(max(10, min(200, 15.0 * single["value"] * R * 0.5)))     # ~15 s of solve at half-ideal speed-up
+    extra = ["--octree", N.split(":", 1)[1]] if isinstance(N, str) else ["--nodes-per-side", str(N)]
+
+    def mp_run(numpy_path, iters):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mp_baseline.py"), "--ranks", str(R), "--iters", str(iters)] + extra +
+                           (["--numpy"] if numpy_path else []), capture_output=True, text=True, timeout=600)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # sample size: ~12 s of solve at 60 % parallel efficiency, estimated from the one-core rate per dof
+    per_dof_s = 1.0 / (single["value"] * single["dofs"]) if single else 4.5e-8
+    est = 0.6 * R / (per_dof_s * float(part["NDOF"]))
+    iters = int(max(10, min(400, 12.0 * est)))
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mp_baseline.py"), "--nodes-per-side", str(N), "--ranks", str(R),
-                            "--iters", str(iters)], capture_output=True, text=True, timeout=600)
-        mp = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        mp = mp_run(True, iters)
+        what = f"{R} parts ({mp['grid'] if isinstance(mp['grid'], str) else 'x'.join(map(str, mp['grid'])) + ' blocks'})"
         out.update(value=mp["value"], cores=R,
-                   sample=f"first {iters} PCG iterations of the same system split into {R} parts ({'x'.join(map(str, mp['grid']))} blocks), "
-                          f"{R} processes x 1 thread = the reference's one-part-per-rank mode (oracle/mp_baseline.py: pcg_oracle.py + "
-                          f"ebe_matvec.c per rank, shared-memory exchange)",
+                   sample=f"first {iters} PCG iterations of the same system split into {what}, {R} processes x 1 thread = the reference's "
+                          f"one-part-per-rank mode (oracle/mp_baseline.py --numpy: pcg_oracle.py per rank with the reference's NumPy mat-vec, "
+                          f"shared-memory exchange)",
                    calc_s_mean=mp["calc_s_mean"], comm_wait_s_mean=mp["comm_wait_s_mean"], t_solve_s=mp["t_solve_s"],
                    dofs_per_rank_max=mp["dofs_per_rank_max"])
     except Exception as ex:      # noqa: BLE001 - the GPU line must survive a failure of the CPU side measurement
         log(f"multi-process CPU baseline failed: {ex!r}")
-        out.update(value=single["value"], cores=1, sample=single["sample"], multi_core_error=repr(ex))
+        out["multi_core_error"] = repr(ex)
+    if not quick:
+        try:
+            mp = mp_run(False, int(max(10, min(200, iters // 2))))
+            out["c_port"] = {"value": mp["value"], "cores": R, "note": "same R-process run with the C port of the EBE mat-vec (oracle/ebe_matvec.c); "
+                             "round 3 quoted this as cpu_baseline.value", "t_solve_s": mp["t_solve_s"], "iterations": mp["iterations"]}
+        except Exception as ex:  # noqa: BLE001
+            log(f"multi-process C-port run failed: {ex!r}")
     return out
 
 
@@ -326,7 +352,7 @@ def pmc_traffic_live(args):
     return out
 
 
-def octree_object(measure, log):
+def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
     """BASELINE configs[1] names "a synthetic 3D elasticity octree mesh, 1M DOFs": the multi-level graded octree mesh of
     pcg_mi355x.octree.GradedOctreeMesh (5 cell sizes, 2:1 balanced over faces / edges / corners, ~95 pattern types with 9-20
     nodes besides hex8) on all three operators - iterations/s, operator time, what the formats make of it."""
@@ -357,6 +383,11 @@ def octree_object(measure, log):
         op.close()
         log(f"[octree {kind}] {e['value']:.0f} it/s, operator {e['operator_avg_ms']:.4f} ms, solve {e['solve']}")
     opart.pop("_pcg_mi355x_operator", None)
+    if with_cpu:                 # north_star: "next to the reference CPU pcg_solver.py timed on the node's own host cores in the same run"
+        try:
+            obj["cpu_baseline"] = cpu_baseline(opart, "octree:1m", cpu_ranks, "octree", quick=True)
+        except Exception as ex:  # noqa: BLE001
+            log(f"octree CPU baseline failed: {ex!r}")
     # The value dictionary needs <= 65535 distinct 3x3 blocks.  The random two-phase material above (Ck in {1, 3} x cell size, per
     # element) makes 151 716 of them on this mesh - the plain format is used, `table.distinct_blocks` = 0 says so.  With ONE
     # material (Ck = cell size) the same mesh has 22 333: the dictionary applies, its head sits in LDS, the tail goes through L2.
@@ -757,13 +788,13 @@ def main():
             out["comm"].update(head["comm"])
     if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:
         try:
-            out["octree"] = octree_object(measure, log)
+            out["octree"] = octree_object(measure, log, with_cpu=not args.no_cpu_baseline, cpu_ranks=args.cpu_ranks)
         except Exception as ex:          # noqa: BLE001 - the headline line must survive
             log(f"octree object failed: {ex!r}")
             out["octree"] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:
-        log("timing the CPU baseline (oracle port: 1 core, then R processes x 1 thread) ...")
-        out["cpu_baseline"] = cpu_baseline(part, N, args.cpu_ranks, args.workload)
+        log("timing the CPU baseline (the reference's NumPy arithmetic: 1 core, then R processes x 1 thread; the C port beside it) ...")
+        out["cpu_baseline"] = cpu_baseline(part, N if args.workload == "brick" else f"octree:{args.octree_size}", args.cpu_ranks, args.workload)
     print(json.dumps(out), flush=True)
     shutdown()
 

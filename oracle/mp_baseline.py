@@ -13,7 +13,9 @@ Synchronisation is a spinning epoch barrier on shared counters (mpi4py / mpiexec
 two functions is the 'communication wait' bucket, everything else 'calculation', as the reference's updateTime does
 (:631-641); the report gives the mean over ranks like configTimeRecData (file_operations.py:101-109).
 
-usage: python oracle/mp_baseline.py --nodes-per-side 150 --ranks 64 --iters 20   -> one JSON line on stdout
+usage: python oracle/mp_baseline.py --nodes-per-side 150 --ranks 64 --iters 20 [--numpy] [--octree 1m]   -> one JSON line on stdout
+--numpy: the reference's own NumPy expressions for the mat-vec (bit-identical to pcg_solver.py, oracle/make_golden.py) instead of
+the C port - what bench.py quotes as cpu_baseline.value since round 4 (the C port is ~2x slower per dof and stays a secondary field).
 """
 from __future__ import annotations
 
@@ -90,7 +92,12 @@ class Shm:
             pass
 
 
+OCTREE_ROOTS = {"1m": (12, 12, 12), "10m": (38, 38, 38), "tiny": (3, 3, 3)}
+
+
 def worker(rank, R, N, iters, prefix, use_c):
+    """N: nodes per side of the brick (int), or "octree:<size>" = the graded octree mesh of bench.py's octree workload
+    (pcg_mi355x.octree.GradedOctreeMesh, parts by recursive bisection of the element centroids - the METIS stand-in)."""
     import pcg_oracle
     from pcg_mi355x.brick import Brick, make_parts, block_partition
     ctl = Shm(prefix + "_ctl")
@@ -110,8 +117,14 @@ def worker(rank, R, N, iters, prefix, use_c):
             if spins > 2000:                      # a late rank: stop burning the core it may need
                 time.sleep(5e-5)
 
-    brick = Brick(N, seed=0)
-    P = make_parts(brick, block_partition(brick, *grid_for(R)) if R > 1 else None, only=[rank])[0]
+    if isinstance(N, str) and N.startswith("octree:"):
+        from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
+        mesh = GradedOctreeMesh(OCTREE_ROOTS[N.split(":", 1)[1]], 4 if N != "octree:tiny" else 3, band=1.2, seed=0)
+        P = make_octree_parts(mesh, R, elem_part=bisect_elements(mesh, R) if R > 1 else None)[rank]
+        del mesh
+    else:
+        brick = Brick(N, seed=0)
+        P = make_parts(brick, block_partition(brick, *grid_for(R)) if R > 1 else None, only=[rank])[0]
     nbrs = [int(v) for v in P["NbrMPIdVector"]]
     ovl = [np.asarray(v, np.int64) for v in P["OvrlpLocalDofVecList"]]
     cnt = [len(v) for v in ovl]
@@ -214,7 +227,8 @@ def run(N, R, iters, use_c=True):
         raise RuntimeError(bad[0])
     t_solve = max(r["t_solve"] for r in res)
     comm = float(np.mean([r["t_comm"] for r in res]))
-    return {"value": iters / t_solve, "unit": "iterations/s", "cores": R, "kind": "port", "grid": list(grid_for(R)),
+    return {"value": iters / t_solve, "unit": "iterations/s", "cores": R, "kind": "port" if use_c else "reference arithmetic (NumPy)",
+            "grid": list(grid_for(R)) if not isinstance(N, str) else f"{R} parts by recursive bisection",
             "iterations": iters, "n_matvec": res[0]["n_matvec"], "t_solve_s": t_solve,
             "calc_s_mean": float(np.mean([r["t_solve"] - r["t_comm"] for r in res])), "comm_wait_s_mean": comm,
             "dofs_per_rank_max": max(r["ndof"] for r in res), "neighbours_max": max(r["n_nbr"] for r in res),
@@ -224,12 +238,13 @@ def run(N, R, iters, use_c=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nodes-per-side", type=int, default=150)
+    ap.add_argument("--octree", choices=sorted(OCTREE_ROOTS), default=None, help="the graded octree mesh of bench.py --workload octree instead of the brick")
     ap.add_argument("--ranks", type=int, default=0, help="0 = min(available cores, 64)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--numpy", action="store_true", help="NumPy EBE mat-vec (the reference's expressions) instead of the C port")
     a = ap.parse_args()
     R = a.ranks or min(available_cores(), 64)
-    print(json.dumps(run(a.nodes_per_side, R, a.iters, not a.numpy)), flush=True)
+    print(json.dumps(run(f"octree:{a.octree}" if a.octree else a.nodes_per_side, R, a.iters, not a.numpy)), flush=True)
 
 
 if __name__ == "__main__":

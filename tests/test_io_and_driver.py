@@ -133,3 +133,10 @@ def test_multi_process_cpu_baseline_matches_one_process(oracle_c):
     assert one["n_matvec"] == four["n_matvec"] == 27
     assert abs(one["relres_after"] / four["relres_after"] - 1) < 1e-9
     assert four["cores"] == 4 and four["comm_wait_s_mean"] > 0
+    # round 4: the reference's own NumPy arithmetic per rank (bench.py's cpu_baseline.value) and the octree workload (bisected parts)
+    np_four = mp_baseline.run(13, 4, 25, use_c=False)
+    assert np_four["kind"].startswith("reference arithmetic") and abs(np_four["relres_after"] / one["relres_after"] - 1) < 1e-9
+    o1 = mp_baseline.run("octree:tiny", 1, 20, use_c=False)
+    o3 = mp_baseline.run("octree:tiny", 3, 20, use_c=False)
+    assert o1["n_matvec"] == o3["n_matvec"] == 22 and abs(o1["relres_after"] / o3["relres_after"] - 1) < 1e-9
+    assert o3["neighbours_max"] >= 1 and o3["dofs_per_rank_max"] < o1["dofs_per_rank_max"]
