@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the SpMV launch on this box (N = 1; they run "
                          "by default when rocprofv3 is on PATH and this process is not itself being profiled)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)       # internal: the workload of one rocprofv3 --pmc pass (pmc_traffic_live)
     ap.add_argument("--pmc-traffic", action="store_true",
                     help="N = 1: measure the HBM traffic of the SpMV launch on THIS box with two extra rocprofv3 --pmc passes of a short "
                          "run of this script (FETCH_SIZE, WRITE_SIZE; +1-2 min) instead of quoting profiles/pmc_traffic.json")
@@ -260,6 +261,27 @@ def scalar_csr_point(dev, n_side=100):
             "GBps_12nnz_20n": (12.0 * nnz + 20.0 * n) / t / 1e9, "frac_of_peak": (12.0 * nnz + 20.0 * n) / t / 1e9 / HBM_PEAK_GBS}
 
 
+def scalar_csr_point_device(op):
+    """SURVEY 8(d)'s literal "CSR SpMV" at the bench's OWN size (round 4): the assembled operator's scalar-CSR copy - one f64 value +
+    one i32 column per non-zero, expanded from the 3x3-block format on the device (pcg_create_scalar_copy, no 10 GB host CSR) -
+    20 back-to-back launches of k_spmv_scalar, GB/s in the formula's own bytes 12 nnz + 20 n, which is what this kernel moves."""
+    import numpy as np
+    sc = op.scalar_copy()
+    try:
+        nnz, n = int(sc.nnz), int(sc.n)
+        ms = sc.bench_spmv(5, 20)
+        by, _ = sc.operator_cost()
+        info = sc.matrix_info()
+    finally:
+        sc.close()
+    t = float(np.median(ms)) * 1e-3
+    return {"kernel": "k_spmv_scalar (SELL-64 over scalar rows: f64 value + i32 column per stored non-zero; the operator is the device-side "
+                      "scalar copy of the headline matrix, pcg_create_scalar_copy)", "n": n, "nnz": nnz, "stored_nonzeros": int(info["stored_blocks"]),
+            "median_launch_ms": t * 1e3, "min_launch_ms": float(ms.min()), "launches": 20, "bytes_12nnz_20n": 12.0 * nnz + 20.0 * n, "stored_bytes": by,
+            "GBps_12nnz_20n": (12.0 * nnz + 20.0 * n) / t / 1e9, "frac_of_peak": (12.0 * nnz + 20.0 * n) / t / 1e9 / HBM_PEAK_GBS,
+            "GBps_stored": by / t / 1e9, "frac_of_peak_stored": by / t / 1e9 / HBM_PEAK_GBS}
+
+
 def cpu_baseline(part, N, ranks=0, workload="brick", quick=False):
     """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core.
     `value` (round 4) = the reference's OWN NumPy arithmetic per rank (pcg_oracle with use_c=False: bit-identical to the unmodified
@@ -322,33 +344,104 @@ def cpu_baseline(part, N, ranks=0, workload="brick", quick=False):
     return out
 
 
-def pmc_traffic_live(args):
-    """HBM bytes per k_spmv<1,true> launch on this box: rocprofv3 --kernel-trace --pmc <counter> passes (one counter per pass, as
-    MI355X_MICROARCH.md prescribes) of a short assembled-operator run of this script; FETCH_SIZE x2 (gfx950: 128-B requests are
-    tallied at 64 B for wide streaming reads - calibrated on the vector kernels in profiles/pmc_traffic.json), WRITE_SIZE as is."""
+PMC_MARKER = "k_stream_copy"        # pcg_bench_hbm(mode copy): the launches that bracket a segment of the PMC child run
+
+
+def pmc_child(args):
+    """The workload of one rocprofv3 --pmc pass (pmc_traffic_live): for every segment `workload:operator` build the operator, then
+    marker launches / 3 + K PCG iterations / marker launches - the parent finds the segment's dispatches between the two marker runs."""
+    import numpy as np
+    import pcg_mi355x as pm
+    from pcg_mi355x import _lib
+    from pcg_mi355x.brick import Brick, make_parts
+    _lib.use_library(None)
+    parts = {}
+    for seg in args.pmc_child.split(","):
+        wl, kind = seg.split(":")
+        if wl not in parts:
+            if wl == "octree":
+                from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+                parts[wl] = make_octree_parts(GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size], 4, band=1.2, seed=0), 1)[0]
+            else:
+                parts[wl] = make_parts(Brick(args.nodes_per_side, seed=0))[0]
+        part = parts[wl]
+        part.pop("_pcg_mi355x_operator", None)
+        pm.configure(comm=None, device=0, rows_per_lane=args.rows_per_lane, operator=kind)
+        op = pm.get_operator(part)
+        pm.update_bc(part); pm.update_preconditioner(part)
+        eff = np.asarray(part["LocDofEff"], np.int64)
+        inv = np.zeros(op.n); inv[eff] = part["InvDiagPreCondVector0"]
+        op.solve_begin(part["Fext"], np.zeros(op.n), inv, 1e-30, 1000, int(part["GlobData"]["GlobNDofEff"]))
+        op.solve_run(3)
+        op.bench_hbm(1 << 22, "copy", 1)                       # ---- marker
+        op.solve_run(args.steps)
+        op.bench_hbm(1 << 22, "copy", 1)                       # ---- marker
+        op.solve_end()
+        op.close()
+        part.pop("_pcg_mi355x_operator", None)
+
+
+PMC_OPERATOR_KERNELS = {"sell": ("k_spmv",), "dict": ("k_spmv_dict",), "ebe": ("k_ebe",)}      # substrings of the kernels of one operator apply
+PMC_PRIMARY = {"sell": ("k_spmv<", "k_spmv_win<"), "dict": ("k_spmv_dict<",), "ebe": ("k_ebe_hexs<", "k_ebe_hex<", "k_ebe_mixed<")}   # one launch per apply
+
+
+def pmc_traffic_live(args, segments):
+    """HBM bytes per operator apply (and per k_vec launch) on THIS box: rocprofv3 --kernel-trace --pmc <counter> passes (one counter
+    per pass, as MI355X_MICROARCH.md prescribes) of a short run of this script (pmc_child) over `segments` = ["brick:sell", ...];
+    FETCH_SIZE x2 (gfx950: 128-B requests are tallied at 64 B for wide streaming reads - calibrated on the vector kernels in
+    profiles/pmc_traffic.json), WRITE_SIZE as is.  -> {segment: {"bytes", "FETCH_SIZE_KB_raw", "WRITE_SIZE_KB_raw", "applies",
+    "kernels": {name: bytes per apply}, "vec": {...}}}"""
     import glob
     import sqlite3
     import tempfile
-    vals = {}
+    raw = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pcg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "20", "--warmup", "3", "--operator", "sell", "--no-cpu-baseline", "--no-finish", "--no-pmc-traffic",
-               "--nodes-per-side", str(args.nodes_per_side), "--rows-per-lane", str(args.rows_per_lane)]
-        subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+               "--pmc-child", ",".join(segments), "--steps", "12", "--nodes-per-side", str(args.nodes_per_side), "--octree-size", args.octree_size,
+               "--rows-per-lane", str(args.rows_per_lane)]
+        subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
         db = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
-        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_spmv<1, true%' and counter_name = ?",
-                          (ctr,)).fetchall()
-        vals[ctr] = (float(rows[0][0]), int(rows[0][1]))
-        rows = db.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_vec<true>%' and counter_name = ?",
-                          (ctr,)).fetchall()
-        vals["vec_" + ctr] = (float(rows[0][0] or 0.0), int(rows[0][1]))
-    out = {"bytes": 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"][0],
-           "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1]}
-    if vals["vec_FETCH_SIZE"][1] > 0:             # the vector-phase launch of the same passes (16-B streaming loads: the same x2 correction)
-        out["vec"] = {"bytes": 2.0 * vals["vec_FETCH_SIZE"][0] * 1024 + vals["vec_WRITE_SIZE"][0] * 1024,
-                      "FETCH_SIZE_KB_raw": vals["vec_FETCH_SIZE"][0], "WRITE_SIZE_KB_raw": vals["vec_WRITE_SIZE"][0],
-                      "dispatches": vals["vec_FETCH_SIZE"][1]}
+        rows = db.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name = ? order by dispatch_id", (ctr,)).fetchall()
+        # the dispatch sequence is [set-up 0] M [body 0] M [set-up 1] M [body 1] M ... (M = a run of marker launches)
+        groups, in_marker = [[]], False
+        for _, name, val in rows:
+            if PMC_MARKER in name:
+                if not in_marker:
+                    groups.append([])
+                in_marker = True
+            else:
+                in_marker = False
+                groups[-1].append((name, float(val)))
+        bodies = groups[1::2]
+        if len(bodies) != len(segments):
+            raise RuntimeError(f"PMC pass {ctr}: {len(bodies)} marked segments found, {len(segments)} expected")
+        raw[ctr] = bodies
+    out = {}
+    for i, seg in enumerate(segments):
+        kind = seg.split(":")[1]
+        res = {"kernels": {}}
+        applies = sum(1 for name, _ in raw["FETCH_SIZE"][i] if any(p in name for p in PMC_PRIMARY[kind]))
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        vec = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            for name, val in raw[ctr][i]:
+                if any(k in name for k in PMC_OPERATOR_KERNELS[kind]):
+                    tot[ctr] += val
+                    short = name.split("(")[0].replace("void pcg::", "")
+                    res["kernels"].setdefault(short, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[ctr] += val
+                elif "k_vec<true>" in name:
+                    vec[ctr] += val
+                    vec["n"] += ctr == "FETCH_SIZE"
+        if applies == 0:
+            raise RuntimeError(f"PMC segment {seg}: no operator launch found")
+        res.update(bytes=(2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / applies, FETCH_SIZE_KB_raw=tot["FETCH_SIZE"] / applies,
+                   WRITE_SIZE_KB_raw=tot["WRITE_SIZE"] / applies, applies=applies, dispatches=applies)
+        res["kernels"] = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / applies for k, v in res["kernels"].items()}
+        if vec["n"]:
+            res["vec"] = {"bytes": (2.0 * vec["FETCH_SIZE"] + vec["WRITE_SIZE"]) * 1024 / vec["n"], "FETCH_SIZE_KB_raw": vec["FETCH_SIZE"] / vec["n"],
+                          "WRITE_SIZE_KB_raw": vec["WRITE_SIZE"] / vec["n"], "dispatches": vec["n"]}
+        out[seg] = res
     return out
 
 
@@ -371,6 +464,10 @@ def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
              "vector_phase_ms": mm["vec"]["avg_launch_ms"] if mm["vec"] else None}
         by, fl = op.operator_cost()
         e["operator_bytes"], e["operator_flops"] = by, fl
+        t_op = mm["op_ms"] * 1e-3
+        e["roofline"] = {"bound": "hbm", "bytes_per_apply": by, "avg_apply_ms": mm["op_ms"], "achieved": by / t_op / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": by / t_op / 1e9 / HBM_PEAK_GBS, "flops_per_apply": fl, "frac_flops": fl / t_op / 1e12 / F64_PEAK_TFLOPS, "traffic": None,
+                         "bytes_definition": "what the stored structures of one apply have to move (pcg_operator_cost), all launches of the apply together"}
         if kind in ("sell", "dict"):
             info = op.matrix_info()
             e["sell_padding"] = info["stored_blocks"] / max(1, info["nnzb"]) - 1
@@ -431,6 +528,8 @@ def box_identity(dev):
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -620,6 +719,13 @@ def main():
         if rank == 0:                                # what THIS box's HBM delivers to a plain stream kernel on the engine's stream
             stream = {"read_GBps": op.bench_hbm(8 << 30, "read", 10), "copy_GBps": op.bench_hbm(1 << 30, "copy"),
                       "note": "pcg_bench_hbm: 16 B/lane non-temporal grid-stride kernels over 8 GiB (read, 8 loads in flight per lane) / 1 + 1 GiB (copy)"}
+        scalar_point = None
+        if rank == 0 and world == 1 and args.workload == "brick" and not args.no_finish:
+            try:
+                scalar_point = scalar_csr_point_device(op)        # the literal CSR volume at THIS size, built on the device
+                log(f"scalar-CSR copy: {scalar_point['nnz']} nnz, {scalar_point['median_launch_ms']:.4f} ms = {scalar_point['frac_of_peak']:.3f} of peak on 12 nnz + 20 n")
+            except Exception as ex:      # noqa: BLE001 - informational
+                log(f"device-side scalar-CSR point failed: {ex!r}")
         if rank == 0:
             if brick.nnz is None:
                 brick.nnz = op.nnz if world == 1 else None
@@ -749,10 +855,13 @@ def main():
             "standalone_spmv": m["standalone"]}
         out["roofline_vector_phase"] = m["vec"]
         if world == 1 and args.workload == "brick" and not args.no_finish:
-            try:
-                out["roofline"]["scalar_csr_same_run"] = scalar_csr_point(dev)
-            except Exception as ex:      # noqa: BLE001 - informational
-                log(f"scalar-CSR point failed: {ex!r}")
+            if scalar_point is not None:
+                out["roofline"]["scalar_csr_same_run"] = scalar_point
+            else:
+                try:
+                    out["roofline"]["scalar_csr_same_run"] = scalar_csr_point(dev)      # host-built CSR at N = 100 (round 3's point)
+                except Exception as ex:      # noqa: BLE001 - informational
+                    log(f"scalar-CSR point failed: {ex!r}")
         try:        # PMC traffic of an identical launch, collected by separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}" + ("_col16" if col_bytes == 2 else ""))
             if pmc and world == 1 and args.workload == "brick":
@@ -761,24 +870,43 @@ def main():
                                                    "(gfx950-corrected), collected on another box in another session - not a measurement of this run")
         except OSError:
             pass
-        import shutil
-        profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ)       # already under a profiler: no nested passes
-        if world == 1 and not args.no_pmc_traffic and args.workload == "brick" and (args.pmc_traffic or (shutil.which("rocprofv3") and not profiled)):
-            try:
-                live = pmc_traffic_live(args)
-                out["roofline"]["traffic"] = live["bytes"]
-                out["roofline"]["traffic_note"] = ("measured on THIS box by two rocprofv3 --kernel-trace --pmc passes of a 20-step run of this command "
-                                                   f"(FETCH_SIZE {live['FETCH_SIZE_KB_raw']:.0f} KB x2 gfx950 correction + WRITE_SIZE {live['WRITE_SIZE_KB_raw']:.0f} KB, "
-                                                   f"mean of {live['dispatches']} launches)")
-                out["roofline"]["traffic_over_bytes"] = live["bytes"] / sell_bytes
-                if live.get("vec") and out.get("roofline_vector_phase"):
-                    v = out["roofline_vector_phase"]
-                    v["traffic"] = live["vec"]["bytes"]
-                    v["traffic_over_bytes"] = live["vec"]["bytes"] / v["bytes_per_launch"]
-                    v["traffic_note"] = (f"same two PMC passes: FETCH_SIZE {live['vec']['FETCH_SIZE_KB_raw']:.0f} KB x2 + WRITE_SIZE "
-                                         f"{live['vec']['WRITE_SIZE_KB_raw']:.0f} KB, mean of {live['vec']['dispatches']} launches of k_vec<true>")
-            except Exception as ex:      # noqa: BLE001
-                log(f"live PMC traffic measurement failed: {ex!r}")
+    pmc_live = None
+    import shutil
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ)       # already under a profiler: no nested passes
+    if world == 1 and not args.no_pmc_traffic and (args.pmc_traffic or (shutil.which("rocprofv3") and not profiled)):
+        # HBM traffic of THIS run's kernels: two rocprofv3 --pmc passes of a short child run over the operators of this line
+        wl = args.workload
+        segs = [f"{wl}:sell"] if m is not None else []
+        if e is not None:
+            segs.append(f"{wl}:ebe")
+        if wl == "brick" and not args.no_octree and not args.no_finish:
+            segs += ["octree:sell", "octree:ebe"]                  # the `octree` object (1 M dof)
+        try:
+            t0 = time.perf_counter()
+            pmc_live = pmc_traffic_live(args, segs) if segs else None
+            log(f"PMC traffic passes over {segs}: {time.perf_counter() - t0:.0f} s")
+        except Exception as ex:      # noqa: BLE001
+            log(f"live PMC traffic measurement failed: {ex!r}")
+
+    def pmc_note(r):
+        return (f"measured on THIS box by two rocprofv3 --kernel-trace --pmc passes of a short run of this command (FETCH_SIZE {r['FETCH_SIZE_KB_raw']:.0f} KB "
+                f"x2 gfx950 correction + WRITE_SIZE {r['WRITE_SIZE_KB_raw']:.0f} KB per apply, mean of {r['applies']} applies; per kernel: "
+                + ", ".join(f"{k} {v / 1e6:.1f} MB" for k, v in r["kernels"].items()) + ")")
+    if pmc_live and m is not None and f"{args.workload}:sell" in pmc_live:
+        live = pmc_live[f"{args.workload}:sell"]
+        out["roofline"]["traffic"] = live["bytes"]
+        out["roofline"]["traffic_note"] = pmc_note(live)
+        out["roofline"]["traffic_over_bytes"] = live["bytes"] / sell_bytes
+        if live.get("vec") and out.get("roofline_vector_phase"):
+            v = out["roofline_vector_phase"]
+            v["traffic"] = live["vec"]["bytes"]
+            v["traffic_over_bytes"] = live["vec"]["bytes"] / v["bytes_per_launch"]
+            v["traffic_note"] = (f"same two PMC passes: FETCH_SIZE {live['vec']['FETCH_SIZE_KB_raw']:.0f} KB x2 + WRITE_SIZE "
+                                 f"{live['vec']['WRITE_SIZE_KB_raw']:.0f} KB, mean of {live['vec']['dispatches']} launches of k_vec<true>")
+    if pmc_live and matrix_free and "roofline" in matrix_free and f"{args.workload}:ebe" in pmc_live:
+        live = pmc_live[f"{args.workload}:ebe"]
+        matrix_free["roofline"].update(traffic=live["bytes"], traffic_over_bytes=live["bytes"] / matrix_free["roofline"]["bytes_per_apply"],
+                                       traffic_note=pmc_note(live))
     if world > 1:
         out["comm"] = {"transport": transport, "ranks": comm.world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in head["per_rank_s"]],
                        "per_rank_setup_s": setup_all}
@@ -789,6 +917,10 @@ def main():
     if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:
         try:
             out["octree"] = octree_object(measure, log, with_cpu=not args.no_cpu_baseline, cpu_ranks=args.cpu_ranks)
+            for key, seg in (("assembled", "octree:sell"), ("matrix_free", "octree:ebe")):
+                if pmc_live and seg in pmc_live and key in out["octree"]:
+                    r = out["octree"][key]["roofline"]
+                    r.update(traffic=pmc_live[seg]["bytes"], traffic_over_bytes=pmc_live[seg]["bytes"] / r["bytes_per_apply"], traffic_note=pmc_note(pmc_live[seg]))
         except Exception as ex:          # noqa: BLE001 - the headline line must survive
             log(f"octree object failed: {ex!r}")
             out["octree"] = {"error": repr(ex)}

@@ -107,6 +107,13 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
                    int64_t n_boundary_nodes, int32_t block, pcg_engine **out);
 /* Matrix-free variant: the operator stays in the reference's element-by-element form
  * (pcg_solver.py:265-300); nothing is assembled.  Same groups / numbering arguments as pcg_asm_create. */
+
+/* The literal CSR data volume of an ASSEMBLED engine (pcg_create / pcg_create_asm, plain 3x3-block format, not split): a second
+ * engine on the same device whose operator stores one f64 value + one i32 column per scalar non-zero (12 B, the format of
+ * pcg_create_csr(block = 1), k_spmv_scalar) - expanded from the block format ON THE DEVICE, so that the "CSR SpMV" point of
+ * SURVEY 8(d) (12 nnz + 20 n bytes) can be measured at the metric's own size without a 10 GB host CSR copy.  Same product
+ * (tested); vectors of the copy have the same length and numbering as src's.  src stays valid and independent. */
+int pcg_create_scalar_copy(pcg_engine *src, pcg_engine **out);
 /* node_coords (n_nodes x 3, ORIGINAL node numbering, may be NULL: RefMeshPart['NodeCoordVec'],
  * partition_mesh.py:357) only steers the spatial clustering of elements into workgroup chunks.
  * flags bit0: disable the chunked (LDS-tiled) form and use one colour per launch for every group;

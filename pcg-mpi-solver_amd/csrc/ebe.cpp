@@ -408,7 +408,9 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
     if (mixed_mode) {
         auto &M = C.mixed;
         auto &K = C.cls[kMixedClass];
-        const int hex_cap = kChunkThreads * ept, tile_cap = ept == 2 ? kMixedMaxTiles : kMixedMaxTiles / 2;
+        int hex_cap = kChunkThreads * ept, tile_cap = ept == 2 ? kMixedMaxTiles : kMixedMaxTiles / 2;
+        if (const char *tv = std::getenv("PCG_EBE_TILE_CAP")) tile_cap = std::max(1, std::atoi(tv));          // development knobs (tools/iter_ab.py)
+        if (const char *hv = std::getenv("PCG_EBE_HEX_CAP")) hex_cap = std::max(16, std::min(kMixedHexSlots, std::atoi(hv)));
         std::vector<int32_t> type_of(n_groups, -1);
         for (size_t t = 0; t < M.types.size(); ++t) type_of[M.types[t].group] = (int32_t)t;
         std::vector<ElemRef> L;

@@ -200,7 +200,7 @@ public:
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
                         (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
-                        (void *)d_ov_vals_, (void *)d_ov_mask_})
+                        (void *)d_ov_vals_, (void *)d_ov_mask_, (void *)d_win_slice_, (void *)d_win_ov_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
             for (void *p : {(void *)D.list[0], (void *)D.list[1], (void *)D.lid, (void *)D.ck, (void *)D.sgn, (void *)D.ke, (void *)D.ke_rows})
@@ -366,7 +366,38 @@ public:
             static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "mask words");
             d_ov_mask_ = (unsigned long long *)alloc(sizeof(uint64_t) * m.ov_mask.size());
             h2d(d_ov_mask_, m.ov_mask.data(), sizeof(uint64_t) * m.ov_mask.size());
+            if (!m.win_slice.empty()) {                          // windowed form: one launch (k_spmv_win)
+                n_windows_ = (int64_t)m.win_slice.size() - 1; n_bnd_windows_ = m.n_bnd_windows;
+                up(d_win_slice_, m.win_slice); up(d_win_ov_, m.win_ov);
+            }
         }
+    }
+    void upload_scalar_copy(Backend &src_be, const std::vector<int64_t> &ptr1, const std::vector<int64_t> &src_ptr, int64_t n_rows) override
+    {
+        auto *S = dynamic_cast<HipBackend *>(&src_be);
+        if (!S || S->dev_ != dev_) throw std::runtime_error("scalar copy: the source engine lives on another back end / device");
+        if (S->bs_ != 3 || S->C_ != 64 || S->d_bidx_ || S->ov_slices_ || !S->d_vals_) throw std::runtime_error("scalar copy: plain, unsplit 3x3-block format only");
+        (void)src_ptr;
+        bs_ = 1; C_ = 64;
+        n_nodes_ = n_rows; n_ = n_rows; n_slices_ = (int64_t)ptr1.size() - 1; n_bnd_slices_ = 0;
+        const size_t tot = (size_t)ptr1.back() * 64;
+        d_slice_ptr_ = (int64_t *)alloc(sizeof(int64_t) * ptr1.size());
+        h2d(d_slice_ptr_, ptr1.data(), sizeof(int64_t) * ptr1.size());
+        d_cols_ = (int *)alloc(sizeof(int) * std::max<size_t>(1, tot));
+        d_vals_ = (double *)alloc(sizeof(double) * std::max<size_t>(1, tot));
+        d_diag_ = (double *)alloc(sizeof(double) * (size_t)n_);
+        d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
+        HIP_CHECK(hipStreamSynchronize(S->st_));
+        HIP_CHECK(hipMemcpyAsync(d_diag_, S->d_diag_, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, st_));
+        const int grid = (int)((n_rows + kBlock - 1) / kBlock);
+        if (S->d_cols16_)
+            hipLaunchKernelGGL((k_expand_scalar<true>), dim3(grid), dim3(kBlock), 0, st_, S->d_slice_ptr_, (const void *)S->d_cols16_, S->d_colbase_, S->d_vals_,
+                               d_slice_ptr_, d_cols_, d_vals_, n_rows);
+        else
+            hipLaunchKernelGGL((k_expand_scalar<false>), dim3(grid), dim3(kBlock), 0, st_, S->d_slice_ptr_, (const void *)S->d_cols_, S->d_colbase_, S->d_vals_,
+                               d_slice_ptr_, d_cols_, d_vals_, n_rows);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st_));
     }
     // Where the value array lands physically is not the engine's choice, and it matters: the identical launch ran at 1.05 and at
     // 1.22 ms in consecutive processes on ONE box, and FOUR allocations of the same 6.5 GB array inside one process gave 1.124 /
@@ -551,6 +582,8 @@ public:
             T.tinfo = (const int2 *)d_tinfo; T.tlid = (const unsigned short *)d_tlid; T.tck = (const double *)d_tck;
             T.tsgn = (const unsigned *)d_tsgn; T.tcol = (const unsigned char *)d_tcol; T.frag = (const double *)d_frag;
             T.np = M.nnpt; T.words = M.words; T.xcd = ebe_xcd_;
+            T.flags = 0;
+            if (const char *e = getenv("PCG_EBE_MIX_FLAGS")) T.flags = atoi(e);      // bit 0: barriers instead of tickets; 16 / 32 / 64: ablations (development)
             mix_tab_[ph] = T;
             mix_nodes_host_[ph] = nodes;
             mix_tslot_host_[ph] = tslot;
@@ -908,6 +941,24 @@ public:
         return grid;
     }
     int64_t ov_slices_ = 0, ov_bnd_slices_ = 0;
+    int64_t n_windows_ = 0, n_bnd_windows_ = 0;                  // windowed form of the split matrix (SellHost::win_*)
+    int64_t *d_win_slice_ = nullptr, *d_win_ov_ = nullptr;
+    // the whole split operator in ONE launch; -> workgroups launched (= dot partials written)
+    int launch_windowed(const double *x, double *y, int64_t lo, int64_t hi, bool dot)
+    {
+        int64_t wlo, whi;
+        if (lo == 0) wlo = 0; else if (lo == n_bnd_slices_) wlo = n_bnd_windows_; else throw std::runtime_error("spmv: slice range does not match the windows");
+        if (hi == n_slices_) whi = n_windows_; else if (hi == n_bnd_slices_) whi = n_bnd_windows_; else throw std::runtime_error("spmv: slice range does not match the windows");
+        int64_t g = std::min<int64_t>(whi - wlo, std::min<int64_t>((int64_t)n_cu_ * spmv_blocks_per_cu_, kMaxPartials));
+        const int grid = (int)std::max<int64_t>(1, g);
+        auto go = [&](auto kern, const void *cols) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st_, d_win_slice_, d_win_ov_, d_slice_ptr_, cols, d_colbase_, d_vals_, d_ov_mask_,
+                               d_ov_slice_ptr_, d_ov_rows_, d_ov_cols_, d_ov_vals_, x, y, d_flags_, d_part_spmv_, wlo, whi, n_nodes_);
+        };
+        if (d_cols16_) { if (dot) go(k_spmv_win<true, true>, d_cols16_); else go(k_spmv_win<false, true>, d_cols16_); }
+        else { if (dot) go(k_spmv_win<true, false>, d_cols_); else go(k_spmv_win<false, false>, d_cols_); }
+        return grid;
+    }
     int64_t *d_ov_slice_ptr_ = nullptr;
     int *d_ov_rows_ = nullptr, *d_ov_cols_ = nullptr;
     double *d_ov_vals_ = nullptr;
@@ -920,9 +971,14 @@ public:
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         last_spmv_grid_ = grid;
-        if (C_ == 64) launch_spmv<1>(x, y, lo, hi, with_dot, grid);
-        else launch_spmv<2>(x, y, lo, hi, with_dot, grid);
-        const int ov_grid = launch_overflow(x, y, lo, hi, with_dot, last_spmv_grid_);
+        int ov_grid = 0;
+        if (n_windows_ > 0) {
+            last_spmv_grid_ = launch_windowed(x, y, lo, hi, with_dot);
+        } else {
+            if (C_ == 64) launch_spmv<1>(x, y, lo, hi, with_dot, grid);
+            else launch_spmv<2>(x, y, lo, hi, with_dot, grid);
+            ov_grid = launch_overflow(x, y, lo, hi, with_dot, last_spmv_grid_);
+        }
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (hi == n_slices_) ++ev_applies_; }
         if (with_dot) cnt_spmv_ = last_spmv_grid_ + ov_grid;   // (the dictionary kernel may have launched a smaller grid)
@@ -1193,6 +1249,7 @@ public:
         const bool dot = bench_dot_;
         const double *xs = x;
         auto apply_once = [&]() {                              // base part + overflow part, as spmv() launches them
+            if (n_windows_ > 0) { (void)launch_windowed(xs, y, 0, n_slices_, dot); return; }
             if (C_ == 64) launch_spmv<1>(xs, y, 0, n_slices_, dot, grid); else launch_spmv<2>(xs, y, 0, n_slices_, dot, grid);
             (void)launch_overflow(xs, y, 0, n_slices_, dot, grid);      // (split matrices are plain-format: the base launch used `grid`)
         };

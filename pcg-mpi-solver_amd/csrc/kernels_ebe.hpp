@@ -640,6 +640,7 @@ struct MixTab {
     const unsigned char *tcol;    // [tiles][16]   tile-local colour, 255 = padding slot
     const double *frag;
     int np, words, xcd;
+    int flags;                    // bit 0: ordered adds by barriers instead of tickets (A/B); bits 4..6: development ablations (wrong results)
 };
 
 typedef double d4m_t __attribute__((ext_vector_type(4)));
@@ -682,9 +683,23 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
     constexpr int NPT = 3, MAXN = kChunkThreads * NPT, CE = kMixedHexSlots, ND = 24, JM = (4 * MTM) / 3;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
+    // The sums a chunk forms for a node are ORDERED (bit-reproducible): hex section (pass, wave, sub-colour), then the tiles in
+    // ascending order.  The order is kept by a ticket in LDS: the holder of ticket t adds, then hands over to t + 1 - the LDS unit
+    // serves one wave's operations in issue order, so the hand-over follows the adds - and goes on with its NEXT contraction while
+    // the others add (a block barrier per turn kept three of four waves idle through every add phase; T.flags bit 0 = that form).
+    __shared__ int turn;
+    const bool use_barriers = (T.flags & 1) != 0;
+    auto take_turn = [&](int ticket) {
+        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket) __builtin_amdgcn_s_sleep(1);
+    };
+    auto pass_turn = [&](int next) {
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&turn, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
     const int4 h = T.hdr[2 * b], h2 = T.hdr[2 * b + 1];
     const int n_hex = h.z;
+    if (threadIdx.x == 0) turn = 0;
+    const int hex_tickets = n_hex > kChunkThreads ? 2 * kWavesPerBlock : (n_hex > 0 ? kWavesPerBlock : 0);   // the tiles' tickets follow
     unsigned sg = 0xff000000u;
     double c = 0.0;
     int l3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -741,20 +756,28 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             const unsigned my_colour = sg >> 24;
             const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
             if (ps == 0 && n_hex > kChunkThreads) load_elem(1);  // the other half's slots arrive under this accumulation
-            for (int w = 0; w < kWavesPerBlock; ++w) {
-                if (wave == w)
-                    for (int s = 0; s < h.y; ++s)
-                        if ((int)my_colour == s) {
+            auto add_hex = [&]() {
+                for (int s = 0; s < h.y; ++s)
+                    if ((int)my_colour == s) {
 #pragma unroll
-                            for (int a = 0; a < ND; ++a)                                                     // :300, added by the LDS unit
-                                __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                __syncthreads();
+                        for (int a = 0; a < ND; ++a)                                                         // :300, added by the LDS unit
+                            __hip_atomic_fetch_add(&ys[a0[a / 3] + a % 3], acc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            };
+            if (use_barriers) {
+                for (int w = 0; w < kWavesPerBlock; ++w) {
+                    if (wave == w) add_hex();
+                    __syncthreads();
+                }
+            } else {                                             // ticket ps * 4 + wave: wave after wave, nobody else waits
+                take_turn(ps * kWavesPerBlock + wave);
+                add_hex();
+                pass_turn(ps * kWavesPerBlock + wave + 1);
             }
         }
     }
     // ---- tiles: four at a time (one per wave) on the matrix cores, added wave after wave ----------------------------------------
-    const int n_tiles = h2.x, lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
+    const int n_tiles = (T.flags & 64) ? 0 : h2.x, lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
     for (int t0 = 0; t0 < n_tiles; t0 += kWavesPerBlock) {       // block-uniform
         const int ti = t0 + wave;
         const bool have = ti < n_tiles;                          // wave-uniform
@@ -781,7 +804,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
 #pragma unroll
             for (int j = 0; j < JM; ++j)
                 if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
-            switch (J) {                                         // wave-uniform: straight-line code per size
+            switch ((T.flags & 32) ? 0 : J) {                     // wave-uniform: straight-line code per size
             case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
             case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
             case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
@@ -793,8 +816,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             default: break;
             }
         }
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            if (wave == w && have)
+        auto add_tile = [&]() {
                 for (int s = 0; s < ncol; ++s)
                     if (mycol == s) {
 #pragma unroll
@@ -812,9 +834,19 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                                 }
                             }
                     }
-            __syncthreads();
+        };
+        if (use_barriers) {
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                if (wave == w && have && !(T.flags & 16)) add_tile();
+                __syncthreads();
+            }
+        } else if (have) {
+            take_turn(hex_tickets + ti);
+            if (!(T.flags & 16)) add_tile();
+            pass_turn(hex_tickets + ti + 1);
         }
     }
+    if (!use_barriers) __syncthreads();                          // every add is in before the tile is written out
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j)

@@ -158,6 +158,110 @@ __global__ __launch_bounds__(kBlock) void k_spmv_ovf(const int64_t *__restrict__
     }
 }
 
+// Windowed form of the split matrix (round 4, SellHost::win_*): ONE launch.  A workgroup takes a window - a dozen consecutive base
+// slices and the overflow slices that hold the long rows of exactly those slices - runs the base slices (a wave per slice, the
+// loop of k_spmv), meets at a block barrier (the y of the window's rows is then visible to the whole workgroup: same CU, same L1)
+// and runs the window's overflow slices (the loop of k_spmv_ovf).  Why: as a second launch the overflow part gathered x with no
+// locality at all - 64 rows from anywhere in a 512-row list, their tail columns, one 128-B line per lane for 24 B used
+// (47.6 distinct lines per 53 live lanes measured on the 1 M-dof octree mesh) while the whole overflow part was in flight across all
+// of x at once: it moved its bytes at 3.2 TB/s where the base part reaches 6.2.  Here the overflow rows of a window gather around
+// the lines their own base part has just pulled into L1 / L2, and y does not leave L2 in between.  Same arithmetic in the same
+// order per row: y keeps the bits of the unsplit matrix.  The windows are cut so that every workgroup gets the same number.
+template <bool DOT, bool COL16>
+__global__ __launch_bounds__(kBlock) void k_spmv_win(const int64_t *__restrict__ win_slice, const int64_t *__restrict__ win_ov,
+                                                     const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
+                                                     const int *__restrict__ colbase, const double *__restrict__ vals,
+                                                     const unsigned long long *__restrict__ ov_mask,
+                                                     const int64_t *__restrict__ ov_slice_ptr, const int *__restrict__ ov_rows,
+                                                     const int *__restrict__ ov_cols, const double *__restrict__ ov_vals,
+                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                     const uint8_t *__restrict__ flags, double *__restrict__ partials,
+                                                     int64_t win_lo, int64_t win_hi, int64_t n_nodes)
+{
+    using CV = typename std::conditional<COL16, unsigned short, int>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double dot = 0.0;
+    for (int64_t w = win_lo + blockIdx.x; w < win_hi; w += gridDim.x) {
+        const int64_t s0 = win_slice[w], s1 = win_slice[w + 1];
+        for (int64_t s = s0 + wid; s < s1; s += kWavesPerBlock) {          // ---- base slices
+            const int64_t base = slice_ptr[s];
+            const int wd = (int)(slice_ptr[s + 1] - base);
+            const double *vp = vals + (size_t)base * 9 * 64 + lane;
+            const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)base * 64 + lane;
+            int cb = 0;
+            if constexpr (COL16) cb = colbase[s];
+            double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 3
+            for (int k = 0; k < wd; ++k) {
+                int j = ntload(cp + (size_t)k * 64);
+                if constexpr (COL16) j += cb;
+                double v[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
+                const double *xp = x + 3 * (size_t)j;
+                const v2d_a8 x01 = *reinterpret_cast<const v2d_a8 *>(xp);
+                const double x0 = x01.x, x1 = x01.y, x2 = xp[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+            }
+            const int64_t row = s * 64 + lane;
+            if (row < n_nodes) {
+                double *yp = y + 3 * row;
+                yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+                if constexpr (DOT) {
+                    if (((ov_mask[s] >> lane) & 1ull) == 0) {                // (a row that continues below forms its term there)
+                        const uint8_t *fp = flags + 3 * row;
+                        const double *xr = x + 3 * row;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t o0 = win_ov[w], o1 = win_ov[w + 1];
+        for (int64_t s = o0 + wid; s < o1; s += kWavesPerBlock) {          // ---- the window's long rows continue
+            const int64_t base = ov_slice_ptr[s];
+            const int wd = (int)(ov_slice_ptr[s + 1] - base);
+            const int row = ntload(ov_rows + s * 64 + lane);
+            const double *vp = ov_vals + (size_t)base * 9 * 64 + lane;
+            const int *cp = ov_cols + (size_t)base * 64 + lane;
+            double acc[3] = {0.0, 0.0, 0.0};
+            if (row >= 0) { acc[0] = y[3 * (size_t)row]; acc[1] = y[3 * (size_t)row + 1]; acc[2] = y[3 * (size_t)row + 2]; }
+#pragma unroll 3
+            for (int k = 0; k < wd; ++k) {
+                const int j = ntload(cp + (size_t)k * 64);
+                double v[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = ntload(vp + ((size_t)k * 9 + c) * 64);
+                const double *xp = x + 3 * (size_t)j;
+                const v2d_a8 x01 = *reinterpret_cast<const v2d_a8 *>(xp);
+                const double x0 = x01.x, x1 = x01.y, x2 = xp[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = fma(v[3 * a + 2], x2, fma(v[3 * a + 1], x1, fma(v[3 * a], x0, acc[a])));
+            }
+            if (row >= 0) {
+                double *yp = y + 3 * (size_t)row;
+                yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+                if constexpr (DOT) {
+                    const uint8_t *fp = flags + 3 * (size_t)row;
+                    const double *xr = x + 3 * (size_t)row;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if ((fp[a] & 3) == 3) dot += xr[a] * acc[a];
+                }
+            }
+        }
+    }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
 // Dictionary variant (SellHost::bidx / dict, sell.cpp compress_blocks; PCG_FORMAT_DICTIONARY): a stored block is a column and a
 // 16-bit index into the table of the matrix's DISTINCT 3x3 blocks, 4-6 bytes instead of 74-76.  The same lanes multiply the
 // same values in the same order as k_spmv: results are bit-identical, only where the values come from differs.  LDSD: the
@@ -315,6 +419,41 @@ __global__ __launch_bounds__(kBlock) void k_spmv_scalar(const int64_t *__restric
         double v[1] = {dot};
         block_sum<1>(v, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+}
+
+// Scalar-row copy of a plain 3x3-block SELL matrix, built on the device (pcg_create_scalar_copy): thread = scalar row r = 3 node + a,
+// block column k of the node's row becomes the scalar entries 3 k .. 3 k + 2 (columns 3 j + b, values v[3 a + b]); the rest of the
+// scalar slice's width is padding (value 0, the row's own column).  Writes are lane-contiguous in the scalar layout.
+template <bool COL16>
+__global__ __launch_bounds__(kBlock) void k_expand_scalar(const int64_t *__restrict__ bptr, const void *__restrict__ cols_any,
+                                                          const int *__restrict__ colbase, const double *__restrict__ bvals,
+                                                          const int64_t *__restrict__ ptr1, int *__restrict__ cols1,
+                                                          double *__restrict__ vals1, int64_t n_rows)
+{
+    using CV = typename std::conditional<COL16, unsigned short, int>::type;
+    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t node = r / 3, sb = node >> 6, s1 = r >> 6;
+    const int a = (int)(r - 3 * node), lb = (int)(node & 63), l1 = (int)(r & 63);
+    const int64_t bbase = bptr[sb], base1 = ptr1[s1];
+    const int bw = (int)(bptr[sb + 1] - bbase), w1 = (int)(ptr1[s1 + 1] - base1);
+    const CV *cp = reinterpret_cast<const CV *>(cols_any) + (size_t)bbase * 64 + lb;
+    int cb = 0;
+    if constexpr (COL16) cb = colbase[sb];
+    for (int k = 0; k < bw; ++k) {
+        const int j = (int)cp[(size_t)k * 64] + cb;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const size_t q = (size_t)(base1 + 3 * k + b) * 64 + l1;
+            vals1[q] = bvals[((size_t)(bbase + k) * 9 + 3 * a + b) * 64 + lb];
+            cols1[q] = 3 * j + b;
+        }
+    }
+    for (int k = 3 * bw; k < w1; ++k) {
+        const size_t q = (size_t)(base1 + k) * 64 + l1;
+        vals1[q] = 0.0;
+        cols1[q] = (int)r;
     }
 }
 

@@ -55,6 +55,8 @@ struct pcg_engine {
     int64_t n_dict_lds = 0;           // ... of which the SpMV kernel keeps the most frequent ones in LDS
     double dict_lds_share = 0;        // ... share of the stored blocks those cover
     uint64_t fingerprint = 0;         // FNV-1a of the host SELL arrays when PCG_MATRIX_FINGERPRINT is set (tests)
+    std::vector<int64_t> slice_ptr_host;   // block slice pointers of a plain, unsplit 3x3-block operator (pcg_create_scalar_copy)
+    bool plain_unsplit = false;
     int32_t n_colors = 0;
     int64_t n_chunks = 0;
     double op_bytes = 0, op_flops = 0;    // what one local operator apply has to move / compute (stored structures)
@@ -524,6 +526,8 @@ static int finish_create(std::unique_ptr<pcg_engine> e, SellHost &m, pcg_engine 
         h = fnv(h, m.ov_vals.data(), m.ov_vals.size() * sizeof(double));
         e->fingerprint = h;
     }
+    e->plain_unsplit = m.bs == 3 && m.C == 64 && m.bidx.empty() && m.ov_slices == 0;
+    if (e->plain_unsplit) e->slice_ptr_host = m.slice_ptr;
     e->be->upload_matrix(m);
     // 72 B of values + one column (4 B, or a 2 B offset + 4 B per slice) per stored 3x3 block, x read and y written
     // once, the slice pointers
@@ -694,6 +698,40 @@ int pcg_create_csr(int32_t device, int64_t n, const int64_t *rowptr, const int32
             brow[i + 1] = (int64_t)bcol.size();
         }
         return pcg_create(device, nn, brow.data(), bcol.data(), bval.data(), n_boundary_nodes, dict ? PCG_FORMAT_DICTIONARY : 0, out);
+    });
+}
+
+int pcg_create_scalar_copy(pcg_engine *src, pcg_engine **out)
+{
+    return guarded("pcg_create_scalar_copy", src, [&]() -> int {
+        if (!out) return set_error("pcg_create_scalar_copy: null");
+        if (src->kind != 0 || !src->plain_unsplit) return set_error("pcg_create_scalar_copy: the source must be an assembled operator in the plain, unsplit 3x3-block format");
+        const int64_t n = src->n, S1 = (n + 63) / 64, Sb = src->n_slices;
+        const auto &bp = src->slice_ptr_host;
+        std::vector<int64_t> ptr1((size_t)S1 + 1, 0);
+        for (int64_t s = 0; s < S1; ++s) {                   // a scalar slice's rows lie in at most two block slices
+            const int64_t n0 = (64 * s) / 3, n1 = std::min<int64_t>(src->n_nodes - 1, (64 * s + 63) / 3);
+            int64_t w = 0;
+            for (int64_t sb = n0 / 64; sb <= std::min<int64_t>(Sb - 1, n1 / 64); ++sb) w = std::max<int64_t>(w, bp[sb + 1] - bp[sb]);
+            ptr1[s + 1] = ptr1[s] + 3 * w;
+        }
+        auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
+        e->be = make_backend(src->be->device());
+        e->be->upload_scalar_copy(*src->be, ptr1, bp, n);
+        e->n_nodes = n; e->n = n;
+        e->n_slices = S1; e->n_bnd_slices = 0; e->n_bnd_dofs = 0; e->C = 64;
+        e->nnzb = 9 * src->nnzb;                             // scalar non-zeros (explicit zeros inside a stored block included)
+        e->stored_blocks = ptr1.back() * 64;
+        e->op_bytes = 12.0 * (double)e->stored_blocks + 16.0 * (double)e->n + 8.0 * (double)(S1 + 1);
+        e->op_flops = 2.0 * (double)e->nnzb;
+        e->d_st = (double *)e->be->alloc(sizeof(double) * ST_COUNT);
+        e->be->zero(e->d_st, sizeof(double) * ST_COUNT);
+        e->be->set_status_block(e->d_st);
+        e->v_minv = e->vec();
+        std::vector<uint8_t> f((size_t)e->n, 3);
+        e->be->upload_masks(f.data(), e->n);
+        *out = e.release();
+        return 0;
     });
 }
 

@@ -49,6 +49,14 @@ struct SellHost {
     std::vector<int32_t> ov_cols;               // like cols
     std::vector<double> ov_vals;                // like vals
     std::vector<uint64_t> ov_mask;              // per base slice: lanes whose row continues in the overflow part
+    // Windowed overflow (round 4, the default): the base slices are cut into WINDOWS (consecutive slices); the overflow rows of a
+    // window are packed into overflow slices of their own, which follow each other in ov_*: window w = base slices
+    // [win_slice[w], win_slice[w+1]) + overflow slices [win_ov[w], win_ov[w+1]).  ONE workgroup works through a window - base
+    // slices, block barrier, its overflow slices (k_spmv_win): the x lines the overflow rows gather were just touched by the same
+    // rows' base part (L1 / L2 hits instead of a second sweep over x by a second launch), y makes its round trip through L2.
+    // Windows [0, n_bnd_windows) cover the interface slices [0, n_bnd_slices).  Empty = the round-3 form (k_spmv + k_spmv_ovf).
+    std::vector<int64_t> win_slice, win_ov;
+    int64_t n_bnd_windows = 0;
 };
 
 // Octree meshes put rows of 27 ... 99 blocks side by side in every 64-row slice: SELL pads them all to the longest (55 % of the
@@ -56,7 +64,7 @@ struct SellHost {
 // overflow blocks), moves the rest of the longer rows into the overflow part (rows sorted by excess length inside windows of 512
 // overflow rows: the padding of THAT matrix) and compacts the base arrays in place.  Returns false and leaves `m` unchanged when
 // less than `min_saving` of the stored blocks would go (bricks).  Row sums keep their order: results are bit-identical.
-bool split_overflow(SellHost &m, double min_saving, int n_threads);
+bool split_overflow(SellHost &m, double min_saving, int n_threads, int target_blocks = 1024);
 
 void csr_to_sell1(int64_t n, const int64_t *rowptr, const int32_t *cols, const double *vals, int64_t n_boundary_rows,
                   int n_threads, SellHost &out);
@@ -257,6 +265,9 @@ public:
 
     virtual void upload_matrix(const SellHost &m) = 0;
     virtual void upload_ebe(const EbeHost &m) = 0;
+    // this (empty) back end becomes the scalar-row copy (SellHost::bs == 1 layout: one f64 + one i32 column per non-zero) of the
+    // plain 3x3-block matrix `src` holds; ptr1 = scalar slice pointers (n_rows / 64 slices), src_ptr = src's block slice pointers
+    virtual void upload_scalar_copy(Backend &src, const std::vector<int64_t> &ptr1, const std::vector<int64_t> &src_ptr, int64_t n_rows) = 0;
     // y (+)= sum over the elements of phases [phase_lo, phase_hi) ; zero_first clears y before
     // with_dot: also accumulate partials of sum x[d]*y[d]*own_free(d) over the dofs d >= dot_lo that become
     // final in these phases (interface dofs < dot_lo get theirs from boundary_fixup); returns false when the

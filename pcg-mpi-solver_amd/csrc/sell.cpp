@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <unordered_map>
 
@@ -72,7 +73,7 @@ void bsr_to_sell(int64_t n_nodes, const int64_t *rowptr, const int32_t *cols, co
     }
 }
 
-bool split_overflow(SellHost &m, double min_saving, int n_threads)
+bool split_overflow(SellHost &m, double min_saving, int n_threads, int target_blocks)
 {
     if (m.bs != 3 || m.C != 64 || m.ov_slices != 0 || m.n_slices == 0) return false;
     const int C = 64;
@@ -132,15 +133,34 @@ bool split_overflow(SellHost &m, double min_saving, int n_threads)
     std::vector<Row> rows;
     m.ov_slice_ptr.assign(1, 0);
     m.ov_mask.assign((size_t)S, 0);
+    // Windowed form (default; PCG_SPMV_OVF=split keeps the round-3 form: windows of 512 overflow ROWS, a second launch): the base
+    // slices of a range are cut into k x target_blocks windows of (nearly) equal slice counts - every workgroup of k_spmv_win then
+    // works through exactly k of them - of about 12 slices each (at least 8: a window's overflow rows should fill a slice or two).
+    bool windowed = true;
+    if (const char *ev = std::getenv("PCG_SPMV_OVF")) windowed = std::string(ev) != "split";
+    int64_t per_win = 12;
+    if (const char *ev = std::getenv("PCG_SPMV_OVF_WINDOW")) per_win = std::max(1, std::atoi(ev));
     auto emit_range = [&](int64_t s_lo, int64_t s_hi) {
+        std::vector<int64_t> cuts;                                           // window boundaries (base slices) of this range
+        if (windowed && s_hi > s_lo) {
+            const int64_t n = s_hi - s_lo;
+            int64_t nw = std::max<int64_t>(1, (n + per_win - 1) / per_win);
+            if (nw > target_blocks) nw = (nw + target_blocks / 2) / target_blocks * target_blocks;   // a whole number of windows per workgroup
+            nw = std::min(nw, n);
+            for (int64_t w = 0; w <= nw; ++w) cuts.push_back(s_lo + (n * w) / nw);
+        } else {
+            cuts = {s_lo, s_hi};
+        }
+        for (size_t wdx = 0; wdx + 1 < cuts.size(); ++wdx) {
         rows.clear();
-        for (int64_t s = s_lo; s < s_hi; ++s)
+        for (int64_t s = cuts[wdx]; s < cuts[wdx + 1]; ++s)
             for (int l = 0; l < C; ++l) {
                 const int32_t e = len[(size_t)s * C + l] - wb[s];
                 if (e > 0) { rows.push_back(Row{(int32_t)(s * C + l), e}); m.ov_mask[s] |= 1ull << l; }
             }
-        for (size_t a = 0; a < rows.size(); a += window)
-            std::stable_sort(rows.begin() + a, rows.begin() + std::min(rows.size(), a + window), [](const Row &x, const Row &y) { return x.exc > y.exc; });
+        const size_t sort_window = windowed ? std::max<size_t>(1, rows.size()) : window;
+        for (size_t a = 0; a < rows.size(); a += sort_window)
+            std::stable_sort(rows.begin() + a, rows.begin() + std::min(rows.size(), a + sort_window), [](const Row &x, const Row &y) { return x.exc > y.exc; });
         for (size_t a = 0; a < rows.size(); a += C) {
             const size_t b = std::min(rows.size(), a + C);
             // the 64 rows of a slice in ascending row order again: neighbouring lanes gather neighbouring x (the width of the
@@ -172,11 +192,20 @@ bool split_overflow(SellHost &m, double min_saving, int n_threads)
                 }
             }
         }
+        if (windowed) {
+            if (m.win_slice.empty()) { m.win_slice.push_back(cuts[wdx]); m.win_ov.push_back(0); }
+            m.win_slice.push_back(cuts[wdx + 1]);
+            m.win_ov.push_back((int64_t)m.ov_slice_ptr.size() - 1);
+        }
+        }
     };
+    m.win_slice.clear(); m.win_ov.clear();
     emit_range(0, m.n_bnd_slices);
     m.ov_bnd_slices = (int64_t)m.ov_slice_ptr.size() - 1;
+    m.n_bnd_windows = windowed && !m.win_slice.empty() ? (int64_t)m.win_slice.size() - 1 : 0;
     emit_range(m.n_bnd_slices, S);
     m.ov_slices = (int64_t)m.ov_slice_ptr.size() - 1;
+    if (windowed && m.win_slice.empty()) { m.win_slice = {0, S}; m.win_ov = {0, m.ov_slices}; }
     // compact the base arrays in place (a slice keeps its first wb block columns)
     int64_t dst = 0;
     for (int64_t s = 0; s < S; ++s) {

@@ -73,6 +73,7 @@ _SIGS = {
     "pcg_create": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "pcg_create_asm": (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "pcg_create_csr": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    "pcg_create_scalar_copy": (C.c_int, [_P, C.POINTER(_P)]),
     "pcg_create_ebe": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.POINTER(ElemGroup), _P, C.c_int64, _P, C.c_int32, C.POINTER(_P)]),
     "pcg_destroy": (None, [_P]),
     "pcg_set_masks": (C.c_int, [_P, _P]),

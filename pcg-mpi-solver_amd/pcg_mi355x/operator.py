@@ -166,6 +166,22 @@ class Operator:
         self.last_result = None
         return self
 
+    def scalar_copy(self):
+        """The same operator in the literal CSR data volume (one f64 + one i32 column per scalar non-zero, k_spmv_scalar), expanded
+        from this engine's plain 3x3-block format on the device (pcg_create_scalar_copy) - the "CSR SpMV" measurement point at the
+        metric's own size.  Engine numbering and masks are NOT carried over: a measurement / test object (apply, bench_spmv)."""
+        other = Operator.__new__(Operator)
+        h = C.c_void_p()
+        check(self._L.pcg_create_scalar_copy(self._h, C.byref(h)), "pcg_create_scalar_copy")
+        other._L, other._h, other.kind = self._L, h, "sell"
+        other.n, other.n_nodes, other._map = self.n, self.n_nodes, self._map
+        info = other.matrix_info()
+        other.nnzb = other.nnz = info["nnzb"]
+        other._comm = other._hooks = None
+        other.glob_n_eff = None
+        other.last_result = None
+        return other
+
     # -- numbering ------------------------------------------------------------------------------
     def to_engine(self, v):
         v = _f64(v)

@@ -43,6 +43,29 @@ public:
         ebe_ = m; n_ = 3 * m.n_nodes;
         m_ = SellHost(); m_.n_nodes = m.n_nodes; m_.diag = m.diag;
     }
+    void upload_scalar_copy(Backend &src_be, const std::vector<int64_t> &ptr1, const std::vector<int64_t> &, int64_t n_rows) override
+    {
+        const SellHost &B = static_cast<HostBackend &>(src_be).m_;
+        if (B.bs != 3 || B.C != 64 || !B.bidx.empty() || B.ov_slices) throw std::runtime_error("scalar copy: plain, unsplit 3x3-block format only");
+        m_ = SellHost();
+        m_.bs = 1; m_.C = 64; m_.n_nodes = n_rows; m_.n_slices = (int64_t)ptr1.size() - 1; m_.slice_ptr = ptr1; m_.diag = B.diag;
+        m_.cols.assign((size_t)ptr1.back() * 64, 0); m_.vals.assign((size_t)ptr1.back() * 64, 0.0);
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t node = r / 3, sb = node / 64, s1 = r / 64;
+            const int a = (int)(r % 3), lb = (int)(node % 64), l1 = (int)(r % 64);
+            const int64_t bbase = B.slice_ptr[sb], bw = B.slice_ptr[sb + 1] - bbase, base1 = ptr1[s1], w1 = ptr1[s1 + 1] - base1;
+            for (int64_t k = 0; k < w1; ++k) {
+                const size_t q = (size_t)(base1 + k) * 64 + l1;
+                if (k < 3 * bw) {
+                    m_.vals[q] = B.vals[((size_t)(bbase + k / 3) * 9 + 3 * a + k % 3) * 64 + lb];
+                    m_.cols[q] = 3 * B.cols[(size_t)(bbase + k / 3) * 64 + lb] + (int32_t)(k % 3);
+                } else {
+                    m_.cols[q] = (int32_t)r;
+                }
+            }
+        }
+        n_ = n_rows;
+    }
     bool ebe_apply(const double *x, double *y, int plo, int phi, bool zero_first, bool with_dot, int64_t dot_lo) override
     {
         const bool fuse = with_dot && ebe_.ranges[0].empty() && ebe_.ranges[1].empty() && ebe_.chunked.n_chunks > 0;

@@ -185,3 +185,38 @@ def test_operator_from_scalar_csr_kept_scalar(hostops):
     assert relerr(out[0][0], out[1][0]) < 1e-7
     with pytest.raises(Exception):
         Operator.from_csr(A.indptr, A.indices, A.data, block=2)
+
+
+def check_scalar_copy(rows_per_lane=0):
+    """pcg_create_scalar_copy (round 4): the literal CSR data volume of an assembled engine, expanded from the 3x3-block format by
+    the back end - same product as the block operator and as the oracle, 12 B per stored non-zero, the fused dot."""
+    import ctypes as C
+    from pcg_mi355x.operator import from_refmeshpart
+    from pcg_mi355x._lib import check, PcgError
+    b = Brick(14, n_types=2)                       # 2 744 nodes: 43 block slices, the last one ragged; 129 scalar slices
+    P = make_parts(b)[0]
+    op = from_refmeshpart(P, kind="sell", rows_per_lane=rows_per_lane)
+    sc = op.scalar_copy()
+    info_b, info_s = op.matrix_info(), sc.matrix_info()
+    assert info_s["nnzb"] == 9 * info_b["nnzb"] and info_s["slice_rows"] == 64 and info_s["n_slices"] == -(-b.n_dof // 64)
+    by, fl = sc.operator_cost()
+    assert by == 12.0 * info_s["stored_blocks"] + 16.0 * b.n_dof + 8.0 * (info_s["n_slices"] + 1) and fl == 2.0 * info_s["nnzb"]
+    x = np.random.default_rng(3).standard_normal(b.n_dof)
+    y = np.empty(b.n_dof); pxy = C.c_double()
+    check(sc._L.pcg_k_spmv_local(sc._h, x.ctypes.data, y.ctypes.data, C.byref(pxy)))
+    ref = pcg_oracle.matvec_local(P, x)
+    assert relerr(y, ref) < 1e-13 and relerr(y, op.apply(x)) < 1e-13
+    assert abs(pxy.value - np.dot(x, ref)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref))      # default masks: every dof owned and free
+    assert sc.bench_spmv(1, 2).shape == (2,)
+    sc.close()
+    x2 = np.random.default_rng(4).standard_normal(b.n_dof)
+    assert relerr(op.apply(x2), pcg_oracle.matvec_local(P, x2)) < 1e-13                 # the source engine is untouched
+    op.close()
+    e = from_refmeshpart(P, kind="ebe")
+    with pytest.raises(PcgError, match="plain, unsplit"):
+        e.scalar_copy()
+    e.close()
+
+
+def test_scalar_copy_of_an_assembled_engine(hostops):
+    check_scalar_copy()

@@ -50,6 +50,18 @@ def test_spmv_kernel_vs_oracle(gpu_lib, oracle_c, rpl, n_types):
     op.close()
 
 
+def test_scalar_copy_of_an_assembled_engine_on_gpu(gpu_lib):
+    """k_expand_scalar: the literal-CSR copy of a block-format engine built on the device (16-bit and 32-bit block columns)."""
+    import os
+    from test_brick_and_assembly import check_scalar_copy
+    check_scalar_copy()
+    os.environ["PCG_SPMV_COL16"] = "0"
+    try:
+        check_scalar_copy()
+    finally:
+        del os.environ["PCG_SPMV_COL16"]
+
+
 def test_scalar_csr_format_kernel_and_solve(gpu_lib):
     """pcg_create_csr(block = 1), the literal CSR data volume: k_spmv_scalar vs the oracle mat-vec (<= 1e-13),
     the fused dot, a ragged non-3-dof system, and the same iteration path as the blocked format."""
@@ -632,8 +644,9 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
     from pcg_mi355x._lib import check
     from pcg_mi355x.operator import from_refmeshpart
     from test_ebe_cpu import mixed_chunk_cases
-    for ept in ("1", "2"):
+    for ept, flags in (("1", "0"), ("2", "0"), ("2", "1")):       # one / two hex passes; ordered adds by tickets (default) / by block barriers
         monkeypatch.setenv("PCG_EBE_EPT", ept)
+        monkeypatch.setenv("PCG_EBE_MIX_FLAGS", flags)
         for name, P in mixed_chunk_cases():
             ys = {}
             for mixed in ("1", "0"):
@@ -654,6 +667,7 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
             assert relerr(ys["1"], ys["0"]) < 1e-13
     monkeypatch.setenv("PCG_EBE_MIXED", "1")
     monkeypatch.delenv("PCG_EBE_EPT")
+    monkeypatch.delenv("PCG_EBE_MIX_FLAGS")
     P = dict(mixed_chunk_cases())["graded_octree"]
     R = copy.deepcopy(P)
     pm.configure(comm=None, device=0, operator="ebe")

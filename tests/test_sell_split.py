@@ -28,7 +28,11 @@ def _apply_and_solve(P0, monkeypatch, split):
     return y, info, P["GlobData"]["TimeList_Flag"][1], P["GlobData"]["TimeList_Iter"][1], np.array(P["Un"]), np.array(P["InvDiagPreCondVector0"])
 
 
-def _check(P0, monkeypatch):
+FORMS = ["win", "split"]      # PCG_SPMV_OVF: windowed overflow in ONE launch (k_spmv_win, round 4, the default) / k_spmv + k_spmv_ovf (round 3)
+
+
+def _check(P0, monkeypatch, form):
+    monkeypatch.setenv("PCG_SPMV_OVF", form)
     single = _apply_and_solve(P0, monkeypatch, "0")
     split = _apply_and_solve(P0, monkeypatch, "1")
     auto = _apply_and_solve(P0, monkeypatch, None)
@@ -42,8 +46,9 @@ def _check(P0, monkeypatch):
         assert relerr(other[4], single[4]) < 1e-9
 
 
-def test_split_matrix_is_bit_identical_on_the_cpu_double(hostops, monkeypatch):
-    _check(_mesh_part(), monkeypatch)
+@pytest.mark.parametrize("form", FORMS)
+def test_split_matrix_is_bit_identical_on_the_cpu_double(hostops, monkeypatch, form):
+    _check(_mesh_part(), monkeypatch, form)
 
 
 def test_brick_matrices_are_not_split(hostops, monkeypatch):
@@ -59,7 +64,7 @@ def test_brick_matrices_are_not_split(hostops, monkeypatch):
 
 
 @pytest.mark.parametrize("case,nproc,port", [("goct_p4", 4, 29671), ("oct_p3", 3, 29672)])
-def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):
+def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):        # (the windowed form: the default)
     """Interface rows first, interior rows behind the exchange: the overflow part is split at the same row, every rank runs
     base + overflow for each range (forced split: the fixtures are small)."""
     import conftest
@@ -77,17 +82,20 @@ def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):
 
 
 @pytest.mark.gpu
-def test_split_matrix_is_bit_identical_on_the_gpu(gpu_lib, monkeypatch):
-    _check(_mesh_part(), monkeypatch)
+@pytest.mark.parametrize("form", FORMS)
+def test_split_matrix_is_bit_identical_on_the_gpu(gpu_lib, monkeypatch, form):
+    _check(_mesh_part(), monkeypatch, form)
 
 
 @pytest.mark.gpu
-def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("form", FORMS)
+def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch, form):
     """At 1 M dof the automatic rule applies (>= 65 536 rows, a third of the stored blocks goes): 1.57 -> 1.05 x the true blocks,
     and the mat-vec is still the single matrix's bit for bit."""
     from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
     from pcg_mi355x.operator import from_refmeshpart
     P = make_octree_parts(GradedOctreeMesh((12, 12, 12), 4, band=1.2), 1)[0]
+    monkeypatch.setenv("PCG_SPMV_OVF", form)
     res = {}
     for tag, env in (("single", "0"), ("auto", None)):
         if env is None: monkeypatch.delenv("PCG_SELL_SPLIT", raising=False)
@@ -101,16 +109,27 @@ def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("case", ["goct_p4", "oct_p3"])
-def test_split_matrix_multi_part_on_one_gpu(gpu_lib, monkeypatch, case):
+def test_split_matrix_multi_part_on_one_gpu(gpu_lib, monkeypatch, case, form):
     """All parts of a fixture on one GPU through the thread communicator, split forced."""
     import test_gpu_parity as T
+    monkeypatch.setenv("PCG_SPMV_OVF", form)
     monkeypatch.setenv("PCG_SELL_SPLIT", "1")
     T.test_multi_part_kernels_on_one_gpu(gpu_lib, case, "sell")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_split_on_random_block_matrices_on_gpu(gpu_lib, monkeypatch, seed):
+    """The same random matrices on the device, both forms of the overflow part (k_spmv_win / k_spmv + k_spmv_ovf)."""
+    for form in FORMS:
+        test_split_on_random_block_matrices(gpu_lib, monkeypatch, seed, form)
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_split_on_random_block_matrices(hostops, monkeypatch, seed):
+def test_split_on_random_block_matrices(hostops, monkeypatch, seed, form):
     """Rows of 0 ... 200 blocks in random order (hub nodes, empty rows, explicit zero blocks at the end of a row) through
     pcg_create_csr: split and single matrix give the same bits, both agree with scipy."""
     import scipy.sparse as sp
@@ -128,6 +147,7 @@ def test_split_on_random_block_matrices(hostops, monkeypatch, seed):
     A = sp.bsr_matrix((blocks, cols, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=nn))])), shape=(3 * nn, 3 * nn)).tocsr()
     A.sort_indices()
     x = rng.standard_normal(3 * nn)
+    monkeypatch.setenv("PCG_SPMV_OVF", form)
     ys = {}
     for tag, env in (("single", "0"), ("split", "1")):
         monkeypatch.setenv("PCG_SELL_SPLIT", env)

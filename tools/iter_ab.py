@@ -15,9 +15,9 @@ kinds = sys.argv[2].split(",")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 switches = [a.split("=", 1) for a in sys.argv[4:]] or [["PCG_VEC_FUSED", "1|0"]]
 out = []
-CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT", "PCG_EBE_GREEDY_CHUNKS", "PCG_EBE_STREAMS", "PCG_EBE_ROWS_LDS", "PCG_EBE_DIRECT", "PCG_EBE_XCD", "PCG_SPMV_XCD", "PCG_SELL_SPLIT", "PCG_EBE_MIXED", "PCG_NODE_ORDER", "PCG_SPMV_OVF")   # read when the operator is built
-create = [sw for sw in switches if sw[0] in CREATE] or [["_", "-"]]
-switches = [sw for sw in switches if sw[0] not in CREATE] or [["_", "-"]]
+CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT", "PCG_EBE_GREEDY_CHUNKS", "PCG_EBE_STREAMS", "PCG_EBE_ROWS_LDS", "PCG_EBE_DIRECT", "PCG_EBE_XCD", "PCG_SPMV_XCD", "PCG_SELL_SPLIT", "PCG_EBE_MIXED", "PCG_NODE_ORDER", "PCG_SPMV_OVF", "PCG_EBE_MIX_FLAGS", "PCG_EBE_TILE_CAP", "PCG_EBE_HEX_CAP")   # read when the operator is built
+create = [sw for sw in switches if sw[0].split("+")[0] in CREATE] or [["_", "-"]]      # A+B=a1+b1|a2+b2: several variables switched together
+switches = [sw for sw in switches if sw[0].split("+")[0] not in CREATE] or [["_", "-"]]
 for N in Ns:
     if isinstance(N, str):                       # the multi-level graded octree mesh (pcg_mi355x.octree.GradedOctreeMesh)
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
@@ -27,8 +27,11 @@ for N in Ns:
     for kind in kinds:
       for cvar, cvals in create:
         for cv in cvals.split("|"):
-          os.environ[cvar] = cv
+          for name, val in zip(cvar.split("+"), cv.split("+")):
+              os.environ[name] = val
           op = from_refmeshpart(P, kind=kind)
+          if kind != "ebe":
+              print({"N": N, "kind": kind, cvar: cv, "matrix": op.matrix_info(), "bytes": op.operator_cost()[0]}, file=sys.stderr, flush=True)
           fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
           inv = op.build_jacobi()
           for var, vals in switches:
@@ -53,5 +56,6 @@ for N in Ns:
                     out.append(rec); print(rec, file=sys.stderr, flush=True)
             os.environ.pop(var, None)
           op.close()
-        os.environ.pop(cvar, None)
+        for name in cvar.split("+"):
+            os.environ.pop(name, None)
 print(json.dumps(out))
