@@ -631,7 +631,8 @@ public:
                 std::copy(&K.lid[(size_t)kci * 8 * CE], &K.lid[(size_t)kci * 8 * CE] + 8 * CE, &lid[b * 8 * CE]);
             }
             hex_tab_[ph] = HexTab{(const int4 *)up(hdr), (const int *)up(nodes), (const int *)up(dst), (const unsigned short *)up(tslot),
-                                  (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn), ebe_xcd_};
+                                  (const unsigned short *)up(lid), (const double *)up(ck), (const unsigned *)up(sgn), ebe_xcd_,
+                                  getenv("PCG_EBE_HEX_FLAGS") ? atoi(getenv("PCG_EBE_HEX_FLAGS")) : 0};
             hex_nodes_host_[ph] = nodes;
             hex_tslot_host_[ph] = tslot;
         }

@@ -75,6 +75,7 @@ struct HexTab {
     const double *ck;             // [n][CE]
     const unsigned *sgn;          // [n][CE]    24 sign bits, sub-colour in bits 24..31 (255 = padding slot)
     int xcd;                      // chunk = xcd_chunk(workgroup) instead of the workgroup index
+    int flags;                    // k_ebe_hexs: bit 0 = ordered adds by block barriers (round 3) instead of tickets (round 4)
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup i -> XCD i % 8).  Consecutive chunks are spatial neighbours and share
@@ -254,8 +255,10 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
     constexpr int SEQ = 2, NPT = 3, CE = kChunkThreads * SEQ, MAXN = kChunkThreads * NPT, ND = 24;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
+    __shared__ int turn;
     const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
     const int4 h = T.hdr[b];
+    if (threadIdx.x == 0) turn = 0;
     unsigned sg;
     double c;
     int l3[8];
@@ -311,8 +314,7 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
         const unsigned my_colour = sg >> 24;
         const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
         if (ps + 1 < SEQ) load_elem(ps + 1);                 // the other half's slots arrive under this accumulation
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            if (wave == w) {
+        auto add_mine = [&]() {
                 if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(3);
                 for (int s = 0; s < h.y; ++s)
                     if ((int)my_colour == s) {
@@ -332,10 +334,23 @@ __global__ __launch_bounds__(kChunkThreads, LB) void k_ebe_hexs(HexTab T, const 
                         }
                     }
                 if constexpr (ACCM == 0) __builtin_amdgcn_s_setprio(0);
+        };
+        if (T.flags & 1) {
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                if (wave == w) add_mine();
+                __syncthreads();
             }
-            __syncthreads();
+        } else {
+            // ticket ps * 4 + wave (round 4, as k_ebe_mixed): the holder adds and hands over - the LDS unit serves a wave's operations
+            // in issue order - then goes straight on with the next pass's contraction instead of idling at a block barrier through the
+            // other three waves' adds.  Same order of additions per node.
+            const int ticket = ps * kWavesPerBlock + wave;
+            while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket) __builtin_amdgcn_s_sleep(1);
+            add_mine();
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&turn, ticket + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    if (!(T.flags & 1)) __syncthreads();                     // every add is in before the tile is written out
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
@@ -640,7 +655,8 @@ struct MixTab {
     const unsigned char *tcol;    // [tiles][16]   tile-local colour, 255 = padding slot
     const double *frag;
     int np, words, xcd;
-    int flags;                    // bit 0: ordered adds by barriers instead of tickets (A/B); bits 4..6: development ablations (wrong results)
+    int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
+                                  // bits 4..6: development ablations (wrong results)
 };
 
 typedef double d4m_t __attribute__((ext_vector_type(4)));
@@ -734,6 +750,10 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         if (n_hex > ps * kChunkThreads) {                        // block-uniform
+          // (a wave whose 64 slots of this pass are all padding skips the contraction - a pass is rarely full on graded meshes:
+          //  348 hex elements per chunk on the 10 M-dof octree mesh - but still takes its turn)
+          const bool wave_has = (T.flags & 4) || n_hex > ps * kChunkThreads + wave * 64;      // (bit 2: no skipping, A/B)
+          {
             double acc[ND];
 #pragma unroll
             for (int a = 0; a < ND; ++a) acc[a] = 0.0;
@@ -751,8 +771,10 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                     for (int a = 0; a < ND; ++a) acc[a] = flip_sign(acc[a], sg, a);                          // :280
                 }
             };
-            if (h.w) contract(std::true_type());
-            else contract(std::false_type());
+            if (wave_has) {                                      // (padding slots carry colour 255: they never add)
+                if (h.w) contract(std::true_type());
+                else contract(std::false_type());
+            }
             const unsigned my_colour = sg >> 24;
             const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
             if (ps == 0 && n_hex > kChunkThreads) load_elem(1);  // the other half's slots arrive under this accumulation
@@ -774,13 +796,18 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                 add_hex();
                 pass_turn(ps * kWavesPerBlock + wave + 1);
             }
+          }
         }
     }
     // ---- tiles: four at a time (one per wave) on the matrix cores, added wave after wave ----------------------------------------
     const int n_tiles = (T.flags & 64) ? 0 : h2.x, lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // (provably wave-uniform: the tile's header comes by scalar loads)
+    int2 info_next = wave_u < n_tiles ? T.tinfo[(size_t)h2.y + wave_u] : make_int2(0, 0);
     for (int t0 = 0; t0 < n_tiles; t0 += kWavesPerBlock) {       // block-uniform
-        const int ti = t0 + wave;
+        const int ti = t0 + wave_u;
         const bool have = ti < n_tiles;                          // wave-uniform
+        const int2 info = info_next;                             // this tile's header was requested a round ago:
+        if (ti + kWavesPerBlock < n_tiles) info_next = T.tinfo[(size_t)h2.y + ti + kWavesPerBlock];   // header -> fragments is the dependent chain
         d4m_t acc[MTM];
         int tl3[JM];
         unsigned tsg[3] = {0u, 0u, 0u};
@@ -791,7 +818,6 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         for (int j = 0; j < JM; ++j) tl3[j] = 0;
         if (have) {
             const size_t tg = (size_t)h2.y + ti;
-            const int2 info = T.tinfo[tg];
             nn = __builtin_amdgcn_readfirstlane(info.x & 255);
             const int J = __builtin_amdgcn_readfirstlane((info.x >> 8) & 255);
             ncol = __builtin_amdgcn_readfirstlane(info.x >> 16);

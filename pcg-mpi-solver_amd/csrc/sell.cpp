@@ -133,12 +133,17 @@ bool split_overflow(SellHost &m, double min_saving, int n_threads, int target_bl
     std::vector<Row> rows;
     m.ov_slice_ptr.assign(1, 0);
     m.ov_mask.assign((size_t)S, 0);
-    // Windowed form (default; PCG_SPMV_OVF=split keeps the round-3 form: windows of 512 overflow ROWS, a second launch): the base
+    // Windowed form (PCG_SPMV_OVF=split keeps the round-3 form: windows of 512 overflow ROWS, a second launch): the base
     // slices of a range are cut into k x target_blocks windows of (nearly) equal slice counts - every workgroup of k_spmv_win then
     // works through exactly k of them - of about 12 slices each (at least 8: a window's overflow rows should fill a slice or two).
-    bool windowed = true;
+    // Measured (profiles/r04_ab_win_*_sessionB.log, graded octree mesh, same process): at 10 M dof the windowed form is SLOWER - 1727 us
+    // with 12-slice windows (1715 with 6, 1786 with 24) against 1599 us for the two launches: the block barrier between the two
+    // phases of a window and the 2-3 overflow slices left for four waves cost more than the gathers gain; at 1 M dof (5 129 slices:
+    // every launch is a single wave of work per CU) 4-slice windows win, 176 against 187 us.  So: windows of 4 slices below 8 192
+    // slices, the two-launch form above; PCG_SPMV_OVF=win / split and PCG_SPMV_OVF_WINDOW override.
+    bool windowed = S < 8192;
+    int64_t per_win = windowed ? 4 : 12;
     if (const char *ev = std::getenv("PCG_SPMV_OVF")) windowed = std::string(ev) != "split";
-    int64_t per_win = 12;
     if (const char *ev = std::getenv("PCG_SPMV_OVF_WINDOW")) per_win = std::max(1, std::atoi(ev));
     auto emit_range = [&](int64_t s_lo, int64_t s_hi) {
         std::vector<int64_t> cuts;                                           // window boundaries (base slices) of this range
