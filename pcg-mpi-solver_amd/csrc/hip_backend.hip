@@ -199,7 +199,7 @@ public:
         (void)hipSetDevice(dev_);
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
-                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
+                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_last_cnt_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
                         (void *)d_ov_vals_, (void *)d_ov_mask_, (void *)d_win_slice_, (void *)d_win_ov_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
@@ -831,6 +831,7 @@ public:
     {
         for (void *p : {(void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_}) if (p) (void)hipFree(p);
         halo_count_ = (int64_t)h.send_idx.size();
+        fix_grid_seen_ = 0;                                   // (the fix-up launch's arrival counter starts over)
         if (ebe_) nb_dofs_ = h.fix_dof.empty() ? 0 : (int64_t)h.fix_dof.back() + 1;
         d_send_idx_ = (int *)alloc(sizeof(int) * h.send_idx.size());
         h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
@@ -913,15 +914,20 @@ public:
         last_spmv_grid_ = grid;
     }
     int last_spmv_grid_ = 0;
+    double *pack_send_ = nullptr;                 // set by spmv() for the launch it is about to make: halo_pack folded into the epilogue
     template <int RPL, bool COL16>
     void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
+        const PackArgs pk{d_fptr_, d_fpos_, pack_send_};
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
+        else if (pack_send_ && RPL == 1)
+            hipLaunchKernelGGL((k_spmv<1, false, COL16, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
         else
             hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
     }
     // overflow part of a split matrix (k_spmv_ovf) for the base slices [lo, hi): its partials follow those of the base launch
     int launch_overflow(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int part_off)
@@ -952,12 +958,14 @@ public:
         if (hi == n_slices_) whi = n_windows_; else if (hi == n_bnd_slices_) whi = n_bnd_windows_; else throw std::runtime_error("spmv: slice range does not match the windows");
         int64_t g = std::min<int64_t>(whi - wlo, std::min<int64_t>((int64_t)n_cu_ * spmv_blocks_per_cu_, kMaxPartials));
         const int grid = (int)std::max<int64_t>(1, g);
+        const PackArgs pk{d_fptr_, d_fpos_, pack_send_};
         auto go = [&](auto kern, const void *cols) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st_, d_win_slice_, d_win_ov_, d_slice_ptr_, cols, d_colbase_, d_vals_, d_ov_mask_,
-                               d_ov_slice_ptr_, d_ov_rows_, d_ov_cols_, d_ov_vals_, x, y, d_flags_, d_part_spmv_, wlo, whi, n_nodes_);
+                               d_ov_slice_ptr_, d_ov_rows_, d_ov_cols_, d_ov_vals_, x, y, d_flags_, d_part_spmv_, wlo, whi, n_nodes_, pk);
         };
-        if (d_cols16_) { if (dot) go(k_spmv_win<true, true>, d_cols16_); else go(k_spmv_win<false, true>, d_cols16_); }
-        else { if (dot) go(k_spmv_win<true, false>, d_cols_); else go(k_spmv_win<false, false>, d_cols_); }
+        const bool pack = pack_send_ != nullptr && !dot;
+        if (d_cols16_) { if (dot) go(k_spmv_win<true, true>, d_cols16_); else if (pack) go(k_spmv_win<false, true, true>, d_cols16_); else go(k_spmv_win<false, true>, d_cols16_); }
+        else { if (dot) go(k_spmv_win<true, false>, d_cols_); else if (pack) go(k_spmv_win<false, false, true>, d_cols_); else go(k_spmv_win<false, false>, d_cols_); }
         return grid;
     }
     int64_t *d_ov_slice_ptr_ = nullptr;
@@ -965,9 +973,13 @@ public:
     double *d_ov_vals_ = nullptr;
     unsigned long long *d_ov_mask_ = nullptr;
     int col_index_bytes() const override { return d_cols16_ ? 2 : 4; }
-    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
+    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot, double *pack_send) override
     {
-        if (hi <= lo) { if (with_dot) cnt_spmv_ = 0; return; }
+        if (hi <= lo) { if (with_dot) cnt_spmv_ = 0; if (pack_send) halo_pack(y, pack_send); return; }
+        // the pack rides on the launch when the rows are final in it: 3x3-block rows of 64-row slices, plain values, no dot, and no
+        // second (overflow) launch behind it - the windowed form packs in both of its phases
+        const bool can_pack = pack_send && !with_dot && halo_count_ > 0 && bs_ == 3 && C_ == 64 && !d_bidx_ && (ov_slices_ == 0 || n_windows_ > 0);
+        pack_send_ = can_pack ? pack_send : nullptr;
         const int grid = spmv_grid(hi - lo);
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
@@ -983,6 +995,8 @@ public:
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(ev1_[ev_used_], st_)); ++ev_used_; if (hi == n_slices_) ++ev_applies_; }
         if (with_dot) cnt_spmv_ = last_spmv_grid_ + ov_grid;   // (the dictionary kernel may have launched a smaller grid)
+        pack_send_ = nullptr;
+        if (pack_send && !can_pack) halo_pack(y, pack_send);   // formats the epilogue does not cover: a launch of its own
     }
     void halo_pack(const double *y, double *send) override
     {
@@ -991,16 +1005,40 @@ public:
         hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(kBlock), 0, st_, y, d_send_idx_, send, halo_count_);
         HIP_CHECK(hipGetLastError());
     }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) override
+    // last-workgroup reductions of the multi-part loop (k_fixup<true, true>, k_vec<false> with reduce_last): monotonic arrival counters
+    unsigned long long *d_last_cnt_ = nullptr;      // [0]: k_fixup, [16]: k_vec (128 B apart)
+    unsigned long long fix_seq_ = 0, vecl_seq_ = 0;
+    int fix_grid_seen_ = 0, vecl_grid_seen_ = 0;
+    void last_counters()
     {
-        if (!nb_dofs_) { if (with_dot) cnt_fix_ = 0; return; }
+        if (d_last_cnt_) return;
+        d_last_cnt_ = (unsigned long long *)alloc(sizeof(unsigned long long) * 32);
+        HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long) * 32, st_));
+    }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq) override
+    {
+        if (!nb_dofs_) {
+            if (with_dot) { cnt_fix_ = 0; if (reduce_pq) reduce_dot(reduce_pq); }
+            return;
+        }
         int grid = (int)std::min<int64_t>((nb_dofs_ + kBlock - 1) / kBlock, 1024);
-        if (with_dot)
+        FixReduce fr{};
+        if (with_dot && reduce_pq) {
+            last_counters();
+            if (grid != fix_grid_seen_) {                        // (a new interface list: the counter starts over)
+                HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long), st_));
+                fix_seq_ = 0; fix_grid_seen_ = grid;
+            }
+            fr.pa = ebe_ ? d_part_ebe_ : d_part_spmv_; fr.count_a = ebe_ ? cnt_ebe_ : cnt_spmv_;
+            fr.red = reduce_pq; fr.counter = d_last_cnt_; fr.seq = ++fix_seq_;
+            hipLaunchKernelGGL((k_fixup<true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
+                               nb_dofs_, d_part_fix_, fr);
+        } else if (with_dot)
             hipLaunchKernelGGL((k_fixup<true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, d_part_fix_);
+                               nb_dofs_, d_part_fix_, fr);
         else
             hipLaunchKernelGGL((k_fixup<false>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, d_part_fix_);
+                               nb_dofs_, d_part_fix_, fr);
         HIP_CHECK(hipGetLastError());
         if (with_dot) cnt_fix_ = grid;
     }
@@ -1058,6 +1096,8 @@ public:
         vec_kreg_ = kVecKreg;
         if (const char *e = getenv("PCG_VEC_KREG")) vec_kreg_ = std::max(0, std::min(kVecKreg, atoi(e)));
         if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_ok_ && atoi(e) != 0;
+        iter_fused_ = true;
+        if (const char *e = getenv("PCG_ITER_FUSED")) iter_fused_ = atoi(e) != 0;      // multi-part loop: pack / reductions / status copy folded in (A/B)
     }
     void publish_status(bool copy_block) override
     {
@@ -1074,11 +1114,15 @@ public:
         for (int k = 0; k < ST_COUNT; ++k) host_out[k] = m[k];
     }
     void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
-                  bool first) override
+                  bool first, int publish_slot) override
     {
-        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, vec_nt_, n_);
+        double *mirror = publish_slot >= 0 && d_mirror_ ? d_mirror_ + (size_t)publish_slot * ST_COUNT : nullptr;
+        hipLaunchKernelGGL(k_update_p, dim3(vec_grid(n_)), dim3(kBlock), 0, st_, po, pi, r, minv, st, rho_prev, first ? 1 : 0, vec_nt_, n_, mirror);
         HIP_CHECK(hipGetLastError());
+        if (publish_slot >= 0) HIP_CHECK(hipEventRecord(ev_slot_[publish_slot], st_));
     }
+    bool iteration_fusion_available() const override { return iter_fused_; }
+    bool iter_fused_ = true;
     // ---- vector phase (k_vec) --------------------------------------------------------------------------------------
     unsigned long long *d_vec_sync_ = nullptr;     // arrival counters of the fused form's grid barrier (monotonic)
     unsigned long long vec_seq_ = 0;               // fused launches so far
@@ -1102,7 +1146,7 @@ public:
     }
     bool vec_fused_available() const override { return vec_fused_ok_; }
     bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rn, const double *xo,
-                    double *xn, const double *minv, double *p_next) override
+                    double *xn, const double *minv, double *p_next, bool reduce_sums) override
     {
         const bool fused = p_next != nullptr;
         if (fused && !vec_fused_ok_) throw std::runtime_error("vec_update: the fused form is not available on this device");
@@ -1117,6 +1161,14 @@ public:
             a.pb = cnt_fix_ ? d_part_fix_ : nullptr; a.count_b = cnt_fix_;
         }
         a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_; a.spin_limit = vec_spin_limit_;
+        if (reduce_sums && !fused) {
+            last_counters();
+            if (cnt_vec_ != vecl_grid_seen_) {
+                HIP_CHECK(hipMemsetAsync(d_last_cnt_ + 16, 0, sizeof(unsigned long long), st_));
+                vecl_seq_ = 0; vecl_grid_seen_ = cnt_vec_;
+            }
+            a.reduce_last = 1; a.last_counter = d_last_cnt_ + 16; a.last_seq = ++vecl_seq_;
+        }
         const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {

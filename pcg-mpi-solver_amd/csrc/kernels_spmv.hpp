@@ -13,13 +13,19 @@ namespace pcg {
 // 74 instead of 76 bytes per stored block; chosen at upload when every slice spans fewer than 65536 block columns
 // (node numberings with a bandwidth below 32 k nodes, e.g. the 10 M-dof brick: 22 651).  Same columns, same order,
 // same arithmetic: results are bit-identical to the 32-bit form.
-template <int RPL, bool DOT, bool COL16>
+// PACK (round 4; the interface rows' launch of a part with neighbours, no dot): the rows also write their entries of the send
+// buffer - k_halo_pack folded into the epilogue: dof d goes to send[fpos[q]] for q in [fptr[d], fptr[d+1]) (the same positions its
+// neighbours' contributions arrive at in the receive buffer, pcg_set_halo).  Rows that continue in an overflow part pack there.
+struct PackArgs { const int *fptr, *fpos; double *send; };
+
+template <int RPL, bool DOT, bool COL16, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
                                                  const int *__restrict__ colbase,
                                                  const double *__restrict__ vals, const double *__restrict__ x,
                                                  double *__restrict__ y, const uint8_t *__restrict__ flags,
                                                  double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
-                                                 int64_t n_nodes, int xcd_aware, const unsigned long long *__restrict__ ov_mask)
+                                                 int64_t n_nodes, int xcd_aware, const unsigned long long *__restrict__ ov_mask,
+                                                 PackArgs pk)
 {
     constexpr int C = 64 * RPL;
     using DV = typename VecT<RPL>::d;
@@ -84,6 +90,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                     __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
                     __builtin_nontemporal_store(acc[h][2], yp + 2);
                 } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
+                if constexpr (PACK) {
+                    if (RPL != 1 || ov_mask == nullptr || ((ov_mask[s] >> lane) & 1ull) == 0) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            for (int q = pk.fptr[3 * row + a], q1 = pk.fptr[3 * row + a + 1]; q < q1; ++q) pk.send[pk.fpos[q]] = acc[h][a];
+                    }
+                }
                 if constexpr (DOT) {
                     // (a row that continues in the overflow part is not final here: k_spmv_ovf adds its term)
                     const bool final_here = RPL != 1 || ov_mask == nullptr || ((ov_mask[s] >> lane) & 1ull) == 0;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_ovf(const int64_t *__restrict__
 // of x at once: it moved its bytes at 3.2 TB/s where the base part reaches 6.2.  Here the overflow rows of a window gather around
 // the lines their own base part has just pulled into L1 / L2, and y does not leave L2 in between.  Same arithmetic in the same
 // order per row: y keeps the bits of the unsplit matrix.  The windows are cut so that every workgroup gets the same number.
-template <bool DOT, bool COL16>
+template <bool DOT, bool COL16, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_win(const int64_t *__restrict__ win_slice, const int64_t *__restrict__ win_ov,
                                                      const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
                                                      const int *__restrict__ colbase, const double *__restrict__ vals,
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_win(const int64_t *__restrict__
                                                      const int *__restrict__ ov_cols, const double *__restrict__ ov_vals,
                                                      const double *__restrict__ x, double *__restrict__ y,
                                                      const uint8_t *__restrict__ flags, double *__restrict__ partials,
-                                                     int64_t win_lo, int64_t win_hi, int64_t n_nodes)
+                                                     int64_t win_lo, int64_t win_hi, int64_t n_nodes, PackArgs pk)
 {
     using CV = typename std::conditional<COL16, unsigned short, int>::type;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -208,6 +221,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_win(const int64_t *__restrict__
             if (row < n_nodes) {
                 double *yp = y + 3 * row;
                 yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+                if constexpr (PACK) {
+                    if (((ov_mask[s] >> lane) & 1ull) == 0) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            for (int q = pk.fptr[3 * row + a], q1 = pk.fptr[3 * row + a + 1]; q < q1; ++q) pk.send[pk.fpos[q]] = acc[a];
+                    }
+                }
                 if constexpr (DOT) {
                     if (((ov_mask[s] >> lane) & 1ull) == 0) {                // (a row that continues below forms its term there)
                         const uint8_t *fp = flags + 3 * row;
@@ -244,6 +264,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_win(const int64_t *__restrict__
             if (row >= 0) {
                 double *yp = y + 3 * (size_t)row;
                 yp[0] = acc[0]; yp[1] = acc[1]; yp[2] = acc[2];
+                if constexpr (PACK) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        for (int q = pk.fptr[3 * (size_t)row + a], q1 = pk.fptr[3 * (size_t)row + a + 1]; q < q1; ++q) pk.send[pk.fpos[q]] = acc[a];
+                }
                 if constexpr (DOT) {
                     const uint8_t *fp = flags + 3 * (size_t)row;
                     const double *xr = x + 3 * (size_t)row;

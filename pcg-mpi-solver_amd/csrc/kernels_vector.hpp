@@ -56,6 +56,23 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa
     }
 }
 
+// "Last workgroup to finish reduces" (round 4, multi-part loop): a launch that leaves one partial per workgroup can also form the
+// total - in reduce_fixed_256's order, whichever workgroup happens to be last - instead of leaving it to a k_reduce launch.  Thread 0
+// has published the workgroup's partial(s) with agent-scope stores; it counts the workgroup in (acq_rel: the partials are out
+// before, and the last arriver sees everybody's).  The counter is monotonic over the launches of one kind (seq = 1, 2, ...: the
+// launch's number, same grid every time), nothing is reset in between.  -> true in every thread of the last workgroup.
+__device__ __forceinline__ bool last_workgroup(unsigned long long *counter, unsigned long long seq, int *lds_flag)
+{
+    if (threadIdx.x == 0) {
+        const unsigned long long t = __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = (t + 1 == seq * (unsigned long long)gridDim.x) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool last = *lds_flag != 0;
+    __syncthreads();
+    return last;
+}
+
 // ------------------------------------------------------------------------------------------------
 // interface kernels
 // ------------------------------------------------------------------------------------------------
@@ -67,11 +84,15 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
 }
 
 // y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
-template <bool DOT>
+// REDUCE (with DOT): the last workgroup to finish sums the apply's dot partials - pa[0 .. count_a) of the operator launches, then
+// this launch's - in k_reduce's fixed order into red[0]: the p.Ap of the multi-part loop without a reduce launch.
+struct FixReduce { const double *pa; int count_a; double *red; unsigned long long *counter; unsigned long long seq; };
+
+template <bool DOT, bool REDUCE = false>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
                                                   const int *__restrict__ fptr, const int *__restrict__ fpos,
                                                   const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
-                                                  int64_t nb, double *__restrict__ partials)
+                                                  int64_t nb, double *__restrict__ partials, FixReduce fr)
 {
     double dot = 0.0;
     for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
@@ -83,10 +104,19 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
             if ((flags[d] & 3) == 3) dot += xdot[d] * v;
     }
     if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
+        __shared__ double lds[kWavesPerBlock + 5];
         double v[1] = {dot};
         block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+        if constexpr (!REDUCE) {
+            if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+        } else {
+            __shared__ int flag;
+            if (threadIdx.x == 0) __hip_atomic_store(partials + blockIdx.x, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last_workgroup(fr.counter, fr.seq, &flag)) {
+                const double tot = reduce_fixed_256<true>(fr.pa, fr.count_a, partials, (int)gridDim.x, lds);
+                if (threadIdx.x == 0) fr.red[0] = tot;
+            }
+        }
     }
 }
 
@@ -95,10 +125,14 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
 // ------------------------------------------------------------------------------------------------
 // beta = rho / rho_prev (:475) with rho = st[RHO_NEXT] read on the device: the host need not know rho yet when it
 // enqueues this kernel (look-ahead), and divides the same two doubles later for its own Flag-4 test (:476-478).
+// mirror != null (multi-part loop, round 4): workgroup 0 first copies the status block into the host-visible ring slot of the
+// iteration BEFORE (k_publish folded in: the all-reduce rewrote the block in place after the kernels had mirrored it).
 __global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ po, const double *__restrict__ pi,
                                                      const double *__restrict__ r, const double *__restrict__ minv,
-                                                     const double *__restrict__ st, double rho_prev, int first, int nt, int64_t n)
+                                                     const double *__restrict__ st, double rho_prev, int first, int nt, int64_t n,
+                                                     double *__restrict__ mirror)
 {
+    if (mirror && blockIdx.x == 0 && threadIdx.x < ST_COUNT) mirror[threadIdx.x] = st[threadIdx.x];
     const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
     const int64_t n2 = n >> 1;
     const int64_t t0 = blockIdx.x * (int64_t)kBlock + threadIdx.x, ts = (int64_t)gridDim.x * kBlock;
@@ -185,6 +219,9 @@ struct VecArgs {
     int pq_src, nt;
     int kreg;                             // FUSED: chunks of z kept in registers, <= kVecKreg (tests lower it: PCG_VEC_KREG)
     unsigned spin_limit;                  // FUSED: polls of the grid barrier before a workgroup gives up (2^22 = seconds; tests: PCG_TEST_VEC_SPINS)
+    int reduce_last;                      // !FUSED: the last workgroup to finish reduces the five sums into st[SQP..NINF] (multi-part loop)
+    unsigned long long *last_counter;     // ... its arrival counter (monotonic) and this launch's number
+    unsigned long long last_seq;
     int64_t n;
 };
 
@@ -268,9 +305,27 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
     double v[5] = {u.sqp, u.sqx, u.sqr, u.rho, u.ninf};
     block_sum_w<5, kVecWaves>(v, lds);                             // valid in thread 0
     if constexpr (!FUSED) {
-        if (tid == 0)
+        if (!a.reduce_last) {
+            if (tid == 0)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) a.partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+                for (int k = 0; k < 5; ++k) a.partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+        } else {
+            // multi-part loop (round 4): no k_reduce launch before the all-reduce - the last workgroup to finish forms the five sums
+            // from everybody's partials in k_reduce's order (a frozen launch publishes zeros: its sums are not used)
+            __shared__ int flag;
+            if (tid == 0)
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    __hip_atomic_store(a.partials + (size_t)k * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last_workgroup(a.last_counter, a.last_seq, &flag)) {
+                double s5[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s5[k] = reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, (int)gridDim.x, nullptr, 0, lds);
+                if (tid == 0)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { a.st[ST_SQP + k] = s5[k]; if (a.mirror) a.mirror[ST_SQP + k] = s5[k]; }
+            }
+        }
     } else {
         // ---- grid barrier.  Every workgroup adds ONE non-returning agent-scope arrival to the counter of its shard (8 shards,
         // blockIdx % 8: the arrivals of a launch spread over 8 words instead of queueing on one) after its partial sums are out;

@@ -187,8 +187,12 @@ struct pcg_engine {
 
     // y = A x with the interface sum (:242-336).  Interface rows first, exchange overlapped with
     // the interior rows, then the neighbour contributions are added in neighbour order (:333-334).
-    void apply(const double *x, double *y, bool with_dot)
+    // reduce_pq != null (multi-part loop, with_dot): the interface fix-up launch also reduces the apply's dot partials into that
+    // word and the interface rows' launch writes the send buffer itself (Backend::spmv pack_send) - returns true when p.Ap has
+    // been reduced that way (a part without neighbours, or dot partials outside the fused epilogues: the caller reduces)
+    bool apply(const double *x, double *y, bool with_dot, double *reduce_pq = nullptr)
     {
+        const bool fold = reduce_pq != nullptr && with_dot;
         if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
             if (with_dot) be->begin_dot();
             bool fused;
@@ -203,23 +207,30 @@ struct pcg_engine {
                 be->halo_pack(y, d_send);
                 halo_begin();
                 halo_end();
-                be->boundary_fixup(y, d_recv, x, with_dot && fused);
+                be->boundary_fixup(y, d_recv, x, with_dot && fused, fold && fused ? reduce_pq : nullptr);
             } else {
                 fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs);
                 be->halo_pack(y, d_send);
                 halo_begin();
                 be->ebe_apply(x, y, 1, 2, false, with_dot, n_bnd_dofs);
                 halo_end();
-                be->boundary_fixup(y, d_recv, x, with_dot && fused);   // interface dofs: + neighbours, their dot
+                be->boundary_fixup(y, d_recv, x, with_dot && fused, fold && fused ? reduce_pq : nullptr);   // interface dofs: + neighbours, their dot
             }
             ebe_dot_fused = with_dot && fused;
             if (with_dot && !fused) be->dot_w(x, y);          // :487 (pattern types without the fused epilogue)
-            return;
+            return fold && fused && has_halo;
         }
         if (with_dot) be->begin_dot();
         if (!has_halo) {
             be->spmv(x, y, 0, n_slices, with_dot);
             empty_exchange();
+        } else if (be->iteration_fusion_available()) {
+            be->spmv(x, y, 0, n_bnd_slices, false, d_send);   // interface rows + :307-309 in one launch
+            halo_begin();                                     // :318-326
+            be->spmv(x, y, n_bnd_slices, n_slices, with_dot);
+            halo_end();                                       // :328
+            be->boundary_fixup(y, d_recv, x, with_dot, fold ? reduce_pq : nullptr);   // :332-334 (+ dot over the interface slices, + :487)
+            return fold;
         } else {
             be->spmv(x, y, 0, n_bnd_slices, false);
             be->halo_pack(y, d_send);                         // :307-309
@@ -228,6 +239,7 @@ struct pcg_engine {
             halo_end();                                       // :328
             be->boundary_fixup(y, d_recv, x, with_dot);       // :332-334 (+ dot over the interface slices)
         }
+        return false;
     }
     void halo_sum(double *y)
     {
@@ -278,22 +290,43 @@ struct pcg_engine {
                            const double *r_in, double *r_out, const double *x_in, double *x_out, int slot)
     {
         s.n_enqueued++;
+        // Multi-part loop, round 4 (Backend::iteration_fusion_available): FIVE launches and two all-reduces per iteration -
+        //   update_p (+ the status copy of the iteration before), interface rows (+ pack), interior rows (+ dot), interface
+        //   fix-up (+ dot + the reduction of p.Ap by its last workgroup), [all-reduce], vector update (+ the reduction of its five
+        //   sums by its last workgroup), [all-reduce]
+        // where round 3 ran ten stream operations (k_halo_pack, two k_reduce and k_publish on their own).  Same arithmetic, same
+        // orders of summation: bit-identical histories (tests: gloo, the in-process communicator, the RCCL stand-in).
+        const bool fold = multi() && be->iteration_fusion_available();
+        int publish_with_p = -1;
+        if (fold && pending_publish >= 0 && !p_ready) { publish_with_p = pending_publish; pending_publish = -1; }
+        flush_publish();                                                    // (no update_p to carry it: a launch of its own)
         be->set_status_slot(slot);
-        if (!p_ready) be->update_p(p_cur, p_prev, r_in, s.minv, d_st, rho_prev, first);   // :447, :472-479
-        apply(p_cur, v_q, true);                                            // :482-484
+        if (!p_ready) be->update_p(p_cur, p_prev, r_in, s.minv, d_st, rho_prev, first, publish_with_p);   // :447, :472-479
+        const bool pq_reduced = apply(p_cur, v_q, true, fold ? d_st + ST_PQ : nullptr);   // :482-484 (+ :487 when folded in)
         int pq_src = 2;                                                     // :487-498 inside the vector launch
         if (multi() || (kind == 1 && !ebe_dot_fused)) {
-            reduce_apply_dot(d_st + ST_PQ);                                 // :487
+            if (!pq_reduced) reduce_apply_dot(d_st + ST_PQ);                // :487
             allreduce(d_st + ST_PQ, 1);                                     // :488
             pq_src = 1;
         }
-        if (be->vec_update(d_st, pq_src, p_cur, v_q, r_in, r_out, x_in, x_out, s.minv, p_next)) {   // :501-516 (+ :447-479 of i+1)
+        if (be->vec_update(d_st, pq_src, p_cur, v_q, r_in, r_out, x_in, x_out, s.minv, p_next, fold)) {   // :501-516 (+ :447-479 of i+1)
             be->publish_status(false);                                      // the sums are already in the block and its mirror
             return;
         }
-        be->reduce_update(d_st + ST_SQP);
+        if (!fold) be->reduce_update(d_st + ST_SQP);
         allreduce(d_st + ST_SQP, 5);                                        // :507 (+ next rho, inf count)
-        be->publish_status(multi());
+        if (fold) pending_publish = slot;                                   // rides on the next iteration's update_p, or flush_publish()
+        else be->publish_status(multi());
+    }
+    // status block -> ring slot of an iteration whose copy has not been issued yet (the multi-part loop folds it into the NEXT
+    // iteration's update_p; whoever waits for that slot without having enqueued a next iteration flushes first)
+    int pending_publish = -1;
+    void flush_publish()
+    {
+        if (pending_publish < 0) return;
+        be->set_status_slot(pending_publish);
+        be->publish_status(true);
+        pending_publish = -1;
     }
 };
 
@@ -354,6 +387,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
             s.ahead_nx = nx2;
         }
     }
+    if (e->pending_publish == slot) e->flush_publish();        // no look-ahead carried iteration i's status copy: issue it now
     e->be->wait_status(slot, e->h_st);
     const double *st = e->h_st;
     bool fused_done = fused;
@@ -1046,6 +1080,7 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         auto &s = e->s;
         s = pcg_engine::Solve();
         s.active = true;
+        e->pending_publish = -1;
         be.set_status_slot(0);
         be.zero(e->d_st, sizeof(double) * ST_COUNT);                        // STOP is sticky within a solve
         s.t_comm0 = e->t_comm;

@@ -285,10 +285,15 @@ public:
 
     // y[rows of slices lo..hi) = A x ; if partial_slot >= 0 also writes per-block partials of
     // sum_{rows} xdot[i]*y[i]*own_free(i) into the partials buffer starting at that slot.
-    virtual void spmv(const double *x, double *y, int64_t slice_lo, int64_t slice_hi, bool with_dot) = 0;
+    // pack_send != null (the interface rows' launch of a part with neighbours): the launch also writes the send buffer - halo_pack
+    // folded into its epilogue (round 4: the multi-part iteration in five launches); a back end that cannot fuse it for the stored
+    // format packs with a launch of its own, the result is the same
+    virtual void spmv(const double *x, double *y, int64_t slice_lo, int64_t slice_hi, bool with_dot, double *pack_send = nullptr) = 0;
     virtual void halo_pack(const double *y, double *send) = 0;
     // interface rows: y[d] += sum recv[...] (neighbour order); optional dot over the boundary-slice rows
-    virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) = 0;
+    // reduce_pq != null (with_dot): the LAST workgroup of this launch to finish also sums every dot partial of the apply - the
+    // operator launches' and this one's, in reduce_dot()'s fixed order - into reduce_pq[0]: no reduce launch
+    virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq = nullptr) = 0;
     // forget the dot partials of earlier launches (call before an apply that wants the fused dot)
     virtual void begin_dot() = 0;
     // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
@@ -307,8 +312,10 @@ public:
     virtual void wait_status(int slot, double *host_out) = 0;
     // p_out = first ? M^-1 r : M^-1 r + beta p_in , beta = st[RHO_NEXT] / rho_prev (device-side division of the same
     // two doubles the host divides for its Flag-4 test)                     (:447,:472-479)
+    // publish_slot >= 0: the launch FIRST copies the status block into that ring slot (publish_status(true) of the iteration
+    // before, folded in) and the slot counts as published once the launch is done
     virtual void update_p(double *p_out, const double *p_in, const double *r, const double *minv, const double *st,
-                          double rho_prev, bool first) = 0;
+                          double rho_prev, bool first, int publish_slot = -1) = 0;
     // The vector phase of an iteration (:487-516, and :447-479 of the next one).
     //   alpha: pq_src 2 = p.Ap is the fixed-order sum of the dot partials of the operator launches since begin_dot() (single
     //          part: no reduce launch), 1 = st[PQ] (already all-reduced), 0 = alpha is given in st[ALPHA];
@@ -318,8 +325,12 @@ public:
     //   p_next == null: the partial sums are left for reduce_update().  Returns false.
     //   p_next != null (single part only, ask vec_fused_available() first): ONE launch also reduces the five sums into
     //          st[SQP..NINF] and forms the next search direction p_next = z + (rho' / rho) p (:475-479); returns true.
+    //   reduce_sums (with p_next == null): the last workgroup to finish reduces the five partial sums into st[SQP..NINF] itself
+    //          (reduce_update()'s fixed order): no reduce launch before the all-reduce
     virtual bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r_old, double *r_new,
-                            const double *x_old, double *x_new, const double *minv, double *p_next) = 0;
+                            const double *x_old, double *x_new, const double *minv, double *p_next, bool reduce_sums = false) = 0;
+    // the multi-part loop may fold pack / the two reductions / the status copy into the neighbouring launches (PCG_ITER_FUSED=0: no)
+    virtual bool iteration_fusion_available() const { return false; }
     virtual bool vec_fused_available() const { return false; }
     // the fused launch reported a grid-barrier time-out (st[ERR]): clear the report (block and host mirror) and keep to the split
     // form from now on (this engine; reload_tuning() does not bring the fused form back)

@@ -239,8 +239,9 @@ public:
     void upload_masks(const uint8_t *f, int64_t n) override { flags_.assign(f, f + n); }
     void upload_halo(const HaloHost &h) override { h_ = h; }
 
-    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot) override
+    void spmv(const double *x, double *y, int64_t lo, int64_t hi, bool with_dot, double *pack_send) override
     {
+        struct PackAtExit { HostBackend *b; const double *y; double *s; ~PackAtExit() { if (s) b->halo_pack(y, s); } } pack_at_exit{this, y, pack_send};
         const int C = m_.C;
         double acc = 0;
         if (m_.bs == 1) {                                               // scalar rows (pcg_create_csr block = 1)
@@ -305,8 +306,9 @@ public:
     {
         for (size_t m = 0; m < h_.send_idx.size(); ++m) send[m] = y[h_.send_idx[m]];
     }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot) override
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq) override
     {
+        struct ReduceAtExit { HostBackend *b; double *r; ~ReduceAtExit() { if (r) b->reduce_dot(r); } } reduce_at_exit{this, with_dot ? reduce_pq : nullptr};
         for (size_t k = 0; k < h_.fix_dof.size(); ++k) {
             double v = y[h_.fix_dof[k]];
             for (int64_t q = h_.fix_ptr[k]; q < h_.fix_ptr[k + 1]; ++q) v += recv[h_.fix_pos[q]];
@@ -345,9 +347,11 @@ public:
     double *st_ = nullptr;
     int slot_ = 0;
     double ring_[kStatusSlots][ST_COUNT] = {};
+    bool iteration_fusion_available() const override { const char *e = std::getenv("PCG_ITER_FUSED"); return !(e && std::atoi(e) == 0); }
     void update_p(double *po, const double *pi, const double *r, const double *minv, const double *st, double rho_prev,
-                  bool first) override
+                  bool first, int publish_slot) override
     {
+        if (publish_slot >= 0) std::memcpy(ring_[publish_slot], st_, sizeof(double) * ST_COUNT);
         const double beta = first ? 0.0 : st[ST_RHO_NEXT] / rho_prev;
         for (int64_t i = 0; i < n_; ++i) {
             const double z = minv[i] * r[i];
@@ -363,8 +367,9 @@ public:
     const int64_t vec_err_at_ = std::getenv("PCG_TEST_VEC_ERR_AT") ? std::atoll(std::getenv("PCG_TEST_VEC_ERR_AT")) : -1;
     void vec_fused_failed() override { fused_broken_ = true; st_[ST_ERR] = 0.0; }
     bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rnew, const double *xo,
-                    double *xn, const double *minv, double *p_next) override
+                    double *xn, const double *minv, double *p_next, bool reduce_sums) override
     {
+        struct ReduceAtExit { HostBackend *b; double *st; bool on; ~ReduceAtExit() { if (on) b->reduce_update(st + ST_SQP); } } reduce_at_exit{this, st, reduce_sums && !p_next};
         const double rho = st[ST_RHO_NEXT];
         if (pq_src == 2) reduce_dot(st + ST_PQ);
         if (pq_src) scalar_alpha(st);
@@ -432,7 +437,7 @@ public:
     int bench_spmv(const double *x, double *y, int, int reps, float *ms) override
     {
         if (!ebe_.groups.empty()) ebe_apply(x, y, 0, 2, true, false, 0);
-        else spmv(x, y, 0, m_.n_slices, false);
+        else spmv(x, y, 0, m_.n_slices, false, nullptr);
         for (int k = 0; k < reps; ++k) ms[k] = 0.f;
         return 0;
     }

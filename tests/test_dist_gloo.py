@@ -105,6 +105,31 @@ def test_parts_in_threads_on_the_test_double(hostops, case, kind):
     check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0)
 
 
+def fused_and_unfused_iterations_agree(on_gpu, monkeypatch, cases=("n9_p8", "oct_p3", "goct_p4", "n9_p2_flag4", "n13_t3_p4_ud"), kinds=("sell", "ebe")):
+    """Round 4: the multi-part iteration in five launches (pack in the interface rows' epilogue, p.Ap and the five sums reduced by the
+    last workgroup of the fix-up / vector launch, the status copy on the next update_p; PCG_ITER_FUSED, default on) against the
+    round-3 sequence of ten stream operations (=0): same arithmetic in the same order - histories and solutions bit for bit."""
+    from thread_comm import solve_parts_in_threads
+    for case in cases:
+        for kind in kinds:
+            res = {}
+            for fused in ("1", "0"):
+                monkeypatch.setenv("PCG_ITER_FUSED", fused)
+                _, parts = golden_cases.build_case(case)
+                infos = solve_parts_in_threads(parts, kind, on_gpu=on_gpu)
+                res[fused] = (infos, parts)
+            for a, b, pa, pb in zip(res["1"][0], res["0"][0], res["1"][1], res["0"][1]):
+                assert (a.flag, a.iter, a.relres, a.iters_done) == (b.flag, b.iter, b.relres, b.iters_done), (case, kind)
+                assert np.array_equal(a.history, b.history), (case, kind)
+                assert np.array_equal(pa["Un"], pb["Un"]), (case, kind)
+
+
+def test_fused_multi_part_iteration_is_bit_identical_on_the_test_double(hostops, monkeypatch):
+    fused_and_unfused_iterations_agree(False, monkeypatch)
+    monkeypatch.setenv("PCG_LOOK_AHEAD", "0")                  # no look-ahead: every status copy is flushed by a launch of its own
+    fused_and_unfused_iterations_agree(False, monkeypatch, cases=("n9_p8", "oct_p3"))
+
+
 def test_rank_without_neighbours_enters_the_collective_exchange(tmp_path):
     """the callback communicator's exchange is a group-wide all_to_all_single; a rank whose part has no
     neighbours must enter it too (empty splits) or the other ranks hang.  3 ranks, part 2 is an island; checked against

@@ -730,6 +730,18 @@ def test_multi_part_kernels_on_one_gpu(gpu_lib, case, kind):
     check_solution_against_golden(g, i0.flag, i0.iter, i0.relres, U, i0.history, tol_iter=1 if kind == "ebe" else 0, tol_u=tol_u)
 
 
+def test_fused_multi_part_iteration_is_bit_identical_on_gpu(gpu_lib, monkeypatch):
+    """Round 4: k_spmv<PACK> / k_spmv_win<PACK>, k_fixup<DOT, REDUCE>, k_vec<false> with its last-workgroup reduction and the status
+    copy inside k_update_p against the round-3 launches (PCG_ITER_FUSED=0): bit-identical histories and solutions with 2 - 8 parts
+    on one GPU, both operators, the plain and the split SELL format (windowed: the pack runs in both phases of a window)."""
+    from test_dist_gloo import fused_and_unfused_iterations_agree
+    fused_and_unfused_iterations_agree(True, monkeypatch)
+    monkeypatch.setenv("PCG_SELL_SPLIT", "1")
+    fused_and_unfused_iterations_agree(True, monkeypatch, cases=("goct_p4", "oct_p3"), kinds=("sell",))
+    monkeypatch.setenv("PCG_SPMV_OVF", "split")                # the two-launch form: the pack falls back to its own launch
+    fused_and_unfused_iterations_agree(True, monkeypatch, cases=("goct_p4",), kinds=("sell",))
+
+
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 def test_eight_parts_on_one_gpu_match_one_part_at_mid_size(gpu_lib, kind):
     """107 811 dof split 2x2x2 (interfaces of several thousand dofs: multi-block halo kernels, boundary and interior
