@@ -6,7 +6,7 @@ multi-part loop on the real RCCL at world size 1: its neighbours are folded into
 so the interface rows' launch, the pack, the grouped ncclSend / ncclRecv on the communication stream, the fix-up and both
 ncclAllReduce run as they would on 8 GPUs, minus the wire.  (The exchange returns the part's own partial sums, i.e. the operator
 is not the assembled one: timing only - the window is short and checked for an early exit.)
-usage: python tools/multi_part_iter.py [N] [steps] [kinds]      PCG_ITER_FUSED=1|0 is switched per solve"""
+usage: python tools/multi_part_iter.py [N] [steps] [kinds] [modes]      modes: PCG_ITER_FUSED values switched per solve (default 1,0)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -21,6 +21,7 @@ from pcg_mi355x.operator import from_refmeshpart
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 kinds = (sys.argv[3] if len(sys.argv) > 3 else "sell,ebe").split(",")
+modes = (sys.argv[4] if len(sys.argv) > 4 else "1,0").split(",")
 b = Brick(N)
 P = make_parts(b, block_partition(b, 2, 2, 2), only=[0])[0]
 ovl = np.unique(np.concatenate([np.asarray(v, np.int64) for v in P["OvrlpLocalDofVecList"]]))
@@ -33,7 +34,7 @@ for kind in kinds:
     fext, _ = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
     inv = op.build_jacobi()
     for rep in range(2):
-        for fused in ("1", "0"):
+        for fused in modes:
             os.environ["PCG_ITER_FUSED"] = fused
             op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
             op.solve_run(5)

@@ -12,5 +12,5 @@ echo "== per-rank iteration, 1.27 M dof part of the 2x2x2 split, real RCCL world
 timeout 900 python tools/multi_part_iter.py 150 100 sell,ebe,dict > "$OUT/multi_part_iter.json" 2> "$OUT/multi_part_iter.log"; grep "^{" "$OUT/multi_part_iter.log" | cut -c1-240
 cd /tmp
 echo "== kernel trace of the same (fused only)"
-PCG_ITER_FUSED=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_multi" -o k -- python "$R/tools/multi_part_iter.py" 150 100 sell,ebe > "$OUT/prof_multi.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_multi" -o k -- python "$R/tools/multi_part_iter.py" 150 100 sell,ebe 1 > "$OUT/prof_multi.log" 2>&1
 f=$(find "$OUT/prof_multi" -name "*kernel_stats.csv" | head -1); head -24 "$f" | cut -c1-160
