@@ -1173,7 +1173,11 @@ public:
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {
             a.seq = ++vec_seq_;
-            hipLaunchKernelGGL((k_vec<true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+            // small systems (every chunk of a thread fits the preloading form: <= kVecPre per thread): operands requested before the
+            // alpha prologue, p kept in registers (kernels_vector.hpp); PCG_VEC_NT bit 3 / PCG_VEC_KREG < kVecPre: the general form
+            const bool pre = vec_kreg_ >= kVecPre && (n_ >> 1) <= (int64_t)kVecPre * cnt_vec_ * kVecBlock && !(vec_nt_ & 8);
+            if (pre) hipLaunchKernelGGL((k_vec<true, true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+            else hipLaunchKernelGGL((k_vec<true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
         } else {
             hipLaunchKernelGGL((k_vec<false>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
         }

@@ -246,11 +246,40 @@ __device__ __forceinline__ void block_sum_w(double (&v)[NV], double *lds /* NV *
     __syncthreads();
 }
 
-template <bool FUSED>
+constexpr int kVecPre = 4;                // FUSED, small systems: chunks per thread whose operands are requested before the alpha prologue
+
+template <bool FUSED, bool PRE = false>
 __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 {
+    static_assert(FUSED || !PRE, "the preloading form belongs to the fused launch");
     __shared__ double lds[5 * kVecWaves + 8];
     const int tid = threadIdx.x;
+    // Small systems (at most kVecPre chunks per thread: up to 2.1 M dof on 256 CUs - BASELINE configs[1], and a GPU's share of the
+    // 10 M-dof system on 8): the launch is a chain of dependent round trips, not a stream (25 us for 92 MB at 1.27 M dof, round 3).
+    // Round 4 takes two of them out: the operands of ALL of a thread's chunks are requested BEFORE the alpha prologue (its partial
+    // sums, two block barriers) instead of after it, and p stays in registers for p' = z + beta p instead of being read again
+    // behind the grid barrier.  Same chunks per thread, same arithmetic in the same order: the bits of the general path.
+    const int64_t n2_ = a.n >> 1, T_ = (int64_t)gridDim.x * kVecBlock, t0_ = (int64_t)blockIdx.x * kVecBlock + tid;
+    constexpr bool pre = PRE;                                  // (chosen by the launcher: Backend::vec_update)
+    double2 pre_p[PRE ? kVecPre : 1], pre_q[PRE ? kVecPre : 1], pre_x[PRE ? kVecPre : 1], pre_m[PRE ? kVecPre : 1], pre_r[PRE ? kVecPre : 1];
+    uchar2 pre_f[PRE ? kVecPre : 1];
+    if constexpr (PRE) {
+        {
+            const bool ntl0 = (a.nt & 4) != 0;
+#pragma unroll
+            for (int k = 0; k < kVecPre; ++k) {
+                const int64_t t = t0_ + k * T_;
+                if (t < n2_) {
+                    const double2 *P2 = reinterpret_cast<const double2 *>(a.p) + t, *Q2 = reinterpret_cast<const double2 *>(a.q) + t,
+                                  *X2 = reinterpret_cast<const double2 *>(a.xo) + t, *M2 = reinterpret_cast<const double2 *>(a.minv) + t,
+                                  *R2 = reinterpret_cast<const double2 *>(a.r) + t;
+                    pre_p[k] = ntl0 ? ntload(P2) : *P2; pre_q[k] = ntl0 ? ntload(Q2) : *Q2; pre_x[k] = ntl0 ? ntload(X2) : *X2;
+                    pre_m[k] = ntl0 ? ntload(M2) : *M2; pre_r[k] = ntl0 ? ntload(R2) : *R2;
+                    pre_f[k] = reinterpret_cast<const uchar2 *>(a.flags)[t];
+                }
+            }
+        }
+    }
     double stop = a.st[ST_STOP], alpha = a.st[ST_ALPHA];
     const double rho = a.st[ST_RHO_NEXT];
     if (a.pq_src) {                                                // :487-498
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
     double2 *rn2 = reinterpret_cast<double2 *>(a.rn), *xn2 = reinterpret_cast<double2 *>(a.xn);
     const uchar2 *f2 = reinterpret_cast<const uchar2 *>(a.flags);
     Up u = {0, 0, 0, 0, 0};
-    double2 z[FUSED ? kVecKreg : 1];
+    double2 z[PRE ? kVecPre : (FUSED ? kVecKreg : 1)];
     double z_tail = 0.0;
     auto chunk = [&](int64_t t) -> double2 {
         const double2 pp = ntl ? ntload(p2 + t) : p2[t], qq = ntl ? ntload(q2 + t) : q2[t], xx = ntl ? ntload(x2 + t) : x2[t],
@@ -285,12 +314,27 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
     };
     if (stop == 0.0) {                                             // frozen when pq / alpha broke down (:492-498)
         if constexpr (FUSED) {
+            if constexpr (pre) {
+#pragma unroll
+                for (int k = 0; k < kVecPre; ++k) {
+                    const int64_t t = t0 + k * T;
+                    if (t < n2) {                                  // chunk() on the operands already in registers
+                        double2 rr = pre_r[k], xo2, zz;
+                        zz.x = update_one(alpha, pre_p[k].x, pre_q[k].x, rr.x, pre_x[k].x, xo2.x, pre_m[k].x, pre_f[k].x, u);
+                        zz.y = update_one(alpha, pre_p[k].y, pre_q[k].y, rr.y, pre_x[k].y, xo2.y, pre_m[k].y, pre_f[k].y, u);
+                        if (nts) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
+                        else { rn2[t] = rr; xn2[t] = xo2; }
+                        z[k] = zz;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < kVecKreg; ++k) {
                 const int64_t t = t0 + k * T;
-                if (k < a.kreg && t < n2) z[k] = chunk(t);
+                if (k < a.kreg && t < n2) z[k < (int)(sizeof(z) / sizeof(z[0])) ? k : 0] = chunk(t);
             }
             for (int64_t t = t0 + a.kreg * T; t < n2; t += T) (void)chunk(t);
+            }
         } else {
             for (int64_t t = t0; t < n2; t += T) (void)chunk(t);
         }
@@ -390,14 +434,26 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
         const double beta = rho_next / rho;
         const double2 *pc2 = reinterpret_cast<const double2 *>(a.p);
         double2 *pn2 = reinterpret_cast<double2 *>(a.p_next);
+        if constexpr (pre) {
+#pragma unroll
+            for (int k = 0; k < kVecPre; ++k) {
+                const int64_t t = t0 + k * T;
+                if (t < n2) {
+                    const double2 o = make_double2(z[k].x + beta * pre_p[k].x, z[k].y + beta * pre_p[k].y);      // :479, p still in registers
+                    if (nts) ntstore(pn2 + t, o); else pn2[t] = o;
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < kVecKreg; ++k) {
             const int64_t t = t0 + k * T;
             if (k < a.kreg && t < n2) {
                 const double2 pp = pc2[t];
-                const double2 o = make_double2(z[k].x + beta * pp.x, z[k].y + beta * pp.y);      // :479
+                const double2 zk = z[k < (int)(sizeof(z) / sizeof(z[0])) ? k : 0];
+                const double2 o = make_double2(zk.x + beta * pp.x, zk.y + beta * pp.y);      // :479
                 if (nts) ntstore(pn2 + t, o); else pn2[t] = o;
             }
+        }
         }
         for (int64_t t = t0 + a.kreg * T; t < n2; t += T) {        // beyond the register-resident part: z again from r', M^-1
             const double2 rr = rn2[t], mm = m2[t], pp = pc2[t];
