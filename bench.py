@@ -781,7 +781,8 @@ def main():
                        "value": args.steps / e["elapsed"], "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3,
                        "operator_avg_ms": e["op_ms"], "operator_launches_timed": e["n_op"], "n_elem": oi["n_elem"], "n_chunks": oi["n_chunks"],
                        "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"], "vector_phase": e["vec"],
-                       "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (hex8 class; k_ebe_rows for the other node-count classes) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
+                       "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (a single 8-node pattern type) or k_ebe_mixed (several pattern types: mixed-type chunks, "
+                                              "hex section + matrix-core tiles) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
                                     "flops_per_apply": ef, "achieved_TFLOPs": ef / t_op / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                                     "frac_flops": ef / t_op / 1e12 / F64_PEAK_TFLOPS,
                                     "bytes_per_apply": eb, "achieved_GBps": eb / t_op / 1e9, "peak_GBps": HBM_PEAK_GBS,
