@@ -543,10 +543,18 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 todo.emplace_back(a, a + (b - a) / 2);
             }
         };
+        // Development knobs (tools/iter_ab.py): PCG_EBE_NODE_CAP = tile nodes a chunk may hold (<= 768); PCG_EBE_MIX_SHELLS=1 = the
+        // elements of the main 8-node type and all others in SEPARATE runs of the Morton order (fuller tiles - the hanging-node elements of
+        // a transition shell sit together - for more boundary slots: every node between a shell and its hex neighbours is shared).
+        int node_cap = kChunkMaxNodes;
+        if (const char *nv = std::getenv("PCG_EBE_NODE_CAP")) node_cap = std::max(64, std::min(kChunkMaxNodes, std::atoi(nv)));
+        if (const char *sv = std::getenv("PCG_EBE_MIX_SHELLS"); sv && sv[0] == '1' && M.hex_group >= 0)
+            std::stable_partition(L.begin(), L.end(), [&](const ElemRef &r) { return r.g == M.hex_group; });
         std::vector<int32_t> cnt_type(M.types.size(), 0);
         size_t lo_ = 0;
         int n_run_nodes = 0, n_hex = 0, n_tl = 0;
         int32_t run_id = next_stamp++;
+        bool prev_hex = !L.empty() && L[0].g == M.hex_group;
         for (size_t k = 0; k < L.size(); ++k) {
             const auto &in = gs[L[k].g];
             const bool is_hex = L[k].g == M.hex_group;
@@ -561,7 +569,9 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             };
             const int fresh = stamp_new(run_id, false);
             const bool new_tile = !is_hex && cnt_type[t] % 16 == 0;
-            if (k > lo_ && (n_run_nodes + fresh > kChunkMaxNodes || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
+            const bool kind_change = std::getenv("PCG_EBE_MIX_SHELLS") && std::getenv("PCG_EBE_MIX_SHELLS")[0] == '1' && is_hex != prev_hex;
+            prev_hex = is_hex;
+            if (k > lo_ && (kind_change || n_run_nodes + fresh > node_cap || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
                 emit_or_split(lo_, k);
                 lo_ = k;
                 run_id = next_stamp++;

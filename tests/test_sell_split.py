@@ -90,8 +90,9 @@ def test_split_matrix_is_bit_identical_on_the_gpu(gpu_lib, monkeypatch, form):
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", FORMS)
 def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch, form):
-    """At 1 M dof the automatic rule applies (>= 65 536 rows, a third of the stored blocks goes): 1.57 -> 1.05 x the true blocks,
-    and the mat-vec is still the single matrix's bit for bit."""
+    """At 1 M dof the automatic rule applies (>= 65 536 rows, a third of the stored blocks goes): 1.57 -> 1.05 x the true blocks
+    (two-launch form; 1.11 x in the windowed form, whose overflow slices are padded per window of 4 base slices), and the mat-vec is
+    still the single matrix's bit for bit."""
     from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
     from pcg_mi355x.operator import from_refmeshpart
     P = make_octree_parts(GradedOctreeMesh((12, 12, 12), 4, band=1.2), 1)[0]
@@ -104,7 +105,8 @@ def test_large_octree_matrix_is_split_by_default(gpu_lib, monkeypatch, form):
         x = np.random.default_rng(8).standard_normal(op.n)
         res[tag] = (np.array(op.apply(x)), op.matrix_info())
         op.close()
-    assert res["auto"][1]["stored_blocks"] < 1.08 * res["auto"][1]["nnzb"] < 1.08 * res["single"][1]["stored_blocks"] / 1.5
+    pad = {"split": 1.08, "win": 1.13}[form]
+    assert res["auto"][1]["stored_blocks"] < pad * res["auto"][1]["nnzb"] < pad * res["single"][1]["stored_blocks"] / 1.38
     assert np.array_equal(res["auto"][0], res["single"][0])
 
 
