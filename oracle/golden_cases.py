@@ -30,6 +30,10 @@ CASES = {
     "goct_p1":      dict(graded=((3, 3, 3), 2, 1.2), parts=1, sign_seed=None, tol=1e-7, max_iter=10000),
     "goct_p4":      dict(graded=((3, 3, 3), 2, 1.2), parts=4, sign_seed=9, tol=1e-7, max_iter=10000),      # recursive bisection
     "goct_p3_ud":   dict(graded=((3, 3, 3), 2, 1.2), parts=3, sign_seed=5, tol=1e-7, max_iter=10000, ud=2e-3),   # + prescribed displacements (:234-237)
+    # the same mesh with ONE pattern type per class of the cube's 48 symmetries (round 4): 4 types instead of 29, every element with its
+    # own dof order and signs - the reference's pattern-library form (partition_mesh.py:453-455,1074)
+    "goct_sym_p1":  dict(graded=((3, 3, 3), 2, 1.2), parts=1, sign_seed=None, tol=1e-7, max_iter=10000, symmetry=True),
+    "goct_sym_p3":  dict(graded=((3, 3, 3), 2, 1.2), parts=3, sign_seed=7, tol=1e-7, max_iter=10000, symmetry=True, ud=2e-3),
     "n9_zero_rhs":  dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, zero_rhs=True),   # :387-395
     "n9_good_x0":   dict(N=9,  grid=(1, 1, 1), n_types=1, tol=1e-7, max_iter=10000, ud=0.0, good_x0="n9_p1"),  # :421-426
 }
@@ -47,7 +51,7 @@ def build_case(name, golden_dir=None):
     if "graded" in c:
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
         roots, levels, band = c["graded"]
-        mesh = GradedOctreeMesh(roots, levels, band=band, seed=0)
+        mesh = GradedOctreeMesh(roots, levels, band=band, seed=0, symmetry=c.get("symmetry", False))
         ep = bisect_elements(mesh, c["parts"]) if c["parts"] > 1 else None
         parts = make_octree_parts(mesh, c["parts"], 0, c["tol"], c["max_iter"], c["sign_seed"], elem_part=ep)
         for p in parts:

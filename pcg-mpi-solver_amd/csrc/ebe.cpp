@@ -32,16 +32,32 @@ inline uint64_t spread21(uint64_t v)
     return v;
 }
 
-// slots 3l, 3l+1, 3l+2 are the x, y, z dofs of one node, at most 32 nodes per element
-bool node_blocked(const pcg_elem_group &g)
+// 1: slots 3l, 3l+1, 3l+2 are the x, y, z dofs of one node, at most 32 nodes per element.
+// 2: they are the three dofs of one node in an order of the ELEMENT's own (the same for all its nodes): the reference's pattern
+//    library stores one matrix per pattern up to the cube's 48 symmetries and an element of another orientation lists its dofs in
+//    the order of the canonical pattern's (LocDofVector, partition_mesh.py:453, with its sign vector :455) - such groups are handled
+//    by the tiles of the mixed chunks only.     0: neither.
+int node_blocked(const pcg_elem_group &g)
 {
-    if (g.nd % 3 != 0 || g.nd > 96 || g.nd < 3) return false;
+    if (g.nd % 3 != 0 || g.nd > 96 || g.nd < 3) return 0;
+    int kind = 1;
     for (int l = 0; l < g.nd / 3; ++l) {
         const int64_t *d0 = g.dof + (int64_t)(3 * l) * g.ne, *d1 = d0 + g.ne, *d2 = d1 + g.ne;
-        for (int64_t e = 0; e < g.ne; ++e)
-            if (d0[e] % 3 != 0 || d1[e] != d0[e] + 1 || d2[e] != d0[e] + 2) return false;
+        for (int64_t e = 0; e < g.ne; ++e) {
+            if (d0[e] % 3 == 0 && d1[e] == d0[e] + 1 && d2[e] == d0[e] + 2) continue;
+            const int64_t n = d0[e] / 3;
+            const int c0 = (int)(d0[e] % 3), c1 = (int)(d1[e] % 3), c2 = (int)(d2[e] % 3);
+            if (d1[e] / 3 != n || d2[e] / 3 != n || c0 == c1 || c0 == c2 || c1 == c2) return 0;
+            if (g.dof[e] % 3 != c0 || g.dof[g.ne + e] % 3 != c1 || g.dof[2 * g.ne + e] % 3 != c2) return 0;   // node 0's order
+            kind = 2;
+        }
     }
-    return true;
+    if (kind == 2)                       // (an element whose node 0 is in order but a later one is not)
+        for (int l = 1; l < g.nd / 3; ++l)
+            for (int64_t e = 0; e < g.ne; ++e)
+                for (int c = 0; c < 3; ++c)
+                    if (g.dof[(int64_t)(3 * l + c) * g.ne + e] % 3 != g.dof[(int64_t)c * g.ne + e] % 3) return 0;
+    return kind;
 }
 
 
@@ -54,8 +70,8 @@ bool build_mixed_types(int32_t n_groups, const pcg_elem_group *gs, const std::ve
 {
     auto &M = C.mixed;
     int64_t best = 0;
-    for (int g = 0; g < n_groups; ++g)
-        if (chunkable[g] && gs[g].nd == 24 && gs[g].ne > best) { best = gs[g].ne; M.hex_group = g; }
+    for (int g = 0; g < n_groups; ++g)                   // (chunkable == 2: per-element dof order - a tile type, never the hex section)
+        if (chunkable[g] == 1 && gs[g].nd == 24 && gs[g].ne > best) { best = gs[g].ne; M.hex_group = g; }
     auto &K = C.cls[kMixedClass];
     K.ke_col.assign(24 * 24, 0.0);
     if (M.hex_group >= 0)
@@ -119,7 +135,19 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         }
         out.n_elem += in.ne;
         out.n_slots += (int64_t)in.nd * in.ne;
-        chunkable[g] = allow_chunked && node_blocked(in);
+        chunkable[g] = allow_chunked ? (char)node_blocked(in) : 0;
+    }
+    // Mixed-type chunks (EbeMixedHost): the default as soon as two node-blocked pattern types have elements, or one whose elements
+    // carry their own dof order (tiles only); PCG_EBE_MIXED=0 keeps one chunk list per type (the round-3 form, A/B; groups with a
+    // dof order of their own then take the generic colour launches), =1 forces the mixed form for a single type too (tests).
+    bool mixed_mode = false;
+    {
+        int populated = 0, oriented = 0;
+        for (int g = 0; g < n_groups; ++g) { populated += chunkable[g] && gs[g].ne > 0; oriented += chunkable[g] == 2 && gs[g].ne > 0; }
+        const char *mv = std::getenv("PCG_EBE_MIXED");
+        mixed_mode = mv ? (mv[0] != '0' && populated >= 1) : (populated >= 2 || oriented >= 1);
+        if (!mixed_mode)
+            for (int g = 0; g < n_groups; ++g) if (chunkable[g] == 2) chunkable[g] = 0;
     }
 
     // ---- one global, spatially coherent element order (Morton code of the first node, or its id) ----
@@ -271,15 +299,6 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         K.max_nodes = (c == 0 && ept == 1) ? 512 : kChunkMaxNodes;      // 8x8x4 hex cells -> 405 nodes: a 2-nodes-per-thread tile
         const char *dv = std::getenv("PCG_EBE_DIRECT");                              // =0: node tiles for every class (A/B)
         K.direct = c >= 1 && c <= 3 && !(dv && dv[0] == '0');
-    }
-    // Mixed-type chunks (EbeMixedHost): the default as soon as two node-blocked pattern types have elements; PCG_EBE_MIXED=0 keeps
-    // one chunk list per type (the round-3 form, A/B), =1 forces the mixed form for a single type too (tests).
-    bool mixed_mode = false;
-    {
-        int populated = 0;
-        for (int g = 0; g < n_groups; ++g) populated += chunkable[g] && gs[g].ne > 0;
-        const char *mv = std::getenv("PCG_EBE_MIXED");
-        mixed_mode = mv ? (mv[0] != '0' && populated >= 1) : populated >= 2;
     }
     if (mixed_mode) {
         any = build_mixed_types(n_groups, gs, chunkable, C);
@@ -492,6 +511,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     M.tck.resize((ti + 1) * 16, 0.0);
                     M.tsgn.resize((ti + 1) * W * 16, 0u);
                     M.tcol.resize((ti + 1) * 16, 255);
+                    M.tperm.resize((ti + 1) * 16, 0 | 1 << 2 | 2 << 4);
                     int ncol = 0;
                     std::vector<std::pair<int, uint32_t>> seen;       // (local slot, colour mask) of the nodes this tile has touched
                     for (int e = 0; e < cnt; ++e) {
@@ -512,6 +532,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                         M.tcol[ti * 16 + e] = (uint8_t)c;
                         ncol = std::max(ncol, c + 1);
                         M.tck[ti * 16 + e] = in.ck[r.e];
+                        M.tperm[ti * 16 + e] = (uint8_t)((in.dof[r.e] % 3) | (in.dof[in.ne + r.e] % 3) << 2 | (in.dof[2 * in.ne + r.e] % 3) << 4);
                         for (int a = 0; a < T.nd; ++a)
                             if (in.sign[(int64_t)a * in.ne + r.e]) M.tsgn[(ti * W + a / 32) * 16 + e] |= 1u << (a % 32);
                     }

@@ -552,7 +552,7 @@ public:
             tinfo[2 * t] = T.nn | (T.J << 8) | (M.tile_ncol[t] << 16);
             tinfo[2 * t + 1] = (int)(T.frag_off / 64);
         }
-        const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgn = up(M.tsgn), *d_tcol = up(M.tcol), *d_frag = up(M.frag);
+        const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgn = up(M.tsgn), *d_tcol = up(M.tcol), *d_tperm = up(M.tperm), *d_frag = up(M.frag);
         mix_mtm_ = std::max(2, M.max_mt);
         for (int ph = 0; ph < 2; ++ph) {
             const size_t n = K.list[ph].size();
@@ -580,7 +580,7 @@ public:
             T.tslot = (const unsigned short *)up(tslot); T.lid = (const unsigned short *)up(lid); T.ck = (const double *)up(ck);
             T.sgn = (const unsigned *)up(sgn);
             T.tinfo = (const int2 *)d_tinfo; T.tlid = (const unsigned short *)d_tlid; T.tck = (const double *)d_tck;
-            T.tsgn = (const unsigned *)d_tsgn; T.tcol = (const unsigned char *)d_tcol; T.frag = (const double *)d_frag;
+            T.tsgn = (const unsigned *)d_tsgn; T.tcol = (const unsigned char *)d_tcol; T.tperm = (const unsigned char *)d_tperm; T.frag = (const double *)d_frag;
             T.np = M.nnpt; T.words = M.words; T.xcd = ebe_xcd_;
             T.flags = 0;
             if (const char *e = getenv("PCG_EBE_MIX_FLAGS")) T.flags = atoi(e);      // bit 0: barriers instead of tickets; 16 / 32 / 64: ablations (development)

@@ -653,6 +653,7 @@ struct MixTab {
     const double *tck;            // [tiles][16]
     const unsigned *tsgn;         // [tiles][words][16]
     const unsigned char *tcol;    // [tiles][16]   tile-local colour, 255 = padding slot
+    const unsigned char *tperm;   // [tiles][16]   dof order of the element: slot 3 l + c is component (tperm >> 2 c) & 3 of node l
     const double *frag;
     int np, words, xcd;
     int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
@@ -664,7 +665,7 @@ typedef double d4m_t __attribute__((ext_vector_type(4)));
 // one tile, J node quartets (compile time): acc[mt] = sum over the k-steps of A(ks, mt) . U(ks)
 template <int J, int MTM>
 __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F, const double *xs, const int (&l3)[(4 * MTM) / 3], double c,
-                                                    const unsigned (&sg)[3], int g, int nn, d4m_t (&acc)[MTM])
+                                                    const unsigned (&sg)[3], const int (&pc)[3], int g, int nn, d4m_t (&acc)[MTM])
 {
     constexpr int MT = (3 * J + 3) / 4;
     static_assert(MT <= MTM, "tile type larger than the kernel instantiation");
@@ -672,7 +673,7 @@ __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F
     for (int j = 0; j < J; ++j) {
         const int node = 4 * j + g;
         const bool live = node < nn;
-        const double x0 = xs[l3[j]], x1 = xs[l3[j] + 1], x2 = xs[l3[j] + 2];
+        const double x0 = xs[l3[j] + pc[0]], x1 = xs[l3[j] + pc[1]], x2 = xs[l3[j] + pc[2]];      // the element's own dof order (:277)
         const double xv[3] = {x0, x1, x2};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         d4m_t acc[MTM];
         int tl3[JM];
         unsigned tsg[3] = {0u, 0u, 0u};
+        int tpc[3] = {0, 1, 2};
         int nn = 0, ncol = 0, mycol = 255;
 #pragma unroll
         for (int mt = 0; mt < MTM; ++mt) acc[mt] = d4m_t{0.0, 0.0, 0.0, 0.0};
@@ -824,6 +826,8 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             const double *F = T.frag + (size_t)__builtin_amdgcn_readfirstlane(info.y) * 64 + lane;
             const double tc = T.tck[tg * 16 + le];
             mycol = (int)T.tcol[tg * 16 + le];
+            const int pw = (int)T.tperm[tg * 16 + le];
+            tpc[0] = pw & 3; tpc[1] = (pw >> 2) & 3; tpc[2] = (pw >> 4) & 3;
 #pragma unroll
             for (int w = 0; w < 3; ++w)
                 if (w < T.words) tsg[w] = T.tsgn[(tg * T.words + w) * 16 + le];
@@ -831,14 +835,14 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             for (int j = 0; j < JM; ++j)
                 if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
             switch ((T.flags & 32) ? 0 : J) {                     // wave-uniform: straight-line code per size
-            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
-            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, lg, nn, acc); break;
+            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
             default: break;
             }
         }
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                                     word = (d >> 5) == 2 ? tsg[2] : word;
                                     const double a = acc[q / 4][q % 4];
                                     const double o = ((word >> (d & 31)) & 1u) ? -a : a;                      // :280
-                                    __hip_atomic_fetch_add(&ys[tl3[j] + cc], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                                    __hip_atomic_fetch_add(&ys[tl3[j] + tpc[cc]], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
                                 }
                             }
                     }

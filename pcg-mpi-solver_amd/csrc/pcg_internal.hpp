@@ -187,6 +187,8 @@ struct EbeMixedHost {
     std::vector<double> tck;           // (n_tiles, 16), 0 in padding slots
     std::vector<uint32_t> tsgn;        // (n_tiles, words, 16) sign bits of the element's dofs
     std::vector<uint8_t> tcol;         // (n_tiles, 16) tile-local colour, 255 = padding slot
+    std::vector<uint8_t> tperm;        // (n_tiles, 16) dof order of the element: slot 3 l + c of its type is component (tperm >> 2 c) & 3
+                                       //               of local node l (0 | 1 << 2 | 2 << 4 = x, y, z order; ebe.cpp node_blocked kind 2)
     int64_t hex_elems = 0, tile_elems = 0;
 };
 

@@ -158,17 +158,24 @@ def make_octree_parts(mesh, n_parts=1, axis=0, tol=1e-7, max_iter=10000, sign_se
         loc[node_ids] = np.arange(len(node_ids))
         dof_ids = (3 * node_ids[:, None] + np.arange(3)).ravel()
         groups = []
+        comps = getattr(mesh, "group_comp", None) or [None] * len(flips)
+        oflips = getattr(mesh, "group_flip", None) or [None] * len(flips)
         for t, (g, po, ck, ke, fl) in enumerate(zip(mesh.group_nodes, part_of, mesh.group_ck, mesh.group_ke, flips)):
             sel = np.flatnonzero(po == pid)
             if len(sel) == 0:
                 continue
             ln = loc[g[sel]]                                                              # (ne, nn)
-            tbl = np.ascontiguousarray((3 * ln[:, :, None] + np.arange(3)).reshape(len(sel), -1).T)
+            # slot 3 l + c of the type = component comp[e, c] of local node l (x, y, z order unless the mesh orients its types)
+            cp = np.arange(3)[None, :] if comps[t] is None else comps[t][sel]
+            tbl = np.ascontiguousarray((3 * ln[:, :, None] + cp[:, None, :]).reshape(len(sel), -1).T)
+            sgn = np.broadcast_to(fl[:, None], tbl.shape)
+            if oflips[t] is not None:
+                sgn = sgn ^ np.tile(oflips[t][sel], (1, g.shape[1])).T
             d = np.where(fl, -1.0, 1.0)
             ke_t = ke * d[:, None] * d[None, :]
             groups.append({"ElemTypeId": t, "ElemList_LocDofVector": tbl, "ElemList_LocDofVector_Flat": tbl.ravel(),
                            "ElemList_LocNodeIdVector": np.ascontiguousarray(ln.T),
-                           "ElemList_SignVector": np.ascontiguousarray(np.broadcast_to(fl[:, None], tbl.shape)),
+                           "ElemList_SignVector": np.ascontiguousarray(sgn),
                            "ElemList_Ck": ck[sel].copy(), "ElemStiffMat": ke_t, "ElemDiagStiffMat": np.diag(ke_t).copy(),
                            "N_Elem": len(sel), "NNodes": g.shape[1]})
         flat = np.concatenate([g["ElemList_LocDofVector_Flat"] for g in groups])
@@ -269,6 +276,66 @@ def pattern_stiffness(mask):
     return 0.5 * (K + K.T)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Pattern library by SYMMETRY CLASS (round 4).  The reference's library holds one matrix per cell pattern up to the 48
+# rotations / reflections of the cube (Type 0 ... 143, partition_mesh.py:1074); an element of another orientation refers to the
+# class's matrix through the ORDER of its dof list (LocDofVector, partition_mesh.py:453) and its sign vector (:455): canonical
+# dof (node l, component c) is the physical dof (node g(l), component sigma(c)) with sign s(c), g the symmetry that carries
+# the canonical pattern onto the element.  `GradedOctreeMesh(symmetry=True)` builds its types that way: ONE matrix per class,
+# every element with its own dof order and signs - the three dofs of a node are then NOT in x, y, z order in the dof list.
+# ---------------------------------------------------------------------------------------------------------------------
+def cube_symmetries():
+    """The 48 signed permutation matrices Q (as (perm, sign): (Q v)[d] = sign[d] * v[perm[d]]), identity first."""
+    import itertools
+    out = []
+    for perm in itertools.permutations(range(3)):
+        for sg in itertools.product((1, -1), repeat=3):
+            out.append((tuple(perm), tuple(sg)))
+    out.sort(key=lambda q: (q != ((0, 1, 2), (1, 1, 1)), q))
+    return out
+
+
+def _sym_point(q, pt):
+    """Image of the lattice point pt in {0,1,2}^3 of a cell of edge 2 under the symmetry q (about the cell centre)."""
+    perm, sg = q
+    return tuple(sg[d] * (pt[perm[d]] - 1) + 1 for d in range(3))
+
+
+def _sym_mask(q, mask):
+    out = 0
+    for b, pt in enumerate(HANG_POS):
+        if (mask >> b) & 1:
+            out |= 1 << HANG_POS.index(_sym_point(q, pt))
+    return out
+
+
+def canonical_pattern(mask):
+    """(canonical mask, q): the smallest image of `mask` under the 48 symmetries and a symmetry q that carries the canonical
+    pattern ONTO `mask` (first in cube_symmetries() order)."""
+    syms = cube_symmetries()
+    canon = min(_sym_mask(q, mask) for q in syms)
+    for q in syms:
+        if _sym_mask(q, canon) == mask:
+            return canon, q
+    raise AssertionError("no symmetry found")
+
+
+def pattern_frame(mask):
+    """For an element with hanging mask `mask`: (canonical mask, node_src, comp, flip) - canonical local node l sits at the
+    element's position node_src[l] (0..7 = corner a, 8 + b = HANG_POS[b]); canonical component c is the physical component
+    comp[c], negated when flip[c]  (u_canon = Q^T u_phys)."""
+    canon, q = canonical_pattern(mask)
+    perm, sg = q
+    kept = list(_CORNERS) + [HANG_POS[b] for b in range(18) if (canon >> b) & 1]
+    src = []
+    for pt in kept:
+        im = _sym_point(q, pt)
+        src.append(_CORNERS.index(im) if im in _CORNERS else 8 + HANG_POS.index(im))
+    comp = [perm.index(c) for c in range(3)]                     # Q[d][c] != 0  <=>  perm[d] == c
+    flip = [sg[comp[c]] < 0 for c in range(3)]
+    return canon, np.array(src), np.array(comp), np.array(flip)
+
+
 class GradedOctreeMesh:
     """`roots` = (Rx, Ry, Rz) root cells of edge 2**levels lattice units, refined over `levels` levels towards the sphere
     |x - centre| = radius: a cell of edge s is split when its centre lies within band * s of the surface; then balanced 2:1
@@ -276,8 +343,9 @@ class GradedOctreeMesh:
     group_level, coords, fixed_nodes, top_nodes, load_vector) - make_octree_parts, mdf.model_from_octree and
     partition.partition_model take either.  Host-side set-up only (whole-array NumPy)."""
 
-    def __init__(self, roots=(4, 4, 4), levels=3, centre=None, radius=None, band=1.0, seed=0, two_phase=True):
+    def __init__(self, roots=(4, 4, 4), levels=3, centre=None, radius=None, band=1.0, seed=0, two_phase=True, symmetry=False):
         L = int(levels)
+        self.symmetry = bool(symmetry)
         R = np.array(roots, np.int64)
         S0 = 1 << L
         dims = R * S0                                            # lattice extent (cells of edge 1)
@@ -384,23 +452,51 @@ class GradedOctreeMesh:
         mat = np.where(rng.random(len(org)) < 0.5, 1.0, 3.0) if two_phase else np.ones(len(org))    # two-phase scaling like brick.py
         ctr = org + size[:, None] / 2.0
         self.pattern_masks = [0] + sorted(int(m) for m in np.unique(mask) if m != 0)
+        self.n_orientations = len(self.pattern_masks)
         self.group_nodes, self.group_ck, self.group_ke, self.group_centroid, self.group_level = [], [], [], [], []
-        for m in self.pattern_masks:
-            sel = np.flatnonzero(mask == m)
-            if m == 0:
+        # per group (ne, 3) arrays or None: canonical component c of an element is its physical component group_comp[e, c], negated
+        # where group_flip[e, c] (None = x, y, z order, no flips: always so without `symmetry`, and for the hex8 type)
+        self.group_comp, self.group_flip = [], []
+        if symmetry:
+            # ONE type per symmetry class: the elements of every orientation of the class, nodes in the canonical pattern's order
+            frames = {m: pattern_frame(m) for m in self.pattern_masks if m != 0}
+            types = [(0, [0])] + [(cm, [m for m in self.pattern_masks if m != 0 and frames[m][0] == cm])
+                                  for cm in sorted({f[0] for f in frames.values()})]
+            all_pos = np.concatenate([cn, hang_ids], 1)                      # (E, 26): corner a at a, HANG_POS[b] at 8 + b
+        else:
+            types = [(m, [m]) for m in self.pattern_masks]
+        for cm, members in types:
+            sel = np.flatnonzero(np.isin(mask, members))
+            comp = flip = None
+            if cm == 0:
                 nodes = cn[sel]
                 ck = size[sel] * mat[sel]                        # 3-D elasticity: K ~ edge length
                 ke = hex8_stiffness()
-            else:
-                bits = [q for q in range(18) if (m >> q) & 1]
+            elif not symmetry:
+                bits = [q for q in range(18) if (cm >> q) & 1]
                 nodes = np.concatenate([cn[sel], hang_ids[sel][:, bits]], 1)
                 ck = (size[sel] / 2.0) * mat[sel]                # pattern_stiffness is the matrix of a cell of edge 2
-                ke = pattern_stiffness(m)
+                ke = pattern_stiffness(cm)
+            else:
+                nodes = np.zeros((len(sel), 8 + bin(cm).count("1")), np.int64)
+                comp = np.zeros((len(sel), 3), np.int64)
+                flip = np.zeros((len(sel), 3), bool)
+                for m in members:
+                    _, src, cp, fl = frames[m]
+                    w = np.flatnonzero(mask[sel] == m)
+                    nodes[w] = all_pos[sel[w]][:, src]
+                    comp[w] = cp
+                    flip[w] = fl
+                ck = (size[sel] / 2.0) * mat[sel]
+                ke = pattern_stiffness(cm)
             self.group_nodes.append(np.ascontiguousarray(nodes))
             self.group_ck.append(ck)
             self.group_ke.append(ke)
             self.group_centroid.append(ctr[sel])
             self.group_level.append(size[sel].astype(float))
+            self.group_comp.append(comp)
+            self.group_flip.append(flip)
+        self.pattern_masks = [cm for cm, _ in types]
         self.coords = np.stack([used % X, (used // X) % Y, used // (X * Y)], 1).astype(float)
         self.fixed_nodes = np.flatnonzero(self.coords[:, 2] == 0)
         self.top_nodes = np.flatnonzero(self.coords[:, 2] == self.coords[:, 2].max())
@@ -416,6 +512,10 @@ class GradedOctreeMesh:
         return {"dofs": int(self.n_dof), "elements": int(self.n_elem), "levels": self.levels + 1,
                 "leaves_per_level_coarse_to_fine": [int(v) for v in self.leaves_per_level],
                 "pattern_types": len(self.pattern_masks),
+                **({"pattern_orientations": int(self.n_orientations),
+                    "pattern_note": "one type per class of the cube's 48 symmetries; an element carries its orientation in the order "
+                                    "of its dof list and in its sign vector (the reference's pattern library: partition_mesh.py:453-455,1074)"}
+                   if self.symmetry else {}),
                 "nodes_per_element_max": int(max(g.shape[1] for g in self.group_nodes)),
                 "elements_hex8": int(len(self.group_nodes[0])),
                 "elements_with_hanging_nodes": int(self.n_elem - len(self.group_nodes[0])),

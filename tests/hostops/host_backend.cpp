@@ -108,11 +108,12 @@ public:
                         const double *F = M.frag.data() + T.frag_off;
                         out.assign((size_t)16 * T.nd, 0.0);
                         auto sb = [&](int e, int a) { return (M.tsgn[((size_t)ti * W + a / 32) * 16 + e] >> (a % 32)) & 1u; };
+                        auto pc = [&](int e, int c) { return (M.tperm[(size_t)ti * 16 + e] >> (2 * c)) & 3; };   // the element's own dof order
                         for (int e = 0; e < 16; ++e) {
                             if (M.tcol[(size_t)ti * 16 + e] == 255) continue;
                             uu.assign(T.nd, 0.0);
                             for (int b = 0; b < T.nd; ++b) {
-                                double v = xs[3 * M.tlid[((size_t)ti * NP + b / 3) * 16 + e] + b % 3];
+                                double v = xs[3 * M.tlid[((size_t)ti * NP + b / 3) * 16 + e] + pc(e, b % 3)];
                                 uu[b] = M.tck[(size_t)ti * 16 + e] * (sb(e, b) ? -v : v);
                             }
                             for (int g = 0; g < 4; ++g)                  // the data flow of the matrix-core tile (fragments as uploaded)
@@ -133,7 +134,7 @@ public:
                         for (int col = 0; col < M.tile_ncol[ti]; ++col)
                             for (int e = 0; e < 16; ++e)
                                 if (M.tcol[(size_t)ti * 16 + e] == col)
-                                    for (int k = 0; k < T.nd; ++k) ys[3 * M.tlid[((size_t)ti * NP + k / 3) * 16 + e] + k % 3] += out[(size_t)e * T.nd + k];
+                                    for (int k = 0; k < T.nd; ++k) ys[3 * M.tlid[((size_t)ti * NP + k / 3) * 16 + e] + pc(e, k % 3)] += out[(size_t)e * T.nd + k];
                     }
                     for (int n = 0; n < nn; ++n) {
                         const int32_t dst = C.dst[off + n];

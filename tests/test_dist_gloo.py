@@ -26,7 +26,7 @@ def collect(case, outs):
 @pytest.mark.parametrize("case,nproc,port", [("n9_p2", 2, 29611), ("n13_t3_p4_ud", 4, 29612), ("n9_p8", 8, 29613),
                                              ("n9_p2_maxiter", 2, 29614), ("n9_p2_flag4", 2, 29616),
                                              ("oct_p3", 3, 29617), ("oct_p2_z", 2, 29618), ("goct_p4", 4, 29619),
-                                             ("goct_p3_ud", 3, 29681)])
+                                             ("goct_p3_ud", 3, 29681), ("goct_sym_p3", 3, 29684)])
 def test_multi_rank_solve_matches_reference(tmp_path, case, nproc, port):
     outs = run_dist(case, nproc, "gloo", "hostops", tmp_path, port)
     g = golden(case)

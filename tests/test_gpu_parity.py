@@ -636,6 +636,37 @@ def test_graded_octree_1m_dof(gpu_lib, oracle_c, kind):
         print("graded octree 1 M dof, matrix-free:", op.operator_info())
 
 
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_graded_octree_1m_dof_oriented_patterns(gpu_lib, oracle_c, kind):
+    """The same 1 M-dof mesh with ONE pattern type per class of the cube's 48 symmetries (8 types for 95 orientations): every
+    element lists its dofs in the order of its class's canonical pattern, with signs - the reference's pattern-library form
+    (partition_mesh.py:453-455,1074).  The matrix-free operator takes such elements in the tiles of its mixed chunks (a 3-bit
+    component order per element); the operator is the one of the 95-type mesh up to rounding, so the oracle's results for THAT
+    mesh are the reference here: mat-vec <= 1e-13, same Flag, iterations within 1 %, solution <= 2e-7."""
+    from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+    G = _graded_1m()
+    mesh = GradedOctreeMesh((12, 12, 12), 4, band=1.2, symmetry=True)
+    s = mesh.summary()
+    assert s["dofs"] == G["mesh"].n_dof and s["pattern_types"] == 8 and s["pattern_orientations"] == 95
+    P = make_octree_parts(mesh, 1)[0]
+    assert any((g["ElemList_LocDofVector"][:3] % 3 != np.arange(3)[:, None]).any() for g in P["SubDomainData"]["StrucDataList"])
+    pm.configure(comm=None, device=0, operator=kind)
+    op = pm.get_operator(P)
+    pm.configure(comm=None, device=0, operator="sell")
+    assert relerr(op.apply(G["x"]), G["ax"]) < 1e-13
+    if kind == "ebe":
+        info = op.operator_info()
+        print("graded octree 1 M dof, oriented patterns, matrix-free:", info)
+        assert info["n_colors"] == 1                                       # one launch per phase: no colour launches
+    pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P)
+    out = G["out"]
+    assert relerr(P["Fext"], G["R"]["Fext"]) < 1e-13
+    assert relerr(P["InvDiagPreCondVector0"], G["R"]["InvDiagPreCondVector0"]) < 1e-14
+    assert P["GlobData"]["TimeList_Flag"][1] == out["flag"] == 0
+    assert abs(P["GlobData"]["TimeList_Iter"][1] - out["iter"]) <= max(2, out["iter"] // 100)
+    assert relerr(P["Un"], G["R"]["Un"]) < 2e-7
+
+
 def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
     """Round 4, k_ebe_mixed: chunks that hold the elements of every pattern type of a run of the Morton order (hex section on the
     vector FMAs, 16-element tiles of the other types on the f64 matrix cores, node sums in LDS) against the oracle's mat-vec
@@ -759,7 +790,7 @@ def test_hanging_node_kernels_with_and_without_node_tile_agree(gpu_lib, monkeypa
 
 
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
-@pytest.mark.parametrize("case", ["n9_p2", "n9_p8", "n9_p2_flag4", "oct_p3", "oct_p2_z", "goct_p4"])
+@pytest.mark.parametrize("case", ["n9_p2", "n9_p8", "n9_p2_flag4", "oct_p3", "oct_p2_z", "goct_p4", "goct_sym_p3"])
 def test_multi_part_kernels_on_one_gpu(gpu_lib, case, kind):
     """2..8 mesh parts as 2..8 engines on THE SAME GPU, one thread per part, exchanging through tests/thread_comm.py:
     interface-first ordering, k_halo_pack, k_fixup (+ its dot), the boundary / interior launches of both operators and

@@ -65,6 +65,40 @@ def test_patch_test_on_the_assembled_mesh(mesh):
     assert np.abs(pcg_oracle.matvec_local(P, t)).max() < 1e-12
 
 
+def test_one_pattern_type_per_symmetry_class():
+    """GradedOctreeMesh(symmetry=True): the pattern types are the classes of the hanging masks under the cube's 48 symmetries (the
+    reference's library form, partition_mesh.py:1074: Type 0 ... 143); an element's orientation is carried by the order of its dof
+    list and by its sign vector (:453-455).  The frame reproduces the pattern's own matrix (to rounding), the three dofs of a node
+    stay together but not in x, y, z order, and the operator of the mesh is the one of the mesh with one type per ORIENTATION."""
+    from pcg_mi355x.octree import cube_symmetries, pattern_frame
+    assert len(cube_symmetries()) == 48 and cube_symmetries()[0] == ((0, 1, 2), (1, 1, 1))
+    plain = GradedOctreeMesh((4, 4, 4), 3, band=1.2)
+    sym = GradedOctreeMesh((4, 4, 4), 3, band=1.2, symmetry=True)
+    assert len(plain.pattern_masks) == sym.n_orientations == 95 and len(sym.pattern_masks) == 8 and sym.n_elem == plain.n_elem
+    for m in plain.pattern_masks[1::7]:
+        canon, src, comp, flip = pattern_frame(m)
+        bits = [b for b in range(18) if (m >> b) & 1]
+        pos = {**{a: a for a in range(8)}, **{8 + b: 8 + i for i, b in enumerate(bits)}}
+        idx = np.array([3 * pos[src[l]] + comp[c] for l in range(len(src)) for c in range(3)])
+        sg = np.array([-1.0 if flip[c] else 1.0 for l in range(len(src)) for c in range(3)])
+        Kp = pattern_stiffness(m)
+        K2 = np.zeros_like(Kp)
+        K2[np.ix_(idx, idx)] = pattern_stiffness(canon) * sg[:, None] * sg[None, :]
+        assert np.abs(K2 - Kp).max() <= 4e-16 * np.abs(Kp).max()
+    A, B = make_octree_parts(plain, 1)[0], make_octree_parts(sym, 1, sign_seed=4)[0]
+    reordered = 0
+    for g in B["SubDomainData"]["StrucDataList"]:
+        t = g["ElemList_LocDofVector"]
+        assert np.array_equal(t[0::3] // 3, t[1::3] // 3) and np.array_equal(t[0::3] // 3, t[2::3] // 3)      # node-blocked
+        assert np.array_equal(np.sort(np.stack([t[0::3] % 3, t[1::3] % 3, t[2::3] % 3]), axis=0)[:, 0], np.tile(np.arange(3)[:, None], (1, t.shape[1])))
+        reordered += int((t[:3] % 3 != np.arange(3)[:, None]).any(axis=0).sum())
+    assert reordered > 100
+    x = np.random.default_rng(3).standard_normal(plain.n_dof)
+    ya, yb = pcg_oracle.matvec_local(A, x), pcg_oracle.matvec_local(B, x)
+    assert np.abs(ya - yb).max() <= 1e-14 * np.abs(ya).max()
+    assert np.abs(pcg_oracle.matvec_local(A, None, "Preconditioner") - pcg_oracle.matvec_local(B, None, "Preconditioner")).max() <= 1e-14 * np.abs(ya).max()
+
+
 @pytest.mark.parametrize("n_parts", [2, 5, 8])
 def test_bisection_parts_cover_the_mesh(mesh, n_parts):
     ep = bisect_elements(mesh, n_parts)

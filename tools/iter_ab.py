@@ -2,7 +2,8 @@
 """Per-iteration time of the PCG loop, same process / same operator A/B over environment switches the engine re-reads at
 solve_begin (PCG_VEC_FUSED, PCG_VEC_NT, PCG_VEC_KREG, PCG_LOOK_AHEAD is read at creation).
 usage: python tools/iter_ab.py N[,N..] kind[,kind..] [steps] [VAR=a|b ...]      e.g.  iter_ab.py 75,150 ebe,dict 200 PCG_VEC_FUSED=1|0
-N = nodes per side of the brick, or oct1m / oct10m = the graded octree mesh."""
+N = nodes per side of the brick, or oct1m / oct10m = the graded octree mesh (oct1ms / oct10ms: one pattern type per symmetry class,
+GradedOctreeMesh(symmetry=True))."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -21,7 +22,7 @@ switches = [sw for sw in switches if sw[0].split("+")[0] not in CREATE] or [["_"
 for N in Ns:
     if isinstance(N, str):                       # the multi-level graded octree mesh (pcg_mi355x.octree.GradedOctreeMesh)
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
-        P = make_octree_parts(GradedOctreeMesh({"oct1m": (12, 12, 12), "oct10m": (38, 38, 38)}[N], 4, band=1.2), 1)[0]
+        P = make_octree_parts(GradedOctreeMesh({"oct1m": (12, 12, 12), "oct10m": (38, 38, 38)}[N.rstrip("s")], 4, band=1.2, symmetry=N.endswith("s")), 1)[0]
     else:
         P = make_parts(Brick(N))[0]
     for kind in kinds:
