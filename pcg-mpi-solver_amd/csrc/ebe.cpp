@@ -812,6 +812,20 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 fprintf(stderr, "ebe plan: mixed chunks: %lld elements in the hex section, %lld in %lld tiles of 16 (%.0f %% full), %zu tile types, "
                                 "at most %d M-tiles\n", (long long)C.mixed.hex_elems, (long long)C.mixed.tile_elems, (long long)C.mixed.n_tiles,
                         C.mixed.n_tiles ? 100.0 * C.mixed.tile_elems / (16.0 * C.mixed.n_tiles) : 0.0, C.mixed.types.size(), C.mixed.max_mt);
+            if (C.mixed.n_tiles) {                                  // per tile type: node quartets, tiles, elements; fill histogram
+                std::vector<int64_t> tl(C.mixed.types.size(), 0), el(C.mixed.types.size(), 0), hist(17, 0);
+                for (int64_t t = 0; t < C.mixed.n_tiles; ++t) {
+                    int cnt = 0;
+                    for (int e = 0; e < 16; ++e) cnt += C.mixed.tcol[(size_t)t * 16 + e] != 255;
+                    tl[C.mixed.tile_type[t]]++; el[C.mixed.tile_type[t]] += cnt; hist[cnt]++;
+                }
+                for (size_t t = 0; t < tl.size(); ++t)
+                    fprintf(stderr, "ebe plan:   tile type %zu: %d nodes (J = %d), %lld tiles, %lld elements\n", t, C.mixed.types[t].nn, C.mixed.types[t].J,
+                            (long long)tl[t], (long long)el[t]);
+                fprintf(stderr, "ebe plan:   tiles by elements held (1..16):");
+                for (int c = 1; c <= 16; ++c) fprintf(stderr, " %lld", (long long)hist[c]);
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots\n", (long long)n_nodes,
                     (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots);
         }

@@ -554,10 +554,11 @@ public:
         }
         const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgn = up(M.tsgn), *d_tcol = up(M.tcol), *d_tperm = up(M.tperm), *d_frag = up(M.frag);
         mix_mtm_ = std::max(2, M.max_mt);
+        if (const char *e = getenv("PCG_EBE_MIX_MTM")) mix_mtm_ = std::max(mix_mtm_, std::min(6, atoi(e)));   // development: a larger instantiation (>= 5: 168 VGPRs, 3 workgroups per CU)
         for (int ph = 0; ph < 2; ++ph) {
             const size_t n = K.list[ph].size();
             if (!n) continue;
-            std::vector<int> hdr(8 * n, 0), nodes(n * MAXN, -1), dst(n * MAXN, 0);
+            std::vector<int> hdr(8 * n, 0), nodes(n * MAXN, -1), dst(n * MAXN, INT32_MIN);
             std::vector<unsigned short> tslot(n * MAXN, 0), lid(n * 8 * CE, 0);
             std::vector<double> ck(n * CE, 0.0);
             std::vector<unsigned> sgn(n * CE, 0xff000000u);
@@ -593,7 +594,56 @@ public:
     void launch_mixed(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], ke, x, y, d_ch_buf_, part, dot_lo); };
+        if constexpr (MTM == 4) {
+            if (dot && stamp_launch_ >= 0 && count >= 64 && ++stamp_launch_ == 40) { launch_mixed_stamped(ph, count, ke, x, y, part, dot_lo); return; }
+        }
         if (dot) go(k_ebe_mixed<MTM, true>); else go(k_ebe_mixed<MTM, false>);
+    }
+    // Development (PCG_EBE_STAMPS=1): the 40th fused-dot launch of the mixed kernel runs the STAMP instantiation - every wave writes the
+    // shader clock at its phase boundaries - and the means over the waves go to stderr (cycles).  Same results, one slower launch.
+    int stamp_launch_ = getenv("PCG_EBE_STAMPS") && atoi(getenv("PCG_EBE_STAMPS")) ? 0 : -1;
+    void launch_mixed_stamped(int ph, int count, const double *ke, const double *x, double *y, double *part, long long dot_lo)
+    {
+        const size_t nw = (size_t)count * kWavesPerBlock;
+        unsigned long long *d = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d, nw * 16 * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemsetAsync(d, 0, nw * 16 * sizeof(unsigned long long), ls_));
+        MixTab T = mix_tab_[ph];
+        T.stamps = d;
+        hipLaunchKernelGGL((k_ebe_mixed<4, true, true>), dim3(count), dim3(kChunkThreads), 0, ls_, T, ke, x, y, d_ch_buf_, part, dot_lo);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ls_));
+        std::vector<unsigned long long> h(nw * 16);
+        HIP_CHECK(hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        // phase k = stamp[k] - stamp[k - 1] where both were written (a wave without a second hex pass has no stamps 5..7)
+        static const char *name[12] = {"", "stage (tables, x gather, barrier)", "hex pass 0: contraction", "hex pass 0: wait for the ticket", "hex pass 0: adds",
+                                       "hex pass 1: contraction (incl. slot loads)", "hex pass 1: wait for the ticket", "hex pass 1: adds", "-", "tile phase",
+                                       "final barrier", "write-out + dot"};
+        double sum[12] = {0}; long long cnt[12] = {0};
+        double life = 0, tiles = 0, tc = 0, tw = 0, ta = 0;
+        unsigned long long t_min = ~0ull, t_max = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned long long *s = &h[w * 16];
+            unsigned long long prev = s[0];
+            for (int k = 1; k < 12; ++k) {
+                if (k == 8) { if (s[8]) prev = s[8]; continue; }
+                if (!s[k]) continue;
+                sum[k] += (double)(s[k] - prev); cnt[k]++;
+                prev = s[k];
+            }
+            life += (double)(s[11] - s[0]);
+            t_min = std::min(t_min, s[0]); t_max = std::max(t_max, s[11]);
+            tiles += (double)s[12]; tc += (double)s[13]; tw += (double)s[14]; ta += (double)s[15];
+        }
+        fprintf(stderr, "[pcg] k_ebe_mixed stamps, phase %d: %d workgroups, kernel %.0f clock ticks first entry to last exit, mean wave lifetime %.0f\n", ph, count,
+                (double)(t_max - t_min), life / nw);
+        for (int k = 1; k < 12; ++k)
+            if (cnt[k]) fprintf(stderr, "[pcg]   %-44s %9.0f per wave that ran it (%lld of %zu waves), %9.0f averaged over all waves\n", name[k], sum[k] / cnt[k], cnt[k], nw,
+                                sum[k] / nw);
+        if (tiles > 0)
+            fprintf(stderr, "[pcg]   tiles: %.2f per wave; per tile: %.0f header -> end of contraction, %.0f waiting for the ticket, %.0f adds\n", tiles / nw, tc / tiles,
+                    tw / tiles, ta / tiles);
     }
     // k_ebe_hex: the hex8 class laid out per launch (phase): block b's data at fixed strides of b
     void build_hex_tables(const EbeChunkedHost &C)

@@ -658,6 +658,7 @@ struct MixTab {
     int np, words, xcd;
     int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
                                   // bits 4..6: development ablations (wrong results)
+    unsigned long long *stamps;   // STAMP instantiation only (PCG_EBE_STAMPS=1, development): [workgroup][wave][16] shader-clock readings
 };
 
 typedef double d4m_t __attribute__((ext_vector_type(4)));
@@ -665,7 +666,7 @@ typedef double d4m_t __attribute__((ext_vector_type(4)));
 // one tile, J node quartets (compile time): acc[mt] = sum over the k-steps of A(ks, mt) . U(ks)
 template <int J, int MTM>
 __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F, const double *xs, const int (&l3)[(4 * MTM) / 3], double c,
-                                                    const unsigned (&sg)[3], const int (&pc)[3], int g, int nn, d4m_t (&acc)[MTM])
+                                                    const unsigned (&sg)[3], int pw, int g, int nn, d4m_t (&acc)[MTM])
 {
     constexpr int MT = (3 * J + 3) / 4;
     static_assert(MT <= MTM, "tile type larger than the kernel instantiation");
@@ -673,7 +674,7 @@ __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F
     for (int j = 0; j < J; ++j) {
         const int node = 4 * j + g;
         const bool live = node < nn;
-        const double x0 = xs[l3[j] + pc[0]], x1 = xs[l3[j] + pc[1]], x2 = xs[l3[j] + pc[2]];      // the element's own dof order (:277)
+        const double x0 = xs[l3[j] + (pw & 3)], x1 = xs[l3[j] + ((pw >> 2) & 3)], x2 = xs[l3[j] + ((pw >> 4) & 3)];   // the element's own dof order (:277)
         const double xv[3] = {x0, x1, x2};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
@@ -691,7 +692,7 @@ __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F
     }
 }
 
-template <int MTM, bool DOT>
+template <int MTM, bool DOT, bool STAMP = false>
 __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed(MixTab T, const double *__restrict__ ke_col,
                                                                                    const double *__restrict__ x, double *__restrict__ y,
                                                                                    double *__restrict__ buf, double *__restrict__ partials,
@@ -713,6 +714,15 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&turn, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
+    // development: where a wave's lifetime goes - slot k of (workgroup, wave) <- shader clock (STAMP instantiation only)
+    unsigned long long tile_acc[4] = {0, 0, 0, 0};
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + k] = t;
+        }
+    };
+    stamp(0);
     const int4 h = T.hdr[2 * b], h2 = T.hdr[2 * b + 1];
     const int n_hex = h.z;
     if (threadIdx.x == 0) turn = 0;
@@ -728,25 +738,29 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         for (int k = 0; k < 8; ++k) l3[k] = 3 * (int)__builtin_nontemporal_load(T.lid + ((size_t)b * 8 + k) * CE + ps * kChunkThreads + threadIdx.x);
     };
     if (n_hex > 0) load_elem(0);
-    int g[NPT], dst[NPT], sl3[NPT], wmask[NPT];
+    // (two registers per tile node stay live to the write-out: the destination - INT_MIN = no node - and the slot word)
+    int dst[NPT], ts[NPT];
+    {
+        int g[NPT];
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
-        g[j] = ntload(T.nodes + n);
-        dst[j] = ntload(T.dst + n);
-        const int ts = (int)__builtin_nontemporal_load(T.tslot + n);
-        sl3[j] = 3 * (ts & 0x3ff);
-        wmask[j] = ts >> 12;
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
-            const double *xp = x + 3 * (size_t)g[j];
-            const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
-            xs[sl3[j]] = x0; xs[sl3[j] + 1] = x1; xs[sl3[j] + 2] = x2;
-            ys[sl3[j]] = 0.0; ys[sl3[j] + 1] = 0.0; ys[sl3[j] + 2] = 0.0;
+        for (int j = 0; j < NPT; ++j) {
+            const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+            g[j] = ntload(T.nodes + n);
+            dst[j] = ntload(T.dst + n);
+            ts[j] = (int)__builtin_nontemporal_load(T.tslot + n);
         }
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (g[j] >= 0) {
+                const int sl3 = 3 * (ts[j] & 0x3ff);
+                const double *xp = x + 3 * (size_t)g[j];
+                const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+                xs[sl3] = x0; xs[sl3 + 1] = x1; xs[sl3 + 2] = x2;
+                ys[sl3] = 0.0; ys[sl3 + 1] = 0.0; ys[sl3 + 2] = 0.0;
+            }
+    }
     __syncthreads();
+    stamp(1);
     // ---- hex section: two passes of one element per thread (k_ebe_hexs), skipped when empty ----------------------------------
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
@@ -776,6 +790,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                 if (h.w) contract(std::true_type());
                 else contract(std::false_type());
             }
+            stamp(2 + 3 * ps);
             const unsigned my_colour = sg >> 24;
             const int a0[8] = {l3[0], l3[1], l3[2], l3[3], l3[4], l3[5], l3[6], l3[7]};
             if (ps == 0 && n_hex > kChunkThreads) load_elem(1);  // the other half's slots arrive under this accumulation
@@ -794,8 +809,10 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                 }
             } else {                                             // ticket ps * 4 + wave: wave after wave, nobody else waits
                 take_turn(ps * kWavesPerBlock + wave);
+                stamp(3 + 3 * ps);
                 add_hex();
                 pass_turn(ps * kWavesPerBlock + wave + 1);
+                stamp(4 + 3 * ps);
             }
           }
         }
@@ -804,7 +821,10 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
     const int n_tiles = (T.flags & 64) ? 0 : h2.x, lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // (provably wave-uniform: the tile's header comes by scalar loads)
     int2 info_next = wave_u < n_tiles ? T.tinfo[(size_t)h2.y + wave_u] : make_int2(0, 0);
+    stamp(8);
     for (int t0 = 0; t0 < n_tiles; t0 += kWavesPerBlock) {       // block-uniform
+        unsigned long long tt0 = 0, tt1 = 0, tt2 = 0;
+        if constexpr (STAMP) tt0 = __builtin_amdgcn_s_memtime();
         const int ti = t0 + wave_u;
         const bool have = ti < n_tiles;                          // wave-uniform
         const int2 info = info_next;                             // this tile's header was requested a round ago:
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         d4m_t acc[MTM];
         int tl3[JM];
         unsigned tsg[3] = {0u, 0u, 0u};
-        int tpc[3] = {0, 1, 2};
+        int pw = 0 | 1 << 2 | 2 << 4;
         int nn = 0, ncol = 0, mycol = 255;
 #pragma unroll
         for (int mt = 0; mt < MTM; ++mt) acc[mt] = d4m_t{0.0, 0.0, 0.0, 0.0};
@@ -826,8 +846,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             const double *F = T.frag + (size_t)__builtin_amdgcn_readfirstlane(info.y) * 64 + lane;
             const double tc = T.tck[tg * 16 + le];
             mycol = (int)T.tcol[tg * 16 + le];
-            const int pw = (int)T.tperm[tg * 16 + le];
-            tpc[0] = pw & 3; tpc[1] = (pw >> 2) & 3; tpc[2] = (pw >> 4) & 3;
+            pw = (int)T.tperm[tg * 16 + le];
 #pragma unroll
             for (int w = 0; w < 3; ++w)
                 if (w < T.words) tsg[w] = T.tsgn[(tg * T.words + w) * 16 + le];
@@ -835,14 +854,14 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             for (int j = 0; j < JM; ++j)
                 if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
             switch ((T.flags & 32) ? 0 : J) {                     // wave-uniform: straight-line code per size
-            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
-            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, tpc, lg, nn, acc); break;
+            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
             default: break;
             }
         }
@@ -860,7 +879,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                                     word = (d >> 5) == 2 ? tsg[2] : word;
                                     const double a = acc[q / 4][q % 4];
                                     const double o = ((word >> (d & 31)) & 1u) ? -a : a;                      // :280
-                                    __hip_atomic_fetch_add(&ys[tl3[j] + tpc[cc]], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                                    __hip_atomic_fetch_add(&ys[tl3[j] + ((pw >> 2 * cc) & 3)], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
                                 }
                             }
                     }
@@ -871,23 +890,31 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                 __syncthreads();
             }
         } else if (have) {
+            if constexpr (STAMP) tt1 = __builtin_amdgcn_s_memtime();
             take_turn(hex_tickets + ti);
+            if constexpr (STAMP) tt2 = __builtin_amdgcn_s_memtime();
             if (!(T.flags & 16)) add_tile();
             pass_turn(hex_tickets + ti + 1);
+            if constexpr (STAMP) {                               // per wave: tiles taken, cycles to the end of the contraction, waiting, adding
+                tile_acc[0] += 1; tile_acc[1] += tt1 - tt0; tile_acc[2] += tt2 - tt1; tile_acc[3] += __builtin_amdgcn_s_memtime() - tt2;
+            }
         }
     }
+    stamp(9);
     if (!use_barriers) __syncthreads();                          // every add is in before the tile is written out
+    stamp(10);
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
-        if (g[j] >= 0) {
+        if (dst[j] != INT_MIN) {
+            const int sl3 = 3 * (ts[j] & 0x3ff), wmask = ts[j] >> 12;
             double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
-            const double y0 = ys[sl3[j]], y1 = ys[sl3[j] + 1], y2 = ys[sl3[j] + 2];
+            const double y0 = ys[sl3], y1 = ys[sl3 + 1], y2 = ys[sl3 + 2];
             out[0] = y0; out[1] = y1; out[2] = y2;
             if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {        // fused p.Ap.w (:487) on the dofs this chunk finalises
-                if (wmask[j] & 1) dot += xs[sl3[j]] * y0;
-                if (wmask[j] & 2) dot += xs[sl3[j] + 1] * y1;
-                if (wmask[j] & 4) dot += xs[sl3[j] + 2] * y2;
+                if (wmask & 1) dot += xs[sl3] * y0;
+                if (wmask & 2) dot += xs[sl3 + 1] * y1;
+                if (wmask & 4) dot += xs[sl3 + 2] * y2;
             }
         }
     if constexpr (DOT) {
@@ -895,6 +922,11 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         double v[1] = {dot};
         block_sum<1>(v, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+    stamp(11);
+    if constexpr (STAMP) {
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 12 + k] = tile_acc[k];
     }
 }
 

@@ -17,9 +17,10 @@ from pcg_mi355x.operator import from_refmeshpart
 kind = sys.argv[1] if len(sys.argv) > 1 else "ebe"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-if os.environ.get("PROF_OCTREE"):          # PROF_OCTREE=1m|10m: the multi-level graded octree mesh (N is ignored)
+if os.environ.get("PROF_OCTREE"):          # PROF_OCTREE=1m|10m (1ms|10ms: pattern types by symmetry class): the multi-level graded octree mesh (N is ignored)
     from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
-    m = GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[os.environ["PROF_OCTREE"]], 4, band=1.2)
+    m = GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[os.environ["PROF_OCTREE"].rstrip("s")], 4, band=1.2,
+                        symmetry=os.environ["PROF_OCTREE"].endswith("s"))
     P = make_octree_parts(m, 1)[0]
     print("octree mesh", m.summary())
 else:
