@@ -552,7 +552,20 @@ public:
             tinfo[2 * t] = T.nn | (T.J << 8) | (M.tile_ncol[t] << 16);
             tinfo[2 * t + 1] = (int)(T.frag_off / 64);
         }
-        const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgn = up(M.tsgn), *d_tcol = up(M.tcol), *d_tperm = up(M.tperm), *d_frag = up(M.frag);
+        // sign bits regrouped for the tile's lanes: lane group g of element e handles the nodes g, g + 4, ... - bit 3 j + c of its word is
+        // the sign of dof c of node 4 j + g (k-step 3 j + c on the way in, accumulator 3 j + c on the way out: constant shifts in the kernel)
+        std::vector<unsigned> tsgw((size_t)std::max<int64_t>(1, M.n_tiles) * 64, 0u);
+        for (int64_t t = 0; t < M.n_tiles; ++t) {
+            const auto &T = M.types[M.tile_type[t]];
+            for (int e = 0; e < 16; ++e)
+                for (int l = 0; l < T.nn; ++l)
+                    for (int c = 0; c < 3; ++c) {
+                        const int a = 3 * l + c;
+                        if ((M.tsgn[((size_t)t * M.words + a / 32) * 16 + e] >> (a % 32)) & 1u)
+                            tsgw[((size_t)t * 4 + l % 4) * 16 + e] |= 1u << (3 * (l / 4) + c);
+                    }
+        }
+        const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgw = up(tsgw), *d_tcol = up(M.tcol), *d_tperm = up(M.tperm), *d_frag = up(M.frag);
         mix_mtm_ = std::max(2, M.max_mt);
         if (const char *e = getenv("PCG_EBE_MIX_MTM")) mix_mtm_ = std::max(mix_mtm_, std::min(6, atoi(e)));   // development: a larger instantiation (>= 5: 168 VGPRs, 3 workgroups per CU)
         for (int ph = 0; ph < 2; ++ph) {
@@ -581,8 +594,8 @@ public:
             T.tslot = (const unsigned short *)up(tslot); T.lid = (const unsigned short *)up(lid); T.ck = (const double *)up(ck);
             T.sgn = (const unsigned *)up(sgn);
             T.tinfo = (const int2 *)d_tinfo; T.tlid = (const unsigned short *)d_tlid; T.tck = (const double *)d_tck;
-            T.tsgn = (const unsigned *)d_tsgn; T.tcol = (const unsigned char *)d_tcol; T.tperm = (const unsigned char *)d_tperm; T.frag = (const double *)d_frag;
-            T.np = M.nnpt; T.words = M.words; T.xcd = ebe_xcd_;
+            T.tsgw = (const unsigned *)d_tsgw; T.tcol = (const unsigned char *)d_tcol; T.tperm = (const unsigned char *)d_tperm; T.frag = (const double *)d_frag;
+            T.np = M.nnpt; T.xcd = ebe_xcd_;
             T.flags = 0;
             if (const char *e = getenv("PCG_EBE_MIX_FLAGS")) T.flags = atoi(e);      // bit 0: barriers instead of tickets; 16 / 32 / 64: ablations (development)
             mix_tab_[ph] = T;

@@ -651,11 +651,11 @@ struct MixTab {
     const int2 *tinfo;            // per tile: nodes | node quartets << 8 | colours << 16 ; fragment offset / 64
     const unsigned short *tlid;   // [tiles][np][16]
     const double *tck;            // [tiles][16]
-    const unsigned *tsgn;         // [tiles][words][16]
+    const unsigned *tsgw;         // [tiles][4][16]   lane group g of element e: bit 3 j + c = sign of dof c of the element's node 4 j + g
     const unsigned char *tcol;    // [tiles][16]   tile-local colour, 255 = padding slot
     const unsigned char *tperm;   // [tiles][16]   dof order of the element: slot 3 l + c is component (tperm >> 2 c) & 3 of node l
     const double *frag;
-    int np, words, xcd;
+    int np, xcd;
     int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
                                   // bits 4..6: development ablations (wrong results)
     unsigned long long *stamps;   // STAMP instantiation only (PCG_EBE_STAMPS=1, development): [workgroup][wave][16] shader-clock readings
@@ -664,30 +664,41 @@ struct MixTab {
 typedef double d4m_t __attribute__((ext_vector_type(4)));
 
 // one tile, J node quartets (compile time): acc[mt] = sum over the k-steps of A(ks, mt) . U(ks)
+// The A fragments come from L2 (one coalesced 512-B load per matrix instruction).  They are requested D k-steps AHEAD of their
+// instruction through an explicit ring of registers: left to itself the compiler issued ONE load, waited for it (vmcnt(0)) and ran
+// ONE instruction - 27-60 dependent L2 round trips per tile, 21.7 k cycles per tile for 2-4 k cycles of matrix-core time (clock
+// stamps, profiles/r04_stamps_sessionJ.log).
 template <int J, int MTM>
 __device__ __forceinline__ void mixed_tile_contract(const double *__restrict__ F, const double *xs, const int (&l3)[(4 * MTM) / 3], double c,
-                                                    const unsigned (&sg)[3], int pw, int g, int nn, d4m_t (&acc)[MTM])
+                                                    unsigned sw, int pw, int g, int nn, d4m_t (&acc)[MTM])
 {
-    constexpr int MT = (3 * J + 3) / 4;
+    constexpr int MT = (3 * J + 3) / 4, KS = 3 * J;
+    constexpr int D = KS < kMixedFragAhead ? KS : kMixedFragAhead;   // k-steps of fragments in flight
     static_assert(MT <= MTM, "tile type larger than the kernel instantiation");
+    double fr[D][MT];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fr[d][mt] = F[(size_t)(d * MT + mt) * 64];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int node = 4 * j + g;
-        const bool live = node < nn;
+        const bool live = g < nn - 4 * j;                        // (nn is wave-uniform: a scalar subtraction, no per-lane node number)
         const double x0 = xs[l3[j] + (pw & 3)], x1 = xs[l3[j] + ((pw >> 2) & 3)], x2 = xs[l3[j] + ((pw >> 4) & 3)];   // the element's own dof order (:277)
         const double xv[3] = {x0, x1, x2};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-            const int d = 3 * node + cc;
-            unsigned word = sg[0];
-            word = (d >> 5) == 1 ? sg[1] : word;
-            word = (d >> 5) == 2 ? sg[2] : word;
-            const double sx = ((word >> (d & 31)) & 1u) ? -xv[cc] : xv[cc];                                 // :278
-            const double u = live ? c * sx : 0.0;                                                           // :279 Ck * U
             const int ks = 3 * j + cc;
+            const double u = live ? c * flip_sign(xv[cc], sw, ks) : 0.0;                                    // :278-279 sign, Ck * U
+            double a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = fr[ks % D][mt];
+            if (ks + D < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fr[ks % D][mt] = F[(size_t)((ks + D) * MT + mt) * 64];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[(size_t)(ks * MT + mt) * 64], u, acc[mt], 0, 0, 0);   // :279 Ke @ (.)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], u, acc[mt], 0, 0, 0);               // :279 Ke @ (.)
         }
     }
 }
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
         if (ti + kWavesPerBlock < n_tiles) info_next = T.tinfo[(size_t)h2.y + ti + kWavesPerBlock];   // header -> fragments is the dependent chain
         d4m_t acc[MTM];
         int tl3[JM];
-        unsigned tsg[3] = {0u, 0u, 0u};
+        unsigned tsw = 0u;
         int pw = 0 | 1 << 2 | 2 << 4;
         int nn = 0, ncol = 0, mycol = 255;
 #pragma unroll
@@ -847,21 +858,19 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
             const double tc = T.tck[tg * 16 + le];
             mycol = (int)T.tcol[tg * 16 + le];
             pw = (int)T.tperm[tg * 16 + le];
-#pragma unroll
-            for (int w = 0; w < 3; ++w)
-                if (w < T.words) tsg[w] = T.tsgn[(tg * T.words + w) * 16 + le];
+            tsw = T.tsgw[(tg * 4 + lg) * 16 + le];
 #pragma unroll
             for (int j = 0; j < JM; ++j)
                 if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
             switch ((T.flags & 32) ? 0 : J) {                     // wave-uniform: straight-line code per size
-            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
-            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsg, pw, lg, nn, acc); break;
+            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
             default: break;
             }
         }
@@ -870,15 +879,11 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
                     if (mycol == s) {
 #pragma unroll
                         for (int j = 0; j < JM; ++j)
-                            if (4 * j + lg < nn) {
+                            if (lg < nn - 4 * j) {
 #pragma unroll
                                 for (int cc = 0; cc < 3; ++cc) {
-                                    const int q = 3 * j + cc, d = 3 * (4 * j + lg) + cc;
-                                    unsigned word = tsg[0];
-                                    word = (d >> 5) == 1 ? tsg[1] : word;
-                                    word = (d >> 5) == 2 ? tsg[2] : word;
-                                    const double a = acc[q / 4][q % 4];
-                                    const double o = ((word >> (d & 31)) & 1u) ? -a : a;                      // :280
+                                    const int q = 3 * j + cc;
+                                    const double o = flip_sign(acc[q / 4][q % 4], tsw, q);                    // :280
                                     __hip_atomic_fetch_add(&ys[tl3[j] + ((pw >> 2 * cc) & 3)], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
                                 }
                             }

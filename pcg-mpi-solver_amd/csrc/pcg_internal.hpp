@@ -139,6 +139,7 @@ constexpr int kChunkClasses = 6;                   // 0: exactly 8 nodes (hex8, 
 constexpr int kMixedClass = 5;
 constexpr int kMixedHexSlots = 512;                // hex8 element slots of a mixed chunk (two passes of 256 threads)
 constexpr int kMixedMaxTiles = 24;                 // 16-element tiles of the other pattern types per mixed chunk
+constexpr int kMixedFragAhead = 4;                 // k-steps whose matrix fragments k_ebe_mixed requests ahead of their instructions
 struct EbeClassHost {
     int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
     bool full = false;                 // every element of the class has exactly nnp nodes (no padding guards needed)
