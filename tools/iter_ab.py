@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
 import numpy as np
 import torch
+if os.environ.get("PCG_LIB"):               # A/B against another build of the engine (tools/build_variant.sh; development only)
+    from pcg_mi355x import _lib
+    _lib.use_library(os.environ["PCG_LIB"])
 from pcg_mi355x.brick import Brick, make_parts
 from pcg_mi355x.operator import from_refmeshpart
 Ns = [a if a.startswith("oct") else int(a) for a in sys.argv[1].split(",")]      # brick nodes per side, or oct1m / oct10m
