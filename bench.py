@@ -361,7 +361,7 @@ def pmc_child(args):
         if wl not in parts:
             if wl == "octree":
                 from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
-                parts[wl] = make_octree_parts(GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size], 4, band=1.2, seed=0), 1)[0]
+                parts[wl] = make_octree_parts(GradedOctreeMesh({"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size], 4, band=1.2, seed=0, symmetry=True), 1)[0]
             else:
                 parts[wl] = make_parts(Brick(args.nodes_per_side, seed=0))[0]
         part = parts[wl]
@@ -447,14 +447,17 @@ def pmc_traffic_live(args, segments):
 
 def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
     """BASELINE configs[1] names "a synthetic 3D elasticity octree mesh, 1M DOFs": the multi-level graded octree mesh of
-    pcg_mi355x.octree.GradedOctreeMesh (5 cell sizes, 2:1 balanced over faces / edges / corners, ~95 pattern types with 9-20
-    nodes besides hex8) on all three operators - iterations/s, operator time, what the formats make of it."""
+    pcg_mi355x.octree.GradedOctreeMesh (5 cell sizes, 2:1 balanced over faces / edges / corners; the hanging-node cells come in 95
+    orientations of 7 patterns with 9-20 nodes besides hex8) on all three operators - iterations/s, operator time, what the formats
+    make of it.  Pattern types as the reference's library holds them (round 4): ONE element matrix per class of the cube's symmetries,
+    the orientation of an element in the order of its dof list and in its sign vector (partition_mesh.py:453-455);
+    `matrix_free_type_per_orientation` = the same mesh with one type (own matrix) per orientation, the round-3 form."""
     import numpy as np
     from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
     t0 = time.perf_counter()
-    mesh = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0)
+    mesh = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0, symmetry=True)
     opart = make_octree_parts(mesh, 1)[0]
-    obj = {"workload": "multi-level 2:1-balanced octree mesh around a sphere (GradedOctreeMesh((12,12,12), levels=4, band=1.2)), Jacobi-PCG Tol 1e-7, 1 part",
+    obj = {"workload": "multi-level 2:1-balanced octree mesh around a sphere (GradedOctreeMesh((12,12,12), levels=4, band=1.2, symmetry=True)), Jacobi-PCG Tol 1e-7, 1 part",
            "mesh": mesh.summary(), "mesh_setup_s": time.perf_counter() - t0, "steps": 150, "warmup": 20}
     for kind in ("sell", "dict", "ebe"):
         mm = measure(kind, opart, steps=150, warmup=20, standalone_reps=30)
@@ -480,6 +483,15 @@ def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
         op.close()
         log(f"[octree {kind}] {e['value']:.0f} it/s, operator {e['operator_avg_ms']:.4f} ms, solve {e['solve']}")
     opart.pop("_pcg_mi355x_operator", None)
+    try:                         # the same elements, one pattern type per ORIENTATION (95 element matrices instead of 8)
+        opart95 = make_octree_parts(GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0), 1)[0]
+        mm = measure("ebe", opart95, steps=150, warmup=20, standalone_reps=30)
+        obj["matrix_free_type_per_orientation"] = {"value": 150 / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / 150 * 1e3,
+                                                   "operator_avg_ms": mm["op_ms"], "solve": mm["final"], "operator_info": mm["op"].operator_info()}
+        mm["op"].close()
+        del opart95
+    except Exception as ex:      # noqa: BLE001
+        log(f"octree (type per orientation) failed: {ex!r}")
     if with_cpu:                 # north_star: "next to the reference CPU pcg_solver.py timed on the node's own host cores in the same run"
         try:
             obj["cpu_baseline"] = cpu_baseline(opart, "octree:1m", cpu_ranks, "octree", quick=True)
@@ -488,7 +500,7 @@ def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
     # The value dictionary needs <= 65535 distinct 3x3 blocks.  The random two-phase material above (Ck in {1, 3} x cell size, per
     # element) makes 151 716 of them on this mesh - the plain format is used, `table.distinct_blocks` = 0 says so.  With ONE
     # material (Ck = cell size) the same mesh has 22 333: the dictionary applies, its head sits in LDS, the tail goes through L2.
-    mesh1 = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0, two_phase=False)
+    mesh1 = GradedOctreeMesh((12, 12, 12), 4, band=1.2, seed=0, two_phase=False, symmetry=True)
     upart = make_octree_parts(mesh1, 1)[0]
     mm = measure("dict", upart, steps=150, warmup=20, standalone_reps=30)
     obj["assembled_dictionary_single_material"] = {
@@ -584,13 +596,13 @@ def main():
     if args.workload == "octree":
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
         roots = {"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size]
-        brick = GradedOctreeMesh(roots, 4, band=1.2, seed=0)        # .n_dof like a Brick; nnz filled in after assembly
+        brick = GradedOctreeMesh(roots, 4, band=1.2, seed=0, symmetry=True)        # .n_dof like a Brick; nnz filled in after assembly
         grid = (world, 1, 1)
         part = make_octree_parts(brick, world, elem_part=bisect_elements(brick, world) if world > 1 else None)[rank]
         brick.nnz = None
         sm = brick.summary()
-        wl_name = (f"multi-level 2:1-balanced octree mesh around a sphere, {sm['levels']} cell sizes, {sm['pattern_types']} pattern types "
-                   f"(up to {sm['nodes_per_element_max']} nodes per element), {brick.n_dof} dof, parts by recursive bisection")
+        wl_name = (f"multi-level 2:1-balanced octree mesh around a sphere, {sm['levels']} cell sizes, {sm['pattern_types']} pattern types in "
+                   f"{sm['pattern_orientations']} orientations (up to {sm['nodes_per_element_max']} nodes per element), {brick.n_dof} dof, parts by recursive bisection")
     else:
         brick = Brick(N, seed=0)
         grid = default_grid(world)
@@ -781,8 +793,8 @@ def main():
                        "value": args.steps / e["elapsed"], "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3,
                        "operator_avg_ms": e["op_ms"], "operator_launches_timed": e["n_op"], "n_elem": oi["n_elem"], "n_chunks": oi["n_chunks"],
                        "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"], "vector_phase": e["vec"],
-                       "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (a single 8-node pattern type) or k_ebe_mixed (several pattern types: mixed-type chunks, "
-                                              "hex section + matrix-core tiles) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
+                       "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (a single 8-node pattern type) or k_ebe_mixed / k_ebe_mtile (several pattern types: mixed-type chunks, "
+                                              "hex section on the vector FMAs or - below 1.2 M elements - colour-pure hex tiles, + matrix-core tiles) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
                                     "flops_per_apply": ef, "achieved_TFLOPs": ef / t_op / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                                     "frac_flops": ef / t_op / 1e12 / F64_PEAK_TFLOPS,
                                     "bytes_per_apply": eb, "achieved_GBps": eb / t_op / 1e9, "peak_GBps": HBM_PEAK_GBS,

@@ -70,8 +70,20 @@ bool build_mixed_types(int32_t n_groups, const pcg_elem_group *gs, const std::ve
 {
     auto &M = C.mixed;
     int64_t best = 0;
+    // PCG_EBE_HEX_TILES: 1 = no hex section, the standard 8-node type runs on the matrix cores in colour-pure tiles (EbeMixedHost);
+    // 2 (development) = as ordinary tiles in run order; 0 = the hex section on the vector FMAs.
+    // Default (measured, sessions q / r): the hex tiles win where the chunks do not fill the GPU twice over - a chunk's life is then the
+    // latency of its chain of phases, and the hex section's chain (two passes, eight ordered turns of 2.3 k cycles) is the longer one
+    // (1 M-dof octree mesh, 661 chunks: 45 vs 50 us); with many chunks in flight per CU the vector FMAs and the matrix cores working
+    // side by side win (10 M dof: 259 vs 272 us).
+    const char *hv = std::getenv("PCG_EBE_HEX_TILES");
+    int64_t chunkable_elems = 0;
+    for (int g = 0; g < n_groups; ++g) if (chunkable[g]) chunkable_elems += gs[g].ne;
+    const int hex_tiles = hv ? std::atoi(hv) : (chunkable_elems < kMixedHexTilesBelow ? 1 : 0);
     for (int g = 0; g < n_groups; ++g)                   // (chunkable == 2: per-element dof order - a tile type, never the hex section)
         if (chunkable[g] == 1 && gs[g].nd == 24 && gs[g].ne > best) { best = gs[g].ne; M.hex_group = g; }
+    int first_group = -1;
+    if (hex_tiles && M.hex_group >= 0) { first_group = M.hex_group; M.hex_group = -1; if (hex_tiles == 1) M.hex_tile_type = 0; }
     auto &K = C.cls[kMixedClass];
     K.ke_col.assign(24 * 24, 0.0);
     if (M.hex_group >= 0)
@@ -79,7 +91,10 @@ bool build_mixed_types(int32_t n_groups, const pcg_elem_group *gs, const std::ve
             for (int a = 0; a < 24; ++a) K.ke_col[(size_t)b * 24 + a] = gs[M.hex_group].ke[(size_t)a * 24 + b];
     bool any = M.hex_group >= 0;
     int max_nn = 4, max_nd = 1;
-    for (int g = 0; g < n_groups; ++g) {
+    std::vector<int> g_order;                            // (the hex tile type is types[0])
+    if (first_group >= 0) g_order.push_back(first_group);
+    for (int g = 0; g < n_groups; ++g) if (g != first_group) g_order.push_back(g);
+    for (int g : g_order) {
         if (!chunkable[g] || g == M.hex_group || gs[g].ne == 0) continue;
         EbeMixedType T;
         T.group = g; T.nd = gs[g].nd; T.nn = gs[g].nd / 3; T.J = (T.nn + 3) / 4;
@@ -500,11 +515,43 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             M.hex_elems += nh;
             // tiles: 16 elements of one type, in run order; tile-local colours (the 16 elements add in ONE wave instruction per colour)
             const int W = M.words, NP = M.nnpt;
+            // hex tiles: the chunk's elements of the standard 8-node type coloured over the chunk, sorted by colour, one colour per tile
+            // (padding at the end of a colour: by_type entry SIZE_MAX)
+            std::vector<int32_t> wait_of_tile;               // per tile of this chunk: completed tiles its adds wait for
+            int n_hex_tiles = 0;
+            if (M.hex_tile_type >= 0 && !by_type[M.hex_tile_type].empty()) {
+                auto &E = by_type[M.hex_tile_type];
+                const int ne_h = (int)E.size();
+                used.assign(nn, 0);
+                std::vector<int> col(ne_h, 0);
+                int ncol_h = 0;
+                for (int t = 0; t < ne_h; ++t) {
+                    uint64_t forb = 1ull << 63;
+                    for (int l = 0; l < 8; ++l) forb |= used[lid_of(L[E[t]], l)];
+                    if (~forb == 0) throw std::runtime_error("ebe: more than 63 elements of the 8-node type at one node");
+                    const int c = __builtin_ctzll(~forb);
+                    for (int l = 0; l < 8; ++l) used[lid_of(L[E[t]], l)] |= 1ull << c;
+                    col[t] = c;
+                    ncol_h = std::max(ncol_h, c + 1);
+                }
+                std::vector<size_t> sorted;
+                for (int c = 0; c < ncol_h; ++c) {
+                    const int first = (int)sorted.size() / 16;
+                    for (int t = 0; t < ne_h; ++t) if (col[t] == c) sorted.push_back(E[t]);
+                    while (sorted.size() % 16) sorted.push_back(SIZE_MAX);
+                    for (int k = first; k < (int)sorted.size() / 16; ++k) wait_of_tile.push_back(first);
+                }
+                E.swap(sorted);
+                n_hex_tiles = (int)E.size() / 16;
+            }
+            if (M.hex_tile_type >= 0) M.chunk_hex_tiles.push_back(n_hex_tiles);
             for (size_t t = 0; t < by_type.size(); ++t) {
                 const auto &T = M.types[t];
                 const auto &in = gs[T.group];
+                const bool pure = (int)t == M.hex_tile_type;
                 for (size_t b0 = 0; b0 < by_type[t].size(); b0 += 16) {
                     const int cnt = (int)std::min<size_t>(16, by_type[t].size() - b0);
+                    if (!pure) wait_of_tile.push_back((int32_t)wait_of_tile.size());
                     const size_t ti = (size_t)M.n_tiles++;
                     M.tile_type.push_back((int32_t)t);
                     M.tlid.resize((ti + 1) * NP * 16, 0);
@@ -515,6 +562,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                     int ncol = 0;
                     std::vector<std::pair<int, uint32_t>> seen;       // (local slot, colour mask) of the nodes this tile has touched
                     for (int e = 0; e < cnt; ++e) {
+                        if (by_type[t][b0 + e] == SIZE_MAX) continue;   // padding slot of a colour-pure tile
                         const ElemRef &r = L[by_type[t][b0 + e]];
                         uint32_t forb = 0;
                         for (int l = 0; l < T.nn; ++l) {
@@ -522,7 +570,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                             M.tlid[(ti * NP + l) * 16 + e] = (uint16_t)li;
                             for (const auto &sn : seen) if (sn.first == li) forb |= sn.second;
                         }
-                        const int c = __builtin_ctz(~forb);            // at most 16 elements: a colour below 16 is always free
+                        const int c = pure ? 0 : __builtin_ctz(~forb); // at most 16 elements: a colour below 16 is always free
                         for (int l = 0; l < T.nn; ++l) {
                             const int li = lid_of(r, l);
                             bool found = false;
@@ -537,9 +585,10 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                             if (in.sign[(int64_t)a * in.ne + r.e]) M.tsgn[(ti * W + a / 32) * 16 + e] |= 1u << (a % 32);
                     }
                     M.tile_ncol.push_back(ncol);
-                    M.tile_elems += cnt;
+                    for (int e = 0; e < cnt; ++e) M.tile_elems += by_type[t][b0 + e] != SIZE_MAX;
                 }
             }
+            M.tile_wait.insert(M.tile_wait.end(), wait_of_tile.begin(), wait_of_tile.end());
             C.hdr.insert(C.hdr.end(), {(int32_t)C.nodes.size(), nn, nsub, nh, kci, (int32_t)(M.n_tiles - tile0), kMixedClass, tile0});
             {
                 std::vector<int32_t> by_id(nn);
@@ -578,7 +627,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         bool prev_hex = !L.empty() && L[0].g == M.hex_group;
         for (size_t k = 0; k < L.size(); ++k) {
             const auto &in = gs[L[k].g];
-            const bool is_hex = L[k].g == M.hex_group;
+            const bool is_hex = L[k].g == M.hex_group || (M.hex_tile_type >= 0 && type_of[L[k].g] == M.hex_tile_type);   // (counted against the hex slots)
             const int t = is_hex ? -1 : type_of[L[k].g];
             auto stamp_new = [&](int32_t id, bool mark) {            // nodes of element k the run `id` does not hold yet
                 int fresh = 0;

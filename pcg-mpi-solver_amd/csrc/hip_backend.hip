@@ -565,6 +565,25 @@ public:
                             tsgw[((size_t)t * 4 + l % 4) * 16 + e] |= 1u << (3 * (l / 4) + c);
                     }
         }
+        // k_ebe_mtile (EbeMixedHost::hex_tile_type): per lane of a hex tile the two slots and the six sign bits it handles; per tile its wait count
+        mix_hex_tiles_ = M.hex_tile_type >= 0;
+        std::vector<uint2> hrec;
+        if (mix_hex_tiles_) {
+            hrec.assign((size_t)std::max<int64_t>(1, M.n_tiles) * 64, make_uint2(0u, 0u));
+            for (int64_t t = 0; t < M.n_tiles; ++t) {
+                if (M.tile_type[t] != M.hex_tile_type) continue;
+                for (int e = 0; e < 16; ++e) {
+                    if (M.tcol[(size_t)t * 16 + e] == 255) continue;
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 r;
+                        r.x = (unsigned)M.tlid[((size_t)t * M.nnpt + g) * 16 + e] | (unsigned)M.tlid[((size_t)t * M.nnpt + g + 4) * 16 + e] << 16;
+                        r.y = tsgw[((size_t)t * 4 + g) * 16 + e] | 0x80000000u;
+                        hrec[(size_t)t * 64 + g * 16 + e] = r;
+                    }
+                }
+            }
+        }
+        const void *d_hrec = mix_hex_tiles_ ? up(hrec) : nullptr, *d_twait = mix_hex_tiles_ ? up(M.tile_wait) : nullptr;
         const void *d_tinfo = up(tinfo), *d_tlid = up(M.tlid), *d_tck = up(M.tck), *d_tsgw = up(tsgw), *d_tcol = up(M.tcol), *d_tperm = up(M.tperm), *d_frag = up(M.frag);
         mix_mtm_ = std::max(2, M.max_mt);
         if (const char *e = getenv("PCG_EBE_MIX_MTM")) mix_mtm_ = std::max(mix_mtm_, std::min(6, atoi(e)));   // development: a larger instantiation (>= 5: 168 VGPRs, 3 workgroups per CU)
@@ -580,7 +599,7 @@ public:
                 const int32_t off = h[0], nn = h[1], nh = h[3], kci = h[4];
                 int any_sign = 0;
                 for (int e = 0; e < nh; ++e) any_sign |= (K.sgn[(size_t)kci * CE + e] & 0x00ffffffu) != 0;
-                hdr[8 * b] = nn; hdr[8 * b + 1] = h[2]; hdr[8 * b + 2] = nh; hdr[8 * b + 3] = any_sign;
+                hdr[8 * b] = nn; hdr[8 * b + 1] = h[2]; hdr[8 * b + 2] = mix_hex_tiles_ ? M.chunk_hex_tiles[kci] : nh; hdr[8 * b + 3] = any_sign;
                 hdr[8 * b + 4] = h[5]; hdr[8 * b + 5] = h[7];
                 for (int k = 0; k < nn; ++k) {
                     nodes[b * MAXN + k] = C.nodes[off + k]; dst[b * MAXN + k] = C.dst[off + k]; tslot[b * MAXN + k] = C.tslot[off + k];
@@ -595,6 +614,7 @@ public:
             T.sgn = (const unsigned *)up(sgn);
             T.tinfo = (const int2 *)d_tinfo; T.tlid = (const unsigned short *)d_tlid; T.tck = (const double *)d_tck;
             T.tsgw = (const unsigned *)d_tsgw; T.tcol = (const unsigned char *)d_tcol; T.tperm = (const unsigned char *)d_tperm; T.frag = (const double *)d_frag;
+            T.hrec = (const uint2 *)d_hrec; T.twait = (const int *)d_twait;
             T.np = M.nnpt; T.xcd = ebe_xcd_;
             T.flags = 0;
             if (const char *e = getenv("PCG_EBE_MIX_FLAGS")) T.flags = atoi(e);      // bit 0: barriers instead of tickets; 16 / 32 / 64: ablations (development)
@@ -606,6 +626,14 @@ public:
     template <int MTM>
     void launch_mixed(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
+        if (mix_hex_tiles_) {                                     // every element on the matrix cores (k_ebe_mtile)
+            auto gom = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], x, y, d_ch_buf_, part, dot_lo); };
+            if constexpr (MTM == 4) {
+                if (dot && stamp_launch_ >= 0 && count >= 64 && ++stamp_launch_ == 40) { launch_mtile_stamped(ph, count, x, y, part, dot_lo); return; }
+            }
+            if (dot) gom(k_ebe_mtile<MTM, true>); else gom(k_ebe_mtile<MTM, false>);
+            return;
+        }
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], ke, x, y, d_ch_buf_, part, dot_lo); };
         if constexpr (MTM == 4) {
             if (dot && stamp_launch_ >= 0 && count >= 64 && ++stamp_launch_ == 40) { launch_mixed_stamped(ph, count, ke, x, y, part, dot_lo); return; }
@@ -615,6 +643,37 @@ public:
     // Development (PCG_EBE_STAMPS=1): the 40th fused-dot launch of the mixed kernel runs the STAMP instantiation - every wave writes the
     // shader clock at its phase boundaries - and the means over the waves go to stderr (cycles).  Same results, one slower launch.
     int stamp_launch_ = getenv("PCG_EBE_STAMPS") && atoi(getenv("PCG_EBE_STAMPS")) ? 0 : -1;
+    bool mix_hex_tiles_ = false;
+    void launch_mtile_stamped(int ph, int count, const double *x, double *y, double *part, long long dot_lo)
+    {
+        const size_t nw = (size_t)count * kWavesPerBlock;
+        unsigned long long *d = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d, nw * 16 * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemsetAsync(d, 0, nw * 16 * sizeof(unsigned long long), ls_));
+        MixTab T = mix_tab_[ph];
+        T.stamps = d;
+        hipLaunchKernelGGL((k_ebe_mtile<4, true, true>), dim3(count), dim3(kChunkThreads), 0, ls_, T, x, y, d_ch_buf_, part, dot_lo);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ls_));
+        std::vector<unsigned long long> h(nw * 16);
+        HIP_CHECK(hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        // stamps 0, 1, 8, 9, 10, 11 = entry, staged, hex tiles done, other tiles done, final barrier passed, exit; 2..5 / 12..15 = per-tile sums
+        double ph_sum[5] = {0}, life = 0, hs[4] = {0}, gs[4] = {0};
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned long long *s = &h[w * 16];
+            const int idx[6] = {0, 1, 8, 9, 10, 11};
+            for (int k = 1; k < 6; ++k) ph_sum[k - 1] += (double)(s[idx[k]] - s[idx[k - 1]]);
+            life += (double)(s[11] - s[0]);
+            for (int k = 0; k < 4; ++k) { hs[k] += (double)s[2 + k]; gs[k] += (double)s[12 + k]; }
+        }
+        fprintf(stderr, "[pcg] k_ebe_mtile stamps, phase %d: %d workgroups, mean wave lifetime %.0f cycles: stage %.0f, hex tiles %.0f, other tiles %.0f, final barrier %.0f, "
+                        "write-out + dot %.0f\n", ph, count, life / nw, ph_sum[0] / nw, ph_sum[1] / nw, ph_sum[2] / nw, ph_sum[3] / nw, ph_sum[4] / nw);
+        if (hs[0] > 0) fprintf(stderr, "[pcg]   hex tiles: %.2f per wave; per tile: %.0f to the end of the contraction, %.0f waiting for its colour, %.0f adds\n", hs[0] / nw,
+                               hs[1] / hs[0], hs[2] / hs[0], hs[3] / hs[0]);
+        if (gs[0] > 0) fprintf(stderr, "[pcg]   other tiles: %.2f per wave; per tile: %.0f to the end of the contraction, %.0f waiting for its turn, %.0f adds\n", gs[0] / nw,
+                               gs[1] / gs[0], gs[2] / gs[0], gs[3] / gs[0]);
+    }
     void launch_mixed_stamped(int ph, int count, const double *ke, const double *x, double *y, double *part, long long dot_lo)
     {
         const size_t nw = (size_t)count * kWavesPerBlock;

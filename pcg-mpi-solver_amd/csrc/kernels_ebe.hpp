@@ -658,6 +658,9 @@ struct MixTab {
     int np, xcd;
     int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
                                   // bits 4..6: development ablations (wrong results)
+    const uint2 *hrec;            // k_ebe_mtile, hex tiles: [tiles][64] per lane (g, e): x = slot of node g | slot of node g + 4 << 16 in the LDS tile,
+                                  //            y = sign bits of the lane's six dofs (bit 3 j + c), bit 31 = the element exists
+    const int *twait;             // k_ebe_mtile: [tiles] completed tiles of the chunk this tile's adds wait for
     unsigned long long *stamps;   // STAMP instantiation only (PCG_EBE_STAMPS=1, development): [workgroup][wave][16] shader-clock readings
 };
 
@@ -932,6 +935,222 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
     if constexpr (STAMP) {
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 12 + k] = tile_acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mixed-type chunks, every element on the matrix cores (round 4; EbeMixedHost::hex_tile_type): k_ebe_mtile.
+// The hex section of k_ebe_mixed feeds its FMAs with scalar loads of Ke, and a dependent s_load_dwordx16 costs 157 - 214 cycles
+// (tools/micro/smem_latency): a wave's pass of 576 FMAs (2.3 k cycles of issue) takes 11 - 12 k, and the ordered LDS sums of the eight
+// (pass, wave) turns of a chunk, 2.3 k cycles each, are the chunk's critical path (clock stamps, profiles/r04_stamps_*).  Here the
+// standard 8-node type runs in 16-element tiles like every other type:
+//   * Ke as TWELVE matrix fragments held in registers for the whole workgroup (J = 2 node quartets: 6 k-steps x 2 M-tiles), no scalar
+//     loads in the contraction; a tile is 12 v_mfma_f64_16x16x4_f64 = 768 cycles of the matrix pipe;
+//   * the tiles are COLOUR-PURE (planner): the 16 elements of a tile share no node - six ds_add_f64 per tile, all lanes - and the
+//     tiles of one colour need no order among themselves: a tile adds once the tiles of all colours before its own have completed
+//     (`twait`), and counts itself in.  One fixed order of additions per node (colour after colour, then the other types' tiles in
+//     ascending order): bit-reproducible;
+//   * lane (g, e) of a tile handles the nodes g and g + 4 of element e: one 8-byte record (two slots of the x / y tile, six sign
+//     bits), Ck, six LDS reads, six products, six adds.  The next tile's record is requested a tile ahead.
+// The other types' tiles follow as in k_ebe_mixed (fragments streamed through the register ring).
+// ------------------------------------------------------------------------------------------------
+template <int MTM, bool DOT, bool STAMP = false>
+__global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile(MixTab T, const double *__restrict__ x, double *__restrict__ y,
+                                                                                   double *__restrict__ buf, double *__restrict__ partials,
+                                                                                   long long dot_lo)
+{
+    constexpr int NPT = 3, MAXN = kChunkThreads * NPT, JM = (4 * MTM) / 3;
+    __shared__ double xs[3 * MAXN];
+    __shared__ double ys[3 * MAXN];
+    __shared__ int turn;                                         // tiles of this chunk that have completed their adds
+    const int b = xcd_chunk(blockIdx.x, gridDim.x, T.xcd), wave = threadIdx.x >> 6;
+    unsigned long long tile_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + k] = t;
+        }
+    };
+    stamp(0);
+    const int4 h = T.hdr[2 * b], h2 = T.hdr[2 * b + 1];
+    if (threadIdx.x == 0) turn = 0;
+    const int lane = threadIdx.x & 63, lg = lane >> 4, le = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int n_hex_tiles = h.z, n_tiles = h2.x;                 // (block-uniform) hex tiles first, then the other types' tiles
+    const size_t tile0 = (size_t)h2.y;
+    // this wave's first hex tile and the matrix of the 8-node type: requested with the chunk's node tables
+    uint2 rec_next = make_uint2(0u, 0u);
+    double ck_next = 0.0;
+    if (wave_u < n_hex_tiles) {
+        rec_next = T.hrec[(tile0 + wave_u) * 64 + lane];
+        ck_next = T.tck[(tile0 + wave_u) * 16 + le];
+    }
+    double A[12];                                                // fragments (k-step ks, M-tile mt) of types[0]: frag[(ks * 2 + mt) * 64 + lane]
+    int dst[NPT], ts[NPT];
+    {
+        int g[NPT];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
+            g[j] = ntload(T.nodes + n);
+            dst[j] = ntload(T.dst + n);
+            ts[j] = (int)__builtin_nontemporal_load(T.tslot + n);
+        }
+        double xg[NPT][3];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {                          // (x of a padding entry: node 0, never stored)
+            const double *xp = x + 3 * (size_t)(g[j] >= 0 ? g[j] : 0);
+            xg[j][0] = xp[0]; xg[j][1] = xp[1]; xg[j][2] = xp[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) A[i] = n_hex_tiles > 0 ? T.frag[(size_t)i * 64 + lane] : 0.0;   // (requested BEHIND the gather: they return in order)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (g[j] >= 0) {
+                const int sl3 = 3 * (ts[j] & 0x3ff);
+                xs[sl3] = xg[j][0]; xs[sl3 + 1] = xg[j][1]; xs[sl3 + 2] = xg[j][2];
+                ys[sl3] = 0.0; ys[sl3 + 1] = 0.0; ys[sl3 + 2] = 0.0;
+            }
+    }
+    __syncthreads();
+    stamp(1);
+    auto wait_done = [&](int count) {                            // until `count` tiles of the chunk have completed
+        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(1);
+    };
+    auto count_in = [&]() {                                      // (the LDS unit serves one wave's operations in issue order: after its adds)
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&turn, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // ---- hex tiles: wave w takes the tiles w, w + 4, ... -----------------------------------------------------------------------
+    // (Deferring a tile's adds behind the next tile's matrix instructions was measured and lost, session r: a wave issues in order, its
+    //  twelve matrix instructions hold it for their 768 cycles of the pipe, and with four waves per SIMD in this phase the pipe is busy.)
+    for (int t = wave_u; t < n_hex_tiles; t += kWavesPerBlock) { // wave-uniform
+        unsigned long long tt0 = 0, tt1 = 0, tt2 = 0;
+        if constexpr (STAMP) tt0 = __builtin_amdgcn_s_memtime();
+        const uint2 rec = rec_next;
+        const double c = ck_next;
+        const int wait_for = T.twait[tile0 + t];                 // (scalar load)
+        if (t + kWavesPerBlock < n_hex_tiles) {
+            rec_next = T.hrec[(tile0 + t + kWavesPerBlock) * 64 + lane];
+            ck_next = T.tck[(tile0 + t + kWavesPerBlock) * 16 + le];
+        }
+        const int l0 = 3 * (int)(rec.x & 0xffffu), l1 = 3 * (int)(rec.x >> 16);
+        const unsigned sw = rec.y;
+        const double xv[6] = {xs[l0], xs[l0 + 1], xs[l0 + 2], xs[l1], xs[l1 + 1], xs[l1 + 2]};              // :277 gather
+        d4m_t acc0 = d4m_t{0.0, 0.0, 0.0, 0.0}, acc1 = d4m_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const double u = c * flip_sign(xv[ks], sw, ks);                                                 // :278-279 sign, Ck * U
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * ks], u, acc0, 0, 0, 0);                       // :279 Ke @ (.)
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * ks + 1], u, acc1, 0, 0, 0);
+        }
+        const double o[6] = {acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1]};                          // accumulator q = 3 j + c
+        if constexpr (STAMP) tt1 = __builtin_amdgcn_s_memtime();
+        wait_done(wait_for);
+        if constexpr (STAMP) tt2 = __builtin_amdgcn_s_memtime();
+        if (sw >> 31) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)                                                                      // :280, :300 (added by the LDS unit)
+                __hip_atomic_fetch_add(&ys[(q < 3 ? l0 : l1) + q % 3], flip_sign(o[q], sw, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        count_in();
+        if constexpr (STAMP) {
+            tile_acc[0] += 1; tile_acc[1] += tt1 - tt0; tile_acc[2] += tt2 - tt1; tile_acc[3] += __builtin_amdgcn_s_memtime() - tt2;
+        }
+    }
+    stamp(8);
+    // ---- the other types' tiles: four at a time (one per wave), added in ascending order (k_ebe_mixed) --------------------------------
+    int2 info_next = n_hex_tiles + wave_u < n_tiles ? T.tinfo[tile0 + n_hex_tiles + wave_u] : make_int2(0, 0);
+    for (int t0 = n_hex_tiles; t0 < n_tiles; t0 += kWavesPerBlock) { // block-uniform
+        unsigned long long tt0 = 0, tt1 = 0, tt2 = 0;
+        if constexpr (STAMP) tt0 = __builtin_amdgcn_s_memtime();
+        const int ti = t0 + wave_u;
+        const bool have = ti < n_tiles;                          // wave-uniform
+        const int2 info = info_next;                             // this tile's header was requested a round ago:
+        if (ti + kWavesPerBlock < n_tiles) info_next = T.tinfo[tile0 + ti + kWavesPerBlock];   // header -> fragments is the dependent chain
+        d4m_t acc[MTM];
+        int tl3[JM];
+        unsigned tsw = 0u;
+        int pw = 0 | 1 << 2 | 2 << 4;
+        int nn = 0, ncol = 0, mycol = 255;
+#pragma unroll
+        for (int mt = 0; mt < MTM; ++mt) acc[mt] = d4m_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < JM; ++j) tl3[j] = 0;
+        if (have) {
+            const size_t tg = tile0 + ti;
+            nn = __builtin_amdgcn_readfirstlane(info.x & 255);
+            const int J = __builtin_amdgcn_readfirstlane((info.x >> 8) & 255);
+            ncol = __builtin_amdgcn_readfirstlane(info.x >> 16);
+            const double *F = T.frag + (size_t)__builtin_amdgcn_readfirstlane(info.y) * 64 + lane;
+            const double tc = T.tck[tg * 16 + le];
+            mycol = (int)T.tcol[tg * 16 + le];
+            pw = (int)T.tperm[tg * 16 + le];
+            tsw = T.tsgw[(tg * 4 + lg) * 16 + le];
+#pragma unroll
+            for (int j = 0; j < JM; ++j)
+                if (j < J) tl3[j] = 3 * (int)T.tlid[(tg * T.np + 4 * j + lg) * 16 + le];
+            switch (J) {                                          // wave-uniform: straight-line code per size
+            case 1: mixed_tile_contract<1, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 2: if constexpr (JM >= 2) mixed_tile_contract<2, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 3: if constexpr (JM >= 3) mixed_tile_contract<3, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 4: if constexpr (JM >= 4) mixed_tile_contract<4, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 5: if constexpr (JM >= 5) mixed_tile_contract<5, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 6: if constexpr (JM >= 6) mixed_tile_contract<6, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 7: if constexpr (JM >= 7) mixed_tile_contract<7, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            case 8: if constexpr (JM >= 8) mixed_tile_contract<8, MTM>(F, xs, tl3, tc, tsw, pw, lg, nn, acc); break;
+            default: break;
+            }
+            if constexpr (STAMP) tt1 = __builtin_amdgcn_s_memtime();
+            wait_done(ti);                                       // every tile before this one has added
+            if constexpr (STAMP) tt2 = __builtin_amdgcn_s_memtime();
+            for (int s = 0; s < ncol; ++s)
+                if (mycol == s) {
+#pragma unroll
+                    for (int j = 0; j < JM; ++j)
+                        if (lg < nn - 4 * j) {
+#pragma unroll
+                            for (int cc = 0; cc < 3; ++cc) {
+                                const int q = 3 * j + cc;
+                                const double o = flip_sign(acc[q / 4][q % 4], tsw, q);                        // :280
+                                __hip_atomic_fetch_add(&ys[tl3[j] + ((pw >> 2 * cc) & 3)], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :300
+                            }
+                        }
+                }
+            count_in();
+            if constexpr (STAMP) {
+                tile_acc[4] += 1; tile_acc[5] += tt1 - tt0; tile_acc[6] += tt2 - tt1; tile_acc[7] += __builtin_amdgcn_s_memtime() - tt2;
+            }
+        }
+    }
+    stamp(9);
+    __syncthreads();                                             // every add is in before the tile is written out
+    stamp(10);
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (dst[j] != INT_MIN) {
+            const int sl3 = 3 * (ts[j] & 0x3ff), wmask = ts[j] >> 12;
+            double *out = dst[j] >= 0 ? y + dst[j] : buf + 3 * (size_t)(-dst[j] - 1);
+            const double y0 = ys[sl3], y1 = ys[sl3 + 1], y2 = ys[sl3 + 2];
+            out[0] = y0; out[1] = y1; out[2] = y2;
+            if (DOT && dst[j] >= 0 && dst[j] >= dot_lo) {        // fused p.Ap.w (:487) on the dofs this chunk finalises
+                if (wmask & 1) dot += xs[sl3] * y0;
+                if (wmask & 2) dot += xs[sl3 + 1] * y1;
+                if (wmask & 4) dot += xs[sl3 + 2] * y2;
+            }
+        }
+    if constexpr (DOT) {
+        __shared__ double lds[kWavesPerBlock];
+        double v[1] = {dot};
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    }
+    stamp(11);
+    if constexpr (STAMP) {
+        if ((threadIdx.x & 63) == 0) {
+            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 12 + k] = tile_acc[4 + k];
+            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 2 + k] = tile_acc[k];
+        }
     }
 }
 

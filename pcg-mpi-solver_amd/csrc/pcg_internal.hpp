@@ -138,6 +138,7 @@ constexpr int kChunkClasses = 6;                   // 0: exactly 8 nodes (hex8, 
                                                    // 4: fewer than 8 nodes (padded to 8); 5: mixed-type chunks (EbeMixedHost)
 constexpr int kMixedClass = 5;
 constexpr int kMixedHexSlots = 512;                // hex8 element slots of a mixed chunk (two passes of 256 threads)
+constexpr int64_t kMixedHexTilesBelow = 1200000;   // mixed chunks: below this many elements the 8-node type runs in matrix-core tiles too (ebe.cpp)
 constexpr int kMixedMaxTiles = 24;                 // 16-element tiles of the other pattern types per mixed chunk
 constexpr int kMixedFragAhead = 4;                 // k-steps whose matrix fragments k_ebe_mixed requests ahead of their instructions
 struct EbeClassHost {
@@ -191,6 +192,14 @@ struct EbeMixedHost {
     std::vector<uint8_t> tperm;        // (n_tiles, 16) dof order of the element: slot 3 l + c of its type is component (tperm >> 2 c) & 3
                                        //               of local node l (0 | 1 << 2 | 2 << 4 = x, y, z order; ebe.cpp node_blocked kind 2)
     int64_t hex_elems = 0, tile_elems = 0;
+    // Hex tiles (round 4, PCG_EBE_HEX_TILES): the standard 8-node type runs on the matrix cores as well - types[hex_tile_type] (= 0),
+    // no hex section.  A chunk's hex tiles come first and are COLOUR-PURE: the chunk's elements of the type are coloured (no two of
+    // a colour share a node), sorted by colour and cut into tiles colour by colour, so the 16 elements of a tile add in one
+    // instruction per dof and the tiles of one colour need no order among themselves: tile t may add once `tile_wait[t]` tiles of
+    // its chunk have completed (= the tiles of all colours before its own; the tiles after the hex tiles wait for all before them).
+    int32_t hex_tile_type = -1;
+    std::vector<int32_t> chunk_hex_tiles;   // (mixed chunks) hex tiles of the chunk
+    std::vector<int32_t> tile_wait;         // (n_tiles) completed tiles of the chunk this tile's adds wait for
 };
 
 struct EbeChunkedHost {

@@ -668,8 +668,9 @@ def test_graded_octree_1m_dof_oriented_patterns(gpu_lib, oracle_c, kind):
 
 
 def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
-    """Round 4, k_ebe_mixed: chunks that hold the elements of every pattern type of a run of the Morton order (hex section on the
-    vector FMAs, 16-element tiles of the other types on the f64 matrix cores, node sums in LDS) against the oracle's mat-vec
+    """Round 4, k_ebe_mixed / k_ebe_mtile: chunks that hold the elements of every pattern type of a run of the Morton order (hex section
+    on the vector FMAs or colour-pure hex tiles on the matrix cores, 16-element tiles of the other types on the f64 matrix cores, node
+    sums in LDS) against the oracle's mat-vec
     (<= 1e-13) and the per-type kernels of round 3 (PCG_EBE_MIXED=0), the fused p.Ap, bit-reproducible from launch to launch,
     and a whole solve - on bricks with three sign-framed hex8 types, graded / two-level octree meshes, one and two passes."""
     from pcg_mi355x._lib import check
@@ -680,8 +681,11 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
         monkeypatch.setenv("PCG_EBE_MIX_FLAGS", flags)
         for name, P in mixed_chunk_cases():
             ys = {}
-            for mixed in ("1", "0"):
-                monkeypatch.setenv("PCG_EBE_MIXED", mixed)
+            for mixed in ("1", "1t", "0"):                        # hex section (k_ebe_mixed) / hex tiles (k_ebe_mtile) / per-type chunks
+                if mixed == "1t" and flags == "1":
+                    continue
+                monkeypatch.setenv("PCG_EBE_MIXED", mixed[0])
+                monkeypatch.setenv("PCG_EBE_HEX_TILES", "1" if mixed == "1t" else "0")
                 op = from_refmeshpart(copy.deepcopy(P), kind="ebe")
                 x = np.random.default_rng(5).standard_normal(op.n)
                 xe = op.to_engine(x)
@@ -695,10 +699,11 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
                 w = np.zeros(op.n); w[P["LocDofEff"]] = 1.0
                 assert abs(pxy.value - np.dot(x, ref * w)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref)), (name, mixed)
                 op.close()
-            assert relerr(ys["1"], ys["0"]) < 1e-13
+            assert relerr(ys["1"], ys["0"]) < 1e-13 and ("1t" not in ys or relerr(ys["1t"], ys["0"]) < 1e-13)
     monkeypatch.setenv("PCG_EBE_MIXED", "1")
     monkeypatch.delenv("PCG_EBE_EPT")
     monkeypatch.delenv("PCG_EBE_MIX_FLAGS")
+    monkeypatch.delenv("PCG_EBE_HEX_TILES")
     P = dict(mixed_chunk_cases())["graded_octree"]
     R = copy.deepcopy(P)
     pm.configure(comm=None, device=0, operator="ebe")
@@ -711,13 +716,16 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
     assert relerr(P["Un"], R["Un"]) < 1e-8
 
 
-@pytest.mark.parametrize("kind", ["sell", "ebe"])
+@pytest.mark.parametrize("kind", ["sell", "ebe", "ebe_sym"])
 def test_graded_octree_10m_dof(gpu_lib, oracle_c, kind):
     """Round-3 verdict: the 10 M-dof octree mesh bench.py publishes numbers for (GradedOctreeMesh((38, 38, 38), 4): 9 893 991 dof,
     2.67 M elements, 95 pattern types) on the GPU against the oracle: the mat-vec of the assembled operator (split SELL format: base +
     overflow launch at this size) and of the matrix-free operator (mixed-type chunks) <= 1e-13 vs pcg_oracle.matvec_local(use_c=True),
-    a rigid rotation in the null space, and after the solve the TRUE residual b - A x recomputed by the oracle <= Tol."""
-    G = _graded_10m()
+    a rigid rotation in the null space, and after the solve the TRUE residual b - A x recomputed by the oracle <= Tol.
+    "ebe_sym" (round 4): the same mesh with ONE pattern type per symmetry class (8 element matrices, every hanging-node element with its
+    own dof order and sign vector - what bench.py measures since round 4), matrix-free."""
+    G = _graded_10m(symmetry=kind == "ebe_sym")
+    kind = kind.split("_")[0]
     mesh, P0 = G["mesh"], G["P"]
     assert mesh.n_dof == 9_893_991
     P = dict(P0)
@@ -748,14 +756,15 @@ def test_graded_octree_10m_dof(gpu_lib, oracle_c, kind):
 _GRADED10 = {}
 
 
-def _graded_10m():
-    if not _GRADED10:
+def _graded_10m(symmetry=False):
+    if symmetry not in _GRADED10:
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
-        mesh = GradedOctreeMesh((38, 38, 38), 4, band=1.2)
+        _GRADED10.clear()                                      # (one 10 M-dof mesh at a time)
+        mesh = GradedOctreeMesh((38, 38, 38), 4, band=1.2, symmetry=symmetry)
         P = make_octree_parts(mesh, 1)[0]
         x = np.random.default_rng(4).standard_normal(mesh.n_dof)
-        _GRADED10.update(mesh=mesh, P=P, x=x, ax=pcg_oracle.matvec_local(P, x, use_c=True))
-    return _GRADED10
+        _GRADED10[symmetry] = dict(mesh=mesh, P=P, x=x, ax=pcg_oracle.matvec_local(P, x, use_c=True))
+    return _GRADED10[symmetry]
 
 
 @pytest.mark.gpu
