@@ -382,7 +382,7 @@ def pmc_child(args):
 
 
 PMC_OPERATOR_KERNELS = {"sell": ("k_spmv",), "dict": ("k_spmv_dict",), "ebe": ("k_ebe",)}      # substrings of the kernels of one operator apply
-PMC_PRIMARY = {"sell": ("k_spmv<", "k_spmv_win<"), "dict": ("k_spmv_dict<",), "ebe": ("k_ebe_hexs<", "k_ebe_hex<", "k_ebe_mixed<")}   # one launch per apply
+PMC_PRIMARY = {"sell": ("k_spmv<", "k_spmv_win<"), "dict": ("k_spmv_dict<",), "ebe": ("k_ebe_hexs<", "k_ebe_hex<", "k_ebe_mixed<", "k_ebe_mtile<")}   # one launch per apply
 
 
 def pmc_traffic_live(args, segments):
