@@ -80,10 +80,15 @@ bool build_mixed_types(int32_t n_groups, const pcg_elem_group *gs, const std::ve
     int64_t chunkable_elems = 0;
     for (int g = 0; g < n_groups; ++g) if (chunkable[g]) chunkable_elems += gs[g].ne;
     const int hex_tiles = hv ? std::atoi(hv) : (chunkable_elems < kMixedHexTilesBelow ? 1 : 0);
-    for (int g = 0; g < n_groups; ++g)                   // (chunkable == 2: per-element dof order - a tile type, never the hex section)
+    int64_t best_any = 0;
+    int any_group = -1;                                  // the most populous 8-node type, whatever the dof order of its elements
+    for (int g = 0; g < n_groups; ++g) {                 // (chunkable == 2: per-element dof order - tiles only, never the hex section)
         if (chunkable[g] == 1 && gs[g].nd == 24 && gs[g].ne > best) { best = gs[g].ne; M.hex_group = g; }
+        if (chunkable[g] && gs[g].nd == 24 && gs[g].ne > best_any) { best_any = gs[g].ne; any_group = g; }
+    }
     int first_group = -1;
-    if (hex_tiles && M.hex_group >= 0) { first_group = M.hex_group; M.hex_group = -1; if (hex_tiles == 1) M.hex_tile_type = 0; }
+    if (hex_tiles && any_group >= 0) { first_group = any_group; M.hex_group = -1; if (hex_tiles == 1) M.hex_tile_type = 0; }
+    else if (!hv && M.hex_group < 0 && any_group >= 0) { first_group = any_group; M.hex_tile_type = 0; }   // oriented 8-node elements: the hex section cannot take them
     auto &K = C.cls[kMixedClass];
     K.ke_col.assign(24 * 24, 0.0);
     if (M.hex_group >= 0)

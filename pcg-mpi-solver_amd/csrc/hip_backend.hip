@@ -577,7 +577,7 @@ public:
                     for (int g = 0; g < 4; ++g) {
                         uint2 r;
                         r.x = (unsigned)M.tlid[((size_t)t * M.nnpt + g) * 16 + e] | (unsigned)M.tlid[((size_t)t * M.nnpt + g + 4) * 16 + e] << 16;
-                        r.y = tsgw[((size_t)t * 4 + g) * 16 + e] | 0x80000000u;
+                        r.y = tsgw[((size_t)t * 4 + g) * 16 + e] | (unsigned)M.tperm[(size_t)t * 16 + e] << 8 | 0x80000000u;
                         hrec[(size_t)t * 64 + g * 16 + e] = r;
                     }
                 }

@@ -659,7 +659,8 @@ struct MixTab {
     int flags;                    // bit 0: ordered adds by barriers instead of tickets, bit 2: empty waves of a hex pass do not skip (A/B);
                                   // bits 4..6: development ablations (wrong results)
     const uint2 *hrec;            // k_ebe_mtile, hex tiles: [tiles][64] per lane (g, e): x = slot of node g | slot of node g + 4 << 16 in the LDS tile,
-                                  //            y = sign bits of the lane's six dofs (bit 3 j + c), bit 31 = the element exists
+                                  //            y = sign bits of the lane's six dofs (bit 3 j + c), bits 8..13 the element's component order (tperm),
+                                  //                bit 31 = the element exists
     const int *twait;             // k_ebe_mtile: [tiles] completed tiles of the chunk this tile's adds wait for
     unsigned long long *stamps;   // STAMP instantiation only (PCG_EBE_STAMPS=1, development): [workgroup][wave][16] shader-clock readings
 };
@@ -1035,7 +1036,8 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
         }
         const int l0 = 3 * (int)(rec.x & 0xffffu), l1 = 3 * (int)(rec.x >> 16);
         const unsigned sw = rec.y;
-        const double xv[6] = {xs[l0], xs[l0 + 1], xs[l0 + 2], xs[l1], xs[l1 + 1], xs[l1 + 2]};              // :277 gather
+        const int p0 = (sw >> 8) & 3, p1 = (sw >> 10) & 3, p2 = (sw >> 12) & 3;                             // the element's own component order
+        const double xv[6] = {xs[l0 + p0], xs[l0 + p1], xs[l0 + p2], xs[l1 + p0], xs[l1 + p1], xs[l1 + p2]};   // :277 gather
         d4m_t acc0 = d4m_t{0.0, 0.0, 0.0, 0.0}, acc1 = d4m_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
@@ -1050,7 +1052,8 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
         if (sw >> 31) {
 #pragma unroll
             for (int q = 0; q < 6; ++q)                                                                      // :280, :300 (added by the LDS unit)
-                __hip_atomic_fetch_add(&ys[(q < 3 ? l0 : l1) + q % 3], flip_sign(o[q], sw, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&ys[(q < 3 ? l0 : l1) + (q % 3 == 0 ? p0 : q % 3 == 1 ? p1 : p2)], flip_sign(o[q], sw, q), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         count_in();
         if constexpr (STAMP) {

@@ -121,9 +121,12 @@ def test_mixed_type_chunks_agree_with_oracle_and_with_per_type_chunks(hostops, e
         ys = {}
         # mixed chunks with the hex section (k_ebe_mixed), mixed chunks with the 8-node type in colour-pure matrix-core tiles
         # (k_ebe_mtile, PCG_EBE_HEX_TILES=1: the default below 1.2 M elements), per-type chunks (round 3)
-        for mixed in ("1", "1t", "0"):
-            monkeypatch.setenv("PCG_EBE_MIXED", mixed[0])
-            monkeypatch.setenv("PCG_EBE_HEX_TILES", "1" if mixed == "1t" else "0")
+        for mixed in ("1", "1t", "0", "auto"):                    # auto: the planner's own choice (no switch set)
+            if mixed == "auto":
+                monkeypatch.delenv("PCG_EBE_MIXED"); monkeypatch.delenv("PCG_EBE_HEX_TILES")
+            else:
+                monkeypatch.setenv("PCG_EBE_MIXED", mixed[0])
+                monkeypatch.setenv("PCG_EBE_HEX_TILES", "1" if mixed == "1t" else "0")
             op = from_refmeshpart(copy.deepcopy(P), kind="ebe")
             x = np.random.default_rng(5).standard_normal(op.n)
             y = np.empty(op.n); pxy = C.c_double()
@@ -134,12 +137,11 @@ def test_mixed_type_chunks_agree_with_oracle_and_with_per_type_chunks(hostops, e
             assert relerr(ys[mixed], ref) < 1e-14, (name, mixed)
             w = np.zeros(op.n); w[P["LocDofEff"]] = 1.0
             assert abs(pxy.value - np.dot(x, ref * w)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref)), (name, mixed)
-            if mixed != "0" or not name.startswith("oriented"):
+            if mixed in ("1", "1t") or (mixed == "0" and not name.startswith("oriented")):
                 assert op.operator_info()["n_colors"] <= (1 if mixed != "0" else 4)     # launches per phase
             op.close()
-        assert relerr(ys["1"], ys["0"]) < 1e-14 and relerr(ys["1t"], ys["0"]) < 1e-14
+        assert relerr(ys["1"], ys["0"]) < 1e-14 and relerr(ys["1t"], ys["0"]) < 1e-14 and relerr(ys["auto"], ys["0"]) < 1e-14
     monkeypatch.setenv("PCG_EBE_MIXED", "1")
-    monkeypatch.delenv("PCG_EBE_HEX_TILES")
     P = dict(mixed_chunk_cases())["graded_octree"]
     R = copy.deepcopy(P)
     pm.configure(comm=None, operator="ebe")

@@ -681,11 +681,14 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
         monkeypatch.setenv("PCG_EBE_MIX_FLAGS", flags)
         for name, P in mixed_chunk_cases():
             ys = {}
-            for mixed in ("1", "1t", "0"):                        # hex section (k_ebe_mixed) / hex tiles (k_ebe_mtile) / per-type chunks
-                if mixed == "1t" and flags == "1":
+            for mixed in ("1", "1t", "0", "auto"):                # hex section (k_ebe_mixed) / hex tiles (k_ebe_mtile) / per-type chunks / the planner's choice
+                if mixed in ("1t", "auto") and flags == "1":
                     continue
-                monkeypatch.setenv("PCG_EBE_MIXED", mixed[0])
-                monkeypatch.setenv("PCG_EBE_HEX_TILES", "1" if mixed == "1t" else "0")
+                if mixed == "auto":
+                    monkeypatch.delenv("PCG_EBE_MIXED"); monkeypatch.delenv("PCG_EBE_HEX_TILES")
+                else:
+                    monkeypatch.setenv("PCG_EBE_MIXED", mixed[0])
+                    monkeypatch.setenv("PCG_EBE_HEX_TILES", "1" if mixed == "1t" else "0")
                 op = from_refmeshpart(copy.deepcopy(P), kind="ebe")
                 x = np.random.default_rng(5).standard_normal(op.n)
                 xe = op.to_engine(x)
@@ -699,11 +702,11 @@ def test_mixed_type_chunks_on_gpu(gpu_lib, monkeypatch):
                 w = np.zeros(op.n); w[P["LocDofEff"]] = 1.0
                 assert abs(pxy.value - np.dot(x, ref * w)) <= 1e-12 * np.dot(np.abs(x), np.abs(ref)), (name, mixed)
                 op.close()
-            assert relerr(ys["1"], ys["0"]) < 1e-13 and ("1t" not in ys or relerr(ys["1t"], ys["0"]) < 1e-13)
+            assert relerr(ys["1"], ys["0"]) < 1e-13 and all(relerr(ys[k], ys["0"]) < 1e-13 for k in ("1t", "auto") if k in ys)
     monkeypatch.setenv("PCG_EBE_MIXED", "1")
     monkeypatch.delenv("PCG_EBE_EPT")
     monkeypatch.delenv("PCG_EBE_MIX_FLAGS")
-    monkeypatch.delenv("PCG_EBE_HEX_TILES")
+    monkeypatch.delenv("PCG_EBE_HEX_TILES", raising=False)
     P = dict(mixed_chunk_cases())["graded_octree"]
     R = copy.deepcopy(P)
     pm.configure(comm=None, device=0, operator="ebe")
