@@ -866,6 +866,11 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 fprintf(stderr, "ebe plan: mixed chunks: %lld elements in the hex section, %lld in %lld tiles of 16 (%.0f %% full), %zu tile types, "
                                 "at most %d M-tiles\n", (long long)C.mixed.hex_elems, (long long)C.mixed.tile_elems, (long long)C.mixed.n_tiles,
                         C.mixed.n_tiles ? 100.0 * C.mixed.tile_elems / (16.0 * C.mixed.n_tiles) : 0.0, C.mixed.types.size(), C.mixed.max_mt);
+            if (C.mixed.hex_tile_type >= 0) {
+                int64_t ht = 0;
+                for (int32_t v : C.mixed.chunk_hex_tiles) ht += v;
+                fprintf(stderr, "ebe plan:   the 8-node type runs in %lld colour-pure hex tiles (k_ebe_mtile), no hex section\n", (long long)ht);
+            }
             if (C.mixed.n_tiles) {                                  // per tile type: node quartets, tiles, elements; fill histogram
                 std::vector<int64_t> tl(C.mixed.types.size(), 0), el(C.mixed.types.size(), 0), hist(17, 0);
                 for (int64_t t = 0; t < C.mixed.n_tiles; ++t) {
