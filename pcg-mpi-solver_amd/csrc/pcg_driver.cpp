@@ -805,7 +805,8 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
                 b += 28.0 * (double)M.hex_elems;             // (fragments: L2-resident, counted once per tile as the kernel reads them)
                 for (int64_t t = 0; t < M.n_tiles; ++t) {
                     const auto &T = M.types[M.tile_type[t]];
-                    b += 16.0 * (2.0 * 4 * T.J + 8.0 + 4.0 * M.words + 1.0) + 8.0;
+                    if (M.tile_type[t] == M.hex_tile_type) b += 64.0 * 8.0 + 16.0 * 8.0 + 4.0;   // hex tile: 8-byte record per lane, Ck, wait count
+                    else b += 16.0 * (2.0 * 4 * T.J + 8.0 + 4.0 * M.words + 1.0) + 8.0;
                 }
             }
             b += 24.0 * (double)Ch.n_slots;                  // shared-node pass: every slot read once ...
