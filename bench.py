@@ -578,9 +578,29 @@ def main():
     assert _lib.backend_name() == "hip-gfx950"
     comm, transport = None, "none (one part)"
     if world > 1:
+        native_err = None
         if args.comm == "native":
-            comm = RcclComm.from_torch(dev)
-            assert comm.world == world
+            # The driver launches the ranks itself (torch.distributed.run), so the retry of launch_ranks() is not around them: a native
+            # communicator that cannot be CREATED (library missing, a symbol, an RCCL error every rank sees) must not take the job down -
+            # the ranks agree over the control plane and fall back to the torch callbacks together; the line says so (comm.native_error).
+            try:
+                comm = RcclComm.from_torch(dev)
+                assert comm.world == world
+            except Exception as ex:                    # noqa: BLE001
+                native_err = repr(ex)[:300]
+                comm = None
+            bad = torch.tensor([0 if native_err is None else 1], dtype=torch.int32, device=torch.device("cpu") if share else torch.device("cuda", dev))
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                native_err = native_err or "the native communicator failed on another rank"
+                log(f"[rank {rank}] native communicator not available ({native_err}); falling back to torch.distributed callbacks")
+                os.environ["PCG_BENCH_NATIVE_FAILED"] = "1"
+                os.environ.setdefault("PCG_BENCH_NATIVE_ERROR", native_err)
+                args.comm = "torch"
+        if comm is not None:
             transport = "native: engine-issued RCCL (grouped ncclSend/ncclRecv on a comm stream, ncclAllReduce on the compute stream)"
             if os.environ.get("PCG_RCCL_LIB"):
                 transport += f" [PCG_RCCL_LIB={os.path.basename(os.environ['PCG_RCCL_LIB'])}]"
