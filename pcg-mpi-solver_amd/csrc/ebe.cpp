@@ -623,7 +623,9 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         // a transition shell sit together - for more boundary slots: every node between a shell and its hex neighbours is shared).
         int node_cap = kChunkMaxNodes;
         if (const char *nv = std::getenv("PCG_EBE_NODE_CAP")) node_cap = std::max(64, std::min(kChunkMaxNodes, std::atoi(nv)));
-        if (const char *sv = std::getenv("PCG_EBE_MIX_SHELLS"); sv && sv[0] == '1' && M.hex_group >= 0)
+        const char *shells_env = std::getenv("PCG_EBE_MIX_SHELLS");
+        const bool mix_shells = shells_env && shells_env[0] == '1';
+        if (mix_shells && M.hex_group >= 0)
             std::stable_partition(L.begin(), L.end(), [&](const ElemRef &r) { return r.g == M.hex_group; });
         std::vector<int32_t> cnt_type(M.types.size(), 0);
         size_t lo_ = 0;
@@ -644,7 +646,7 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
             };
             const int fresh = stamp_new(run_id, false);
             const bool new_tile = !is_hex && cnt_type[t] % 16 == 0;
-            const bool kind_change = std::getenv("PCG_EBE_MIX_SHELLS") && std::getenv("PCG_EBE_MIX_SHELLS")[0] == '1' && is_hex != prev_hex;
+            const bool kind_change = mix_shells && is_hex != prev_hex;
             prev_hex = is_hex;
             if (k > lo_ && (kind_change || n_run_nodes + fresh > node_cap || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
                 emit_or_split(lo_, k);

@@ -389,6 +389,10 @@ public:
         d_flags_ = (uint8_t *)alloc((size_t)n_ + 16);
         HIP_CHECK(hipStreamSynchronize(S->st_));
         HIP_CHECK(hipMemcpyAsync(d_diag_, S->d_diag_, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, st_));
+        // lanes of the last slice past n_rows are written by no thread of k_expand_scalar, yet k_spmv_scalar walks every lane of a
+        // slice over its full width before the row guard: value 0 / column 0 there, not whatever the allocation held before
+        HIP_CHECK(hipMemsetAsync(d_cols_, 0, sizeof(int) * std::max<size_t>(1, tot), st_));
+        HIP_CHECK(hipMemsetAsync(d_vals_, 0, sizeof(double) * std::max<size_t>(1, tot), st_));
         const int grid = (int)((n_rows + kBlock - 1) / kBlock);
         if (S->d_cols16_)
             hipLaunchKernelGGL((k_expand_scalar<true>), dim3(grid), dim3(kBlock), 0, st_, S->d_slice_ptr_, (const void *)S->d_cols16_, S->d_colbase_, S->d_vals_,
@@ -953,7 +957,6 @@ public:
     {
         for (void *p : {(void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_}) if (p) (void)hipFree(p);
         halo_count_ = (int64_t)h.send_idx.size();
-        fix_grid_seen_ = 0;                                   // (the fix-up launch's arrival counter starts over)
         if (ebe_) nb_dofs_ = h.fix_dof.empty() ? 0 : (int64_t)h.fix_dof.back() + 1;
         d_send_idx_ = (int *)alloc(sizeof(int) * h.send_idx.size());
         h2d(d_send_idx_, h.send_idx.data(), sizeof(int) * h.send_idx.size());
@@ -1127,10 +1130,9 @@ public:
         hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(kBlock), 0, st_, y, d_send_idx_, send, halo_count_);
         HIP_CHECK(hipGetLastError());
     }
-    // last-workgroup reductions of the multi-part loop (k_fixup<true, true>, k_vec<false> with reduce_last): monotonic arrival counters
+    // last-workgroup reductions of the multi-part loop (k_fixup<true, true>, k_vec<false> with reduce_last): arrival counters, put
+    // back to 0 by the last arriver of every launch
     unsigned long long *d_last_cnt_ = nullptr;      // [0]: k_fixup, [16]: k_vec (128 B apart)
-    unsigned long long fix_seq_ = 0, vecl_seq_ = 0;
-    int fix_grid_seen_ = 0, vecl_grid_seen_ = 0;
     void last_counters()
     {
         if (d_last_cnt_) return;
@@ -1147,12 +1149,8 @@ public:
         FixReduce fr{};
         if (with_dot && reduce_pq) {
             last_counters();
-            if (grid != fix_grid_seen_) {                        // (a new interface list: the counter starts over)
-                HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long), st_));
-                fix_seq_ = 0; fix_grid_seen_ = grid;
-            }
             fr.pa = ebe_ ? d_part_ebe_ : d_part_spmv_; fr.count_a = ebe_ ? cnt_ebe_ : cnt_spmv_;
-            fr.red = reduce_pq; fr.counter = d_last_cnt_; fr.seq = ++fix_seq_;
+            fr.red = reduce_pq; fr.counter = d_last_cnt_;
             hipLaunchKernelGGL((k_fixup<true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
                                nb_dofs_, d_part_fix_, fr);
         } else if (with_dot)
@@ -1285,11 +1283,7 @@ public:
         a.sync = d_vec_sync_; a.pq_src = pq_src; a.nt = vec_nt_; a.n = n_; a.kreg = vec_kreg_; a.spin_limit = vec_spin_limit_;
         if (reduce_sums && !fused) {
             last_counters();
-            if (cnt_vec_ != vecl_grid_seen_) {
-                HIP_CHECK(hipMemsetAsync(d_last_cnt_ + 16, 0, sizeof(unsigned long long), st_));
-                vecl_seq_ = 0; vecl_grid_seen_ = cnt_vec_;
-            }
-            a.reduce_last = 1; a.last_counter = d_last_cnt_ + 16; a.last_seq = ++vecl_seq_;
+            a.reduce_last = 1; a.last_counter = d_last_cnt_ + 16;
         }
         const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));

@@ -59,13 +59,17 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa
 // "Last workgroup to finish reduces" (round 4, multi-part loop): a launch that leaves one partial per workgroup can also form the
 // total - in reduce_fixed_256's order, whichever workgroup happens to be last - instead of leaving it to a k_reduce launch.  Thread 0
 // has published the workgroup's partial(s) with agent-scope stores; it counts the workgroup in (acq_rel: the partials are out
-// before, and the last arriver sees everybody's).  The counter is monotonic over the launches of one kind (seq = 1, 2, ...: the
-// launch's number, same grid every time), nothing is reset in between.  -> true in every thread of the last workgroup.
-__device__ __forceinline__ bool last_workgroup(unsigned long long *counter, unsigned long long seq, int *lds_flag)
+// before, and the last arriver sees everybody's).  Self-contained (round 5): the last arriver - the one that counts gridDim.x - puts
+// the counter back to 0 for the next launch on the stream, so the test never depends on a launch number the host keeps in step
+// (a lost launch or a changed grid cannot leave every workgroup believing it is not the last).  -> true in every thread of the
+// last workgroup.
+__device__ __forceinline__ bool last_workgroup(unsigned long long *counter, int *lds_flag)
 {
     if (threadIdx.x == 0) {
         const unsigned long long t = __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        *lds_flag = (t + 1 == seq * (unsigned long long)gridDim.x) ? 1 : 0;
+        const bool last = t + 1 == (unsigned long long)gridDim.x;
+        if (last) __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = last ? 1 : 0;
     }
     __syncthreads();
     const bool last = *lds_flag != 0;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
 // y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
 // REDUCE (with DOT): the last workgroup to finish sums the apply's dot partials - pa[0 .. count_a) of the operator launches, then
 // this launch's - in k_reduce's fixed order into red[0]: the p.Ap of the multi-part loop without a reduce launch.
-struct FixReduce { const double *pa; int count_a; double *red; unsigned long long *counter; unsigned long long seq; };
+struct FixReduce { const double *pa; int count_a; double *red; unsigned long long *counter; };
 
 template <bool DOT, bool REDUCE = false>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
         } else {
             __shared__ int flag;
             if (threadIdx.x == 0) __hip_atomic_store(partials + blockIdx.x, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last_workgroup(fr.counter, fr.seq, &flag)) {
+            if (last_workgroup(fr.counter, &flag)) {
                 const double tot = reduce_fixed_256<true>(fr.pa, fr.count_a, partials, (int)gridDim.x, lds);
                 if (threadIdx.x == 0) fr.red[0] = tot;
             }
@@ -220,8 +224,7 @@ struct VecArgs {
     int kreg;                             // FUSED: chunks of z kept in registers, <= kVecKreg (tests lower it: PCG_VEC_KREG)
     unsigned spin_limit;                  // FUSED: polls of the grid barrier before a workgroup gives up (2^22 = seconds; tests: PCG_TEST_VEC_SPINS)
     int reduce_last;                      // !FUSED: the last workgroup to finish reduces the five sums into st[SQP..NINF] (multi-part loop)
-    unsigned long long *last_counter;     // ... its arrival counter (monotonic) and this launch's number
-    unsigned long long last_seq;
+    unsigned long long *last_counter;     // ... its arrival counter (0 between launches: the last arriver resets it)
     int64_t n;
 };
 
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     __hip_atomic_store(a.partials + (size_t)k * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last_workgroup(a.last_counter, a.last_seq, &flag)) {
+            if (last_workgroup(a.last_counter, &flag)) {
                 double s5[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) s5[k] = reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, (int)gridDim.x, nullptr, 0, lds);

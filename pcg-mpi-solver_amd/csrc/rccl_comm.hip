@@ -162,7 +162,11 @@ public:
         // every rank creates the two communicators in the same order
         NCCL_CHECK(A.CommInitRank(&halo_comm_, nranks, id[0], rank));
         NCCL_CHECK(A.CommInitRank(&red_comm_, nranks, id[1], rank));
-        HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        // highest priority: the send / recv kernel of an exchange is queued while the interior rows' workgroups occupy the CUs - it
+        // must be dispatched ahead of their remaining workgroups, not after them (that is the overlap)
+        int prio_lo = 0, prio_hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_CHECK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, prio_hi));
         for (int k = 0; k < kFence; ++k) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_packed_[k], hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming));

@@ -146,6 +146,7 @@ bool split_overflow(SellHost &m, double min_saving, int n_threads, int target_bl
     if (const char *ev = std::getenv("PCG_SPMV_OVF")) windowed = std::string(ev) != "split";
     if (const char *ev = std::getenv("PCG_SPMV_OVF_WINDOW")) per_win = std::max(1, std::atoi(ev));
     auto emit_range = [&](int64_t s_lo, int64_t s_hi) {
+        if (s_hi <= s_lo) return;                                            // (no interface slices: no empty window either)
         std::vector<int64_t> cuts;                                           // window boundaries (base slices) of this range
         if (windowed && s_hi > s_lo) {
             const int64_t n = s_hi - s_lo;

@@ -60,9 +60,22 @@ class RcclComm:
 
     @classmethod
     def from_torch(cls, device, group=None):
-        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast."""
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast.
+        The ranks AGREE before anybody enters ncclCommInitRank (round 5): every rank first does what can fail locally -
+        load the library, resolve its symbols, ncclGetUniqueId - and the outcomes are gathered over the control plane; if any rank
+        failed, every rank raises here, together, instead of the healthy ones blocking inside the collective creation."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
+        err, uid = None, None
+        try:
+            uid = cls.new_unique_id()
+        except Exception as ex:          # noqa: BLE001 - reported to every rank below
+            err = repr(ex)[:300]
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        bad = [f"rank {r}: {e}" for r, e in enumerate(errs) if e]
+        if bad:
+            raise RuntimeError("native communicator not available on every rank (" + "; ".join(bad[:4]) + ")")
+        box = [uid if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
         self = cls(rank, world, device, box[0])
         self.group = group                          # result-file offsets / barriers of this job go over the same group

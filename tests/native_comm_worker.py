@@ -6,6 +6,9 @@ usage: python tests/native_comm_worker.py threads <case[,case..]> <kind[,kind..]
            this process is rank <rank> of <world> (one part per process, as in production)
        python tests/native_comm_worker.py group <case[,case..]> <kind[,kind..]> <outdir>
            every part of a case as a member of ONE device group (pcg_group_*: the library's own thread per member)
+       python tests/native_comm_worker.py bigbrick <N> <kind[,kind..]> <out.json> [iterations]
+           BASELINE configs[3] at its own size: the N-node brick (150 -> 10 125 000 dof) split 2x2x2, eight engines on ONE GPU, one
+           thread + one native communicator per part; prints / writes the deviations from the oracle and from the one-part engine
 The RCCL library is whatever csrc/rccl_comm.hip resolves: the real librccl (one rank per GPU), or - with
 PCG_RCCL_LIB=tests/fakenccl/_build/libfakenccl.so - the shared-GPU test double.  Results go to
 <outdir>/<case>_<kind>_rank<r>.npz in the layout of tests/dist_worker.py.
@@ -59,11 +62,116 @@ def build(case):
     return parts, probe
 
 
+def big_brick(N, kinds, out_json, iters):
+    """Multi-part parity at a BASELINE size: the native multi-part path - interface lists of 139 KB faces, the real
+    n_bnd_slices, the PACK epilogue of the interface rows' launch, k_fixup's and k_vec<false>'s last-workgroup reductions at
+    1.27 M dof per part - against pcg_oracle.calc_matvec / halo_sum (reference pcg_solver.py:242-336) on a probe vector, the
+    assembled diagonal (:346-352, 'Preconditioner' mode), Fext, and `iters` iterations of residual history against ONE engine
+    holding the whole system."""
+    import json
+    import time
+    import pcg_oracle
+    import pcg_mi355x as pm
+    from pcg_mi355x.brick import Brick, make_parts, block_partition
+    from pcg_mi355x.dist import RcclComm
+    from pcg_mi355x.operator import from_refmeshpart
+    t_start = time.time()
+    b = Brick(N, seed=0)
+    parts = make_parts(b, block_partition(b, 2, 2, 2), max_iter=iters)
+    world = len(parts)
+    probe = np.random.default_rng(7).standard_normal(b.n_dof)
+    xs = [probe[P["DofVector"]] for P in parts]
+    t0 = time.time()
+    y_ref = pcg_oracle.calc_matvec(parts, xs, "Strain", use_c=True)                 # the reference's operator + interface sum
+    d_ref = pcg_oracle.calc_matvec(parts, None, "Preconditioner")
+    ref_parts = [dict(P) for P in parts]
+    pcg_oracle.update_bc(ref_parts, use_c=True)
+    t_oracle = time.time() - t0
+    report = {"N": N, "dofs": int(b.n_dof), "parts": world, "dofs_per_part": [int(P["NDOF"]) for P in parts],
+              "interface_dofs_per_part": [int(P["N_NbrDof"]) for P in parts], "iterations": iters, "oracle_s": t_oracle, "kinds": {}}
+
+    def rel(a, c):
+        nc = float(np.linalg.norm(c))
+        return float(np.linalg.norm(a - c)) / (nc if nc > 0 else 1.0)      # (the lower parts of the brick carry no load: Fext == 0)
+    uid = RcclComm.new_unique_id()
+    comms = [None] * world
+    for kind in kinds:
+        outs, errs = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                if comms[r] is None:
+                    comms[r] = RcclComm(r, world, 0, uid)
+                P = parts[r]
+                op = from_refmeshpart(P, device=0, comm=comms[r], kind=kind)
+                try:
+                    o = {"y": op.apply(xs[r]), "diag": op.diag()}
+                    fext, udi = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)
+                    inv = op.build_jacobi()
+                    gd = P["GlobData"]
+                    x, res, hist = op.solve(fext, P["Un"], inv, gd["Tol"], gd["MaxIter"], gd["GlobNDofEff"], history=True)
+                    info = pm.solver.SolveInfo(res, hist)
+                    o.update(fext=fext, x=x, hist=info.history, flag=info.flag, iter=info.iter, relres=info.relres, iters_done=info.iters_done)
+                    o["info"] = op.matrix_info() if kind != "ebe" else op.operator_info()
+                finally:
+                    op.close()
+                outs[r] = o
+            except BaseException as e:      # noqa: BLE001
+                errs[r] = e
+        t0 = time.time()
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        t_multi = time.time() - t0
+        # ---- the same system as ONE engine ------------------------------------------------------------------------------------
+        t0 = time.time()
+        one = make_parts(b, max_iter=iters)[0]
+        op1 = from_refmeshpart(one, device=0, kind=kind)
+        fext1, _ = op1.update_bc(one["RefLoadVector"], one["Ud"], 1.0)
+        inv1 = op1.build_jacobi()
+        gd = one["GlobData"]
+        x1, res1, hist1 = op1.solve(fext1, one["Un"], inv1, gd["Tol"], gd["MaxIter"], gd["GlobNDofEff"], history=True)
+        i1 = pm.solver.SolveInfo(res1, hist1)
+        op1.close()
+        t_one = time.time() - t0
+        h1 = np.asarray(i1.history, float).reshape(-1, 3)
+        rec = {"multi_part_s": t_multi, "one_part_s": t_one, "y": [], "diag": [], "fext": [], "x_vs_one_part": [], "flag": [], "iters_done": [],
+               "relres": [], "hist": []}
+        for r, (P, o) in enumerate(zip(parts, outs)):
+            hm = np.asarray(o["hist"], float).reshape(-1, 3)
+            k = min(len(hm), len(h1), iters)
+            rec["y"].append(rel(o["y"], y_ref[r]))
+            rec["diag"].append(rel(o["diag"], d_ref[r]))
+            rec["fext"].append(rel(o["fext"], ref_parts[r]["Fext"]))
+            rec["x_vs_one_part"].append(rel(o["x"], x1[P["DofVector"]]))
+            rec["flag"].append(int(o["flag"])); rec["iters_done"].append(int(o["iters_done"])); rec["relres"].append(float(o["relres"]))
+            rec["hist"].append(float(np.max(np.abs(hm[:k] - h1[:k]) / np.maximum(np.abs(h1[:k]), 1e-300))))
+            rec["hist_rows"] = int(k)
+        rec["hist_identical_across_ranks"] = bool(all(np.array_equal(np.asarray(o["hist"]), np.asarray(outs[0]["hist"])) for o in outs))
+        rec["one_part"] = {"flag": i1.flag, "iters_done": i1.iters_done, "relres": i1.relres}
+        rec["part0_info"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in outs[0]["info"].items() if np.isscalar(v)}
+        report["kinds"][kind] = rec
+        print(f"[bigbrick {kind}] y {max(rec['y']):.2e} diag {max(rec['diag']):.2e} fext {max(rec['fext']):.2e} hist {max(rec['hist']):.2e} "
+              f"x {max(rec['x_vs_one_part']):.2e} ({t_multi:.0f} s + {t_one:.0f} s)", file=sys.stderr, flush=True)
+    for c in comms:
+        if c is not None:
+            c.close()
+    report["total_s"] = time.time() - t_start
+    with open(out_json, "w") as f:
+        json.dump(report, f)
+    print(json.dumps(report))
+
+
 def main():
     mode = sys.argv[1]
     from pcg_mi355x import _lib
     from pcg_mi355x.dist import RcclComm
-    _lib.use_library(None)
+    _lib.use_library(os.environ.get("PCG_TEST_LIB") or None)      # (PCG_TEST_LIB: the CPU double, for the harness check of the no-GPU tier)
     timing = os.environ.get("PCG_TEST_COMM_TIMING", "1") == "1"
     if mode == "threads":
         cases, kinds, outdir = sys.argv[2].split(","), sys.argv[3].split(","), sys.argv[4]
@@ -95,6 +203,8 @@ def main():
                     np.savez(os.path.join(outdir, f"{case}_{kind}_rank{r}.npz"), **o)
             for c in comms:
                 c.close()
+    elif mode == "bigbrick":
+        big_brick(int(sys.argv[2]), sys.argv[3].split(","), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 30)
     elif mode == "group":
         # ONE process, every part of the case as a member of a device group (pcg_group_*): the library's own threads
         # drive the members; devices from PCG_TEST_GROUP_DEVICES (default: every member on device 0)

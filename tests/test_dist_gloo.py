@@ -144,3 +144,21 @@ def test_rank_without_neighbours_enters_the_collective_exchange(tmp_path):
         assert int(o["flag"]) == out["flag"] == 0 and abs(int(o["iter"]) - out["iter"]) <= 1
         assert relerr(o["Un"], R["Un"]) < 1e-8
     assert int(outs[2]["n_halo"]) > 0            # the island rank took part in every exchange
+
+
+def test_big_multi_part_harness_on_the_test_double(oracle_c, tmp_path):
+    """The harness of test_native_comm.test_eight_parts_of_the_10m_dof_brick_on_one_gpu (tests/native_comm_worker.py bigbrick: eight
+    parts of a 2x2x2 split through the NATIVE communicator branch of the driver vs the oracle's calcMatVecProd + interface sum, the
+    diagonal, Fext, 30 iterations of history vs one engine) at 27 783 dof on the CPU double, where there is no GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import conftest
+    from test_native_comm import WORKER, check_big_brick_report
+    env = dict(os.environ, PCG_TEST_LIB=conftest.build_hostops())
+    env.pop("PCG_RCCL_LIB", None)
+    out = str(tmp_path / "bb.json")
+    r = subprocess.run([sys.executable, WORKER, "bigbrick", "21", "sell,ebe", out, "30"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    check_big_brick_report(json.load(open(out)), ("sell", "ebe"), 30)

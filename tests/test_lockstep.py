@@ -68,8 +68,32 @@ def test_lock_step_window_at_10m_dof(gpu_lib, oracle_c, kind):
     lock_step(kind, 150, max_iter=LOCKSTEP_10M, expect_flag=1)
 
 
-def lock_step(kind, N, case=None, max_iter=None, expect_flag=0):
-    if case is not None:
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["ebe_mtile", "ebe_mixed", "sell_win"])
+def test_octree_solve_in_lock_step(gpu_lib, oracle_c, monkeypatch, form):
+    """Round 5: the kernels round 4 added, walked like the brick's - the 1 M-dof graded octree mesh of BASELINE
+    configs[1] (GradedOctreeMesh((12,12,12), 4, symmetry=True): 8 pattern types in 95 orientations, per-element dof order + sign
+    word), every one of its ~570 iterations with the oracle's vectors: k_ebe_mtile + k_ebe_shared (every element on the matrix
+    cores, the default at this size), k_ebe_mixed (hex section on the vector FMAs, PCG_EBE_HEX_TILES=0) and k_spmv_win (windowed
+    split SELL format).  Late iterations reach these kernels with tiny p and denormal-adjacent residuals under identical inputs;
+    gates as for the brick: q and p.Ap <= 1e-13, the vector phase bit-equal."""
+    if form == "ebe_mixed":
+        monkeypatch.setenv("PCG_EBE_HEX_TILES", "0")
+    st = lock_step("ebe" if form.startswith("ebe") else "sell", 0, octree=(12, 12, 12))
+    info = st["operator_info"]
+    if form == "ebe_mtile":
+        assert info.get("hex_tiles", 1) != 0, info
+    if form == "sell_win":
+        assert info["stored_blocks"] > 0
+    assert st["count"] > 400
+
+
+def lock_step(kind, N, case=None, max_iter=None, expect_flag=0, octree=None):
+    if octree is not None:
+        from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts
+        b = GradedOctreeMesh(octree, 4, band=1.2, seed=0, symmetry=True)
+        P = make_octree_parts(b, 1)[0]
+    elif case is not None:
         import golden_cases
         b, parts = golden_cases.build_case(case)
         P = parts[0]
@@ -136,6 +160,7 @@ def lock_step(kind, N, case=None, max_iter=None, expect_flag=0):
         state["count"] += 1
 
     out = pcg_oracle.pcg([R], use_c=True, record=False, observer=observer)
+    state["operator_info"] = op.operator_info() if kind == "ebe" else op.matrix_info()
     op.close()
     assert out["flag"] == expect_flag, out["flag"]
     if expect_flag == 0:
@@ -153,3 +178,10 @@ def L_fused_available(op):
     rc = op._L.pcg_k_vec_iteration(op._h, 0.0, 1.0, z.ctypes.data, z.ctypes.data, rr.ctypes.data, z.ctypes.data, xn.ctypes.data,
                                    o.ctypes.data, pn.ctypes.data, s5.ctypes.data, 1)
     return rc == 0
+
+
+@pytest.mark.parametrize("kind", ["sell", "ebe"])
+def test_octree_lock_step_harness_on_the_cpu_double(hostops, oracle_c, kind):
+    """The octree walk of test_octree_solve_in_lock_step on a small graded mesh (same generator, same pattern library) on the CPU double."""
+    st = lock_step(kind, 0, octree=(3, 3, 3))
+    assert st["count"] > 50
