@@ -27,7 +27,12 @@ Objects on the JSON line besides the contract's fields:
   comm         - N > 1: transport, ranks seen by RCCL, per-iteration exchange wait / all-reduce time (HIP events,
                  measured in a second, separately timed window), per-rank ms per step.
   cpu_baseline - the oracle (reference algorithm, kind "port") on the node's host cores: R = min(cores, 64) processes,
-                 one part and one thread each - the reference's own mode - plus the 1-core figure.
+                 one part and one thread each - the reference's own mode - plus the 1-core figure.  At N > 1 rank 0 times it after
+                 the GPU windows while the other ranks sleep on the rendezvous store (no spinning barrier next to the CPU run).
+  roofline_iteration - (in the headline, matrix_free and octree objects, every N) the whole ITERATION against the HBM roofline:
+                 (stored operator bytes + 73 B/dof of the vector phase, summed over the ranks) / ms_per_step / (N x 8 TB/s).
+  octree_10m   - every N: the 10 M-dof graded octree mesh split into N parts by recursive bisection, assembled and matrix-free:
+                 the "octree mesh at 1/2/4/8 GPUs" series of BASELINE.json's north_star, with its own CPU baseline.
   box          - GPU clocks / power cap / partition modes of the box the numbers come from.
 """
 from __future__ import annotations
@@ -282,7 +287,7 @@ def scalar_csr_point_device(op):
             "GBps_stored": by / t / 1e9, "frac_of_peak_stored": by / t / 1e9 / HBM_PEAK_GBS}
 
 
-def cpu_baseline(part, N, ranks=0, workload="brick", quick=False):
+def cpu_baseline(part, N, ranks=0, workload="brick", quick=False, total_dofs=None):
     """The reference's mode on this node: R processes x 1 thread, one part each (oracle/mp_baseline.py), beside 1 core.
     `value` (round 4) = the reference's OWN NumPy arithmetic per rank (pcg_oracle with use_c=False: bit-identical to the unmodified
     pcg_solver.py on every fixture); the C port of the mat-vec - ~2x slower per dof, round 3's `value` - stays as `c_port`.
@@ -320,7 +325,7 @@ def cpu_baseline(part, N, ranks=0, workload="brick", quick=False):
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     # sample size: ~12 s of solve at 60 % parallel efficiency, estimated from the one-core rate per dof
     per_dof_s = 1.0 / (single["value"] * single["dofs"]) if single else 4.5e-8
-    est = 0.6 * R / (per_dof_s * float(part["NDOF"]))
+    est = 0.6 * R / (per_dof_s * float(total_dofs or part["NDOF"]))       # (at N > 1 `part` is rank 0's part of the system)
     iters = int(max(10, min(400, 12.0 * est)))
     try:
         mp = mp_run(True, iters)
@@ -445,7 +450,7 @@ def pmc_traffic_live(args, segments):
     return out
 
 
-def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
+def octree_object(measure, log, with_cpu=False, cpu_ranks=0, iteration_roofline=None):
     """BASELINE configs[1] names "a synthetic 3D elasticity octree mesh, 1M DOFs": the multi-level graded octree mesh of
     pcg_mi355x.octree.GradedOctreeMesh (5 cell sizes, 2:1 balanced over faces / edges / corners; the hanging-node cells come in 95
     orientations of 7 patterns with 9-20 nodes besides hex8) on all three operators - iterations/s, operator time, what the formats
@@ -471,6 +476,8 @@ def octree_object(measure, log, with_cpu=False, cpu_ranks=0):
         e["roofline"] = {"bound": "hbm", "bytes_per_apply": by, "avg_apply_ms": mm["op_ms"], "achieved": by / t_op / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": by / t_op / 1e9 / HBM_PEAK_GBS, "flops_per_apply": fl, "frac_flops": fl / t_op / 1e12 / F64_PEAK_TFLOPS, "traffic": None,
                          "bytes_definition": "what the stored structures of one apply have to move (pcg_operator_cost), all launches of the apply together"}
+        if iteration_roofline is not None:
+            e["roofline_iteration"] = iteration_roofline(mm, 150)
         if kind in ("sell", "dict"):
             info = op.matrix_info()
             e["sell_padding"] = info["stored_blocks"] / max(1, info["nnzb"]) - 1
@@ -618,7 +625,7 @@ def main():
         roots = {"1m": (12, 12, 12), "10m": (38, 38, 38)}[args.octree_size]
         brick = GradedOctreeMesh(roots, 4, band=1.2, seed=0, symmetry=True)        # .n_dof like a Brick; nnz filled in after assembly
         grid = (world, 1, 1)
-        part = make_octree_parts(brick, world, elem_part=bisect_elements(brick, world) if world > 1 else None)[rank]
+        part = make_octree_parts(brick, world, elem_part=bisect_elements(brick, world) if world > 1 else None, only=[rank])[0]
         brick.nnz = None
         sm = brick.summary()
         wl_name = (f"multi-level 2:1-balanced octree mesh around a sphere, {sm['levels']} cell sizes, {sm['pattern_types']} pattern types in "
@@ -642,6 +649,23 @@ def main():
         box = [None] * world
         dist.all_gather_object(box, float(x))
         return max(box), box
+
+    def gather_sum(x):
+        if world == 1:
+            return float(x)
+        box = [None] * world
+        dist.all_gather_object(box, float(x))
+        return float(sum(box))
+
+    def iteration_roofline(mm, steps):
+        """The whole iteration against the HBM roofline (north_star: it/s "as fraction of HBM roofline"): the bytes an iteration has to
+        move - the stored operator of every rank (pcg_operator_cost) + 73 B/dof of the vector phase (p, q, r, x, M^-1 read, 1 flag
+        byte, r', x' written, p read and p' written) - over the measured time per step and the N GPUs' 8 TB/s each."""
+        t = mm["elapsed"] / steps
+        ach = mm["iter_bytes"] / t / 1e9
+        return {"bound": "hbm", "bytes_per_iteration": mm["iter_bytes"], "ms_per_step": t * 1e3, "achieved": ach, "peak": HBM_PEAK_GBS * world,
+                "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world),
+                "bytes_definition": "sum over the ranks of: stored operator bytes of one apply (pcg_operator_cost) + 73 B per local dof (vector phase)"}
 
     def measure(kind, part=part, steps=args.steps, warmup=args.warmup, standalone_reps=100):
         """Set up the operator of `kind`, run W warm-up + K timed PCG iterations, finish the solve."""
@@ -703,6 +727,7 @@ def main():
                    "frac": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                    "measured_in": "a second window of K iterations with events around every launch"}
         elapsed, per_rank = gather_max(elapsed_local)
+        iter_bytes = gather_sum(op.operator_cost()[0] + 73.0 * op.n)
         comm_info = None
         if world > 1 and getattr(comm, "native", False):   # second window: HIP events around the exchange wait / all-reduces
             s0 = comm.stats()
@@ -735,7 +760,7 @@ def main():
             ms = op.bench_spmv(10, standalone_reps)
             standalone = {"min_ms": float(ms.min()), "median_ms": float(np.median(ms))}
         return {"op": op, "elapsed": elapsed, "per_rank_s": per_rank, "op_ms": op_ms, "n_op": n_op, "final": final,
-                "standalone": standalone, "t_setup": t_setup, "comm": comm_info, "vec": vec}
+                "standalone": standalone, "t_setup": t_setup, "comm": comm_info, "vec": vec, "iter_bytes": iter_bytes}
 
     box = box_identity(dev) if rank == 0 else None
     stream = None
@@ -781,6 +806,7 @@ def main():
                           "value": args.steps / d["elapsed"], "unit": "iterations/s",
                           "ms_per_step": d["elapsed"] / args.steps * 1e3, "operator_avg_ms": d["op_ms"], "operator_launches_timed": d["n_op"],
                           "standalone_spmv": d["standalone"], "solve": d["final"], "comm": d["comm"], "vector_phase": d["vec"],
+                          "roofline_iteration": iteration_roofline(d, args.steps),
                           "roofline": {"kernel": "k_spmv_dict (SELL-64, 16-bit block index + column per stored block, table in LDS)",
                                        "avg_launch_ms": d["op_ms"], "bytes_per_launch": db, "achieved_GBps": db / t_op / 1e9,
                                        "peak_GBps": HBM_PEAK_GBS, "frac_hbm": db / t_op / 1e9 / HBM_PEAK_GBS,
@@ -813,6 +839,7 @@ def main():
                        "value": args.steps / e["elapsed"], "unit": "iterations/s", "ms_per_step": e["elapsed"] / args.steps * 1e3,
                        "operator_avg_ms": e["op_ms"], "operator_launches_timed": e["n_op"], "n_elem": oi["n_elem"], "n_chunks": oi["n_chunks"],
                        "standalone_operator": e["standalone"], "solve": e["final"], "comm": e["comm"], "vector_phase": e["vec"],
+                       "roofline_iteration": iteration_roofline(e, args.steps),
                        "roofline": {"kernel": "k_ebe_hexs / k_ebe_hex (a single 8-node pattern type) or k_ebe_mixed / k_ebe_mtile (several pattern types: mixed-type chunks, "
                                               "hex section on the vector FMAs or - below 1.2 M elements - colour-pure hex tiles, + matrix-core tiles) + k_ebe_shared = one operator apply", "avg_apply_ms": e["op_ms"],
                                     "flops_per_apply": ef, "achieved_TFLOPs": ef / t_op / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
@@ -826,6 +853,44 @@ def main():
                 stream = {"read_GBps": e["op"].bench_hbm(8 << 30, "read", 10), "copy_GBps": e["op"].bench_hbm(1 << 30, "copy")}
         e["op"].close()
 
+    # ---- north_star: "PCG-iterations/sec on a synthetic 3D elasticity octree mesh ... at 1/2/4/8 GPUs": the 10 M-dof graded octree mesh,
+    # split into one part per rank by recursive bisection (the METIS stand-in), assembled and matrix-free, on EVERY line (N = 1, 2, 4, 8)
+    octree10, opart10 = None, None
+    if args.workload == "brick" and args.operator == "both" and not args.no_octree and not args.no_finish:
+        try:
+            from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
+            t0 = time.perf_counter()
+            roots10 = tuple(int(v) for v in os.environ.get("PCG_BENCH_OCTREE10_ROOTS", "38,38,38").split(","))     # (tests shrink the mesh)
+            mesh10 = GradedOctreeMesh(roots10, 4, band=1.2, seed=0, symmetry=True)
+            opart10 = make_octree_parts(mesh10, world, elem_part=bisect_elements(mesh10, world) if world > 1 else None, only=[rank])[0]
+            octree10 = {"workload": f"multi-level 2:1-balanced octree mesh around a sphere (GradedOctreeMesh({roots10}, levels=4, band=1.2, symmetry=True)), "
+                                    f"Jacobi-PCG Tol 1e-7, {world} part(s) by recursive bisection of the element centroids, one per GPU",
+                        "mesh": mesh10.summary(), "dofs": int(mesh10.n_dof), "parts": world, "mesh_setup_s": time.perf_counter() - t0,
+                        "steps": args.steps, "warmup": args.warmup, "local_dofs_this_rank": int(opart10["NDOF"]),
+                        "interface_dofs_this_rank": int(sum(len(v) for v in opart10["OvrlpLocalDofVecList"]))}
+            del mesh10
+            for kind, key in (("sell", "assembled"), ("ebe", "matrix_free")):
+                mm = measure(kind, opart10, standalone_reps=20)
+                by, fl = mm["op"].operator_cost()
+                t_op = mm["op_ms"] * 1e-3
+                ent = {"value": args.steps / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / args.steps * 1e3,
+                       "per_rank_ms_per_step": [t / args.steps * 1e3 for t in mm["per_rank_s"]], "operator_avg_ms": mm["op_ms"],
+                       "vector_phase_ms": mm["vec"]["avg_launch_ms"] if mm["vec"] else None, "solve": mm["final"], "setup_s": mm["t_setup"],
+                       "comm": mm["comm"], "roofline_iteration": iteration_roofline(mm, args.steps),
+                       "roofline": {"bound": "hbm", "scope": "this rank's operator apply (all its launches)", "bytes_per_apply": by, "avg_apply_ms": mm["op_ms"],
+                                    "achieved": by / t_op / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t_op / 1e9 / HBM_PEAK_GBS,
+                                    "flops_per_apply": fl, "frac_flops": fl / t_op / 1e12 / F64_PEAK_TFLOPS, "traffic": None}}
+                if kind == "ebe":
+                    ent["operator_info"] = mm["op"].operator_info()
+                mm["op"].close()
+                octree10[key] = ent
+                if rank == 0:
+                    log(f"[octree 10 M dof, {world} part(s), {kind}] {ent['value']:.0f} it/s, operator {ent['operator_avg_ms']:.4f} ms, solve {ent['solve']}")
+            opart10.pop("_pcg_mi355x_operator", None)
+        except Exception as ex:          # noqa: BLE001 - the headline line must survive (a failure here is the same on every rank)
+            log(f"[rank {rank}] octree_10m object failed: {ex!r}")
+            octree10 = {"error": repr(ex)}
+
     def shutdown():
         part.pop("_pcg_mi355x_operator", None)
         if world > 1:
@@ -835,11 +900,21 @@ def main():
             dist.destroy_process_group()
 
     if world > 1:                                   # every rank's host set-up (its part + its operator), for the record
-        mine = {"rank": rank, "refmeshpart_s": round(t_parts, 2),
+        import resource
+        mine = {"rank": rank, "refmeshpart_s": round(t_parts, 2), "host_max_rss_GB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 2),
                 "operator_s": {k: round(v["t_setup"], 2) for k, v in (("sell", m), ("dict", dm), ("ebe", e)) if v is not None}}
         setup_all = [None] * world
         dist.all_gather_object(setup_all, mine)
+    CPU_DONE_KEY = "pcg_bench_rank0_done"
     if rank != 0:
+        # rank 0 now times the CPU baselines on the node's host cores: sleep on the rendezvous store (a socket wait) instead of
+        # spinning in a barrier next to the processes being timed
+        try:
+            import datetime
+            from torch.distributed.distributed_c10d import _get_default_store
+            _get_default_store().wait([CPU_DONE_KEY], datetime.timedelta(seconds=1500))
+        except Exception as ex:          # noqa: BLE001 - fall through to the barrier
+            log(f"[rank {rank}] store wait: {ex!r}")
         shutdown()
         return
 
@@ -887,6 +962,7 @@ def main():
                                    "kernel moves (it can exceed the HBM peak) - kept for comparison with CSR codes only",
             "standalone_spmv": m["standalone"]}
         out["roofline_vector_phase"] = m["vec"]
+        out["roofline_iteration"] = iteration_roofline(m, args.steps)
         if world == 1 and args.workload == "brick" and not args.no_finish:
             if scalar_point is not None:
                 out["roofline"]["scalar_csr_same_run"] = scalar_point
@@ -949,7 +1025,7 @@ def main():
             out["comm"].update(head["comm"])
     if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:
         try:
-            out["octree"] = octree_object(measure, log, with_cpu=not args.no_cpu_baseline, cpu_ranks=args.cpu_ranks)
+            out["octree"] = octree_object(measure, log, with_cpu=not args.no_cpu_baseline, cpu_ranks=args.cpu_ranks, iteration_roofline=iteration_roofline)
             for key, seg in (("assembled", "octree:sell"), ("matrix_free", "octree:ebe")):
                 if pmc_live and seg in pmc_live and key in out["octree"]:
                     r = out["octree"][key]["roofline"]
@@ -957,10 +1033,25 @@ def main():
         except Exception as ex:          # noqa: BLE001 - the headline line must survive
             log(f"octree object failed: {ex!r}")
             out["octree"] = {"error": repr(ex)}
-    if not args.no_cpu_baseline and world == 1:
+    if octree10 is not None:
+        out["octree_10m"] = octree10
+        if not args.no_cpu_baseline and "error" not in octree10 and "PCG_BENCH_OCTREE10_ROOTS" not in os.environ:
+            try:          # at most 16 processes: every one builds the 10 M-dof mesh for itself (3.6 GB at its peak)
+                octree10["cpu_baseline"] = cpu_baseline(opart10, "octree:10m", min(args.cpu_ranks or 16, 16), "octree", quick=True,
+                                                        total_dofs=octree10["dofs"])
+            except Exception as ex:      # noqa: BLE001
+                log(f"octree_10m CPU baseline failed: {ex!r}")
+    if not args.no_cpu_baseline:
         log("timing the CPU baseline (the reference's NumPy arithmetic: 1 core, then R processes x 1 thread; the C port beside it) ...")
-        out["cpu_baseline"] = cpu_baseline(part, N if args.workload == "brick" else f"octree:{args.octree_size}", args.cpu_ranks, args.workload)
+        out["cpu_baseline"] = cpu_baseline(part, N if args.workload == "brick" else f"octree:{args.octree_size}", args.cpu_ranks, args.workload,
+                                           quick=world > 1, total_dofs=brick.n_dof)
     print(json.dumps(out), flush=True)
+    if world > 1:
+        try:
+            from torch.distributed.distributed_c10d import _get_default_store
+            _get_default_store().set(CPU_DONE_KEY, "1")
+        except Exception as ex:          # noqa: BLE001
+            log(f"store set: {ex!r}")
     shutdown()
 
 

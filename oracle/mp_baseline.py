@@ -120,7 +120,7 @@ def worker(rank, R, N, iters, prefix, use_c):
     if isinstance(N, str) and N.startswith("octree:"):
         from pcg_mi355x.octree import GradedOctreeMesh, make_octree_parts, bisect_elements
         mesh = GradedOctreeMesh(OCTREE_ROOTS[N.split(":", 1)[1]], 4 if N != "octree:tiny" else 3, band=1.2, seed=0, symmetry=True)
-        P = make_octree_parts(mesh, R, elem_part=bisect_elements(mesh, R) if R > 1 else None)[rank]
+        P = make_octree_parts(mesh, R, elem_part=bisect_elements(mesh, R) if R > 1 else None, only=[rank])[0]
         del mesh
     else:
         brick = Brick(N, seed=0)

@@ -174,14 +174,26 @@ def test_real_rccl_across_gpus(gpu_lib, tmp_path, case, world):
 
 def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
     """`python bench.py --gpus 2` (no torchrun around it) spawns its two ranks itself.  On the 1-GPU box the ranks share
-    the device (PCG_BENCH_SHARE_GPU=1) and talk through the RCCL stand-in; the line it prints has the driver's shape."""
+    the device (PCG_BENCH_SHARE_GPU=1) and talk through the RCCL stand-in; the line it prints has the driver's shape AND
+    (round 5) what north_star asks of an N > 1 line: the octree series (`octree_10m`, here on a small mesh of the same generator),
+    the CPU baseline timed by rank 0 in the same run while the other ranks sleep on the store, `roofline_iteration` everywhere."""
     env = _env(True)
     env["PCG_BENCH_SHARE_GPU"] = "1"
+    env["PCG_BENCH_OCTREE10_ROOTS"] = "5,5,5"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
-                        "--nodes-per-side", "31", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--nodes-per-side", "31", "--cpu-ranks", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0
     assert out["comm"]["ranks"] == 2 and out["comm"]["transport"].startswith("native")
     assert out["solve"]["flag"] == 0
+    assert 0 < out["roofline_iteration"]["frac"] < 1 and out["roofline_iteration"]["peak"] == 16000.0
+    assert 0 < out["matrix_free"]["roofline_iteration"]["frac"] < 1
+    o10 = out["octree_10m"]
+    assert o10["parts"] == 2 and o10["mesh"]["pattern_types"] >= 5
+    for key in ("assembled", "matrix_free"):
+        assert o10[key]["value"] > 0 and o10[key]["solve"]["flag"] == 0 and len(o10[key]["per_rank_ms_per_step"]) == 2
+        assert 0 < o10[key]["roofline_iteration"]["frac"] < 1 and o10[key]["comm"]["exchanges_per_iter"] >= 1
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 2 and "2 parts" in cb["sample"]
