@@ -891,6 +891,26 @@ def main():
             log(f"[rank {rank}] octree_10m object failed: {ex!r}")
             octree10 = {"error": repr(ex)}
 
+    # ---- N > 1: the same brick windows with the engine-side reduction (opt-in pcg_comm_enable_mailbox: MPI_SUM through peer-mapped
+    # mailboxes inside the engine's own launches instead of ncclAllReduce) - an A/B beside the headline, which stays on RCCL.
+    # PCG_BENCH_MAILBOX=0 skips it.  Collective: every rank takes the same branch (enable_mailbox agrees on the outcome).
+    mailbox_ab = None
+    if world > 1 and getattr(comm, "native", False) and args.operator == "both" and os.environ.get("PCG_BENCH_MAILBOX", "1") != "0":
+        try:
+            if comm.enable_mailbox(True):
+                mailbox_ab = {"enabled": True, "note": "all-reduces through peer-mapped mailboxes (rank-order sums) inside k_fixup / k_vec; exchange unchanged"}
+                for kind, key in (("sell", "assembled"), ("ebe", "matrix_free")):
+                    mm = measure(kind)
+                    mailbox_ab[key] = {"value": args.steps / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / args.steps * 1e3,
+                                       "per_rank_ms_per_step": [t / args.steps * 1e3 for t in mm["per_rank_s"]], "solve": mm["final"], "comm": mm["comm"]}
+                    mm["op"].close()
+                comm.enable_mailbox(False)
+            else:
+                mailbox_ab = {"enabled": False, "reason": comm.mailbox_reason}
+        except Exception as ex:          # noqa: BLE001
+            log(f"[rank {rank}] mailbox A/B failed: {ex!r}")
+            mailbox_ab = {"enabled": False, "error": repr(ex)}
+
     def shutdown():
         part.pop("_pcg_mi355x_operator", None)
         if world > 1:
@@ -1023,6 +1043,8 @@ def main():
             out["comm"]["native_error"] = os.environ["PCG_BENCH_NATIVE_ERROR"]
         if head["comm"]:
             out["comm"].update(head["comm"])
+        if mailbox_ab is not None:
+            out["comm"]["mailbox"] = mailbox_ab
     if world == 1 and args.workload == "brick" and not args.no_octree and not args.no_finish:
         try:
             out["octree"] = octree_object(measure, log, with_cpu=not args.no_cpu_baseline, cpu_ranks=args.cpu_ranks, iteration_roofline=iteration_roofline)

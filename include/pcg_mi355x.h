@@ -49,8 +49,9 @@ typedef struct pcg_asm pcg_asm;
  * (pcg_mi355x/_lib.py and the C examples do).  History: 1 = round 1; 2 = pcg_group_*, pcg_comm_* (round 2);
  * 3 = pcg_comm_hooks.collective_exchange, pcg_result.vec_ms_sum / vec_count (round 3; a library of version < 3 called the
  * hooks of a part without neighbours unconditionally - since 3 only with collective_exchange != 0);
- * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4). */
-#define PCG_ABI_VERSION 4
+ * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4);
+ * 5 = pcg_comm_enable_mailbox(), pcg_group_enable_mailbox() (round 5; no struct changed). */
+#define PCG_ABI_VERSION 5
 int pcg_abi_version(void);
 const char *pcg_last_error(void);
 const char *pcg_backend_name(void);          /* "hip-gfx950" for the product library */
@@ -198,6 +199,19 @@ typedef struct {
 } pcg_comm_stats;
 int pcg_comm_set_timing(pcg_comm *c, int32_t on);
 int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out);
+/* Engine-side reduction (round 5, OPT-IN; RCCL's ncclAllReduce stays the default): MPI_SUM (pcg_solver.py:622-628; per iteration
+ * :487-488 and :504-507) through peer-mapped mailboxes.  Every rank owns a 2 KB mailbox in uncached device memory that every other
+ * rank maps (same process: the pointer + peer access; other processes: hipIpcMemHandle, exchanged through the communicator
+ * itself).  An all-reduce is then: write your values + a sequence number into every rank's mailbox (system-scope stores), poll
+ * your own for the n contributions, add them IN RANK ORDER - identical bits on every rank, the order of the reference's
+ * rank-ordered sum.  In the PCG loop this happens inside the launches that produce the operands (the last workgroup of the
+ * interface fix-up for p.Ap, of the vector update for the five sums): no collective kernel, no extra launch per iteration.
+ * COLLECTIVE: every rank of the communicator calls it, between solves.  *enabled_out = 1 on every rank or 0 on every rank: when any
+ * rank cannot map a peer (no peer access, IPC refused, ranks on different hosts, more than 16 ranks) or the self-test all-reduce
+ * returns wrong sums, all ranks keep using ncclAllReduce and pcg_last_error() says why (the call itself still returns 0).
+ * A poll that never sees a peer's contribution gives up after seconds, delivers NaN (the solve ends on it) and the next
+ * pcg_solve_* call on that communicator returns an error - nothing hangs.  on = 0 switches back to ncclAllReduce (collective too). */
+int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out);
 
 /* ---- operator-level calls (host vectors, length n) ----------------------------------------- */
 int pcg_apply(pcg_engine *e, const double *x, double *y);            /* y = A x, interface-summed */
@@ -281,6 +295,7 @@ int pcg_group_solve(pcg_group *g, const double *const *b, const double *const *x
                     double tol, int64_t max_iter, int64_t glob_n_eff, double *const *x_out, double *const *hist,
                     int64_t hist_cap, pcg_result *res /* n_dev results, may be NULL */);
 int pcg_group_set_timing(pcg_group *g, int32_t on);           /* pcg_comm_set_timing on every member */
+int pcg_group_enable_mailbox(pcg_group *g, int32_t on, int32_t *enabled_out);   /* pcg_comm_enable_mailbox on every member (one process: direct peer pointers) */
 
 /* ---- measurement / unit-test entry points --------------------------------------------------- */
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */

@@ -261,4 +261,16 @@ int pcg_group_set_timing(pcg_group *g, int32_t on)
     return g->run_all("pcg_group_set_timing", [&](int k) { return pcg_comm_set_timing(g->comm[k], on); });
 }
 
+int pcg_group_enable_mailbox(pcg_group *g, int32_t on, int32_t *enabled_out)
+{
+    if (!g) return set_error("pcg_group_enable_mailbox: null");
+    std::vector<int32_t> got((size_t)g->n, 0);
+    const int rc = g->run_all("pcg_group_enable_mailbox", [&](int k) { return pcg_comm_enable_mailbox(g->comm[k], on, &got[(size_t)k]); });
+    if (enabled_out) {
+        *enabled_out = 1;
+        for (int32_t v : got) if (!v) *enabled_out = 0;
+    }
+    return rc;
+}
+
 }  // extern "C"

@@ -1139,9 +1139,11 @@ public:
         d_last_cnt_ = (unsigned long long *)alloc(sizeof(unsigned long long) * 32);
         HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long) * 32, st_));
     }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq) override
+    bool mailbox_kernels_available() const override { return true; }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail) override
     {
         if (!nb_dofs_) {
+            if (mail) throw std::runtime_error("boundary_fixup: a part without interface dofs cannot carry the mailbox all-reduce");
             if (with_dot) { cnt_fix_ = 0; if (reduce_pq) reduce_dot(reduce_pq); }
             return;
         }
@@ -1151,9 +1153,16 @@ public:
             last_counters();
             fr.pa = ebe_ ? d_part_ebe_ : d_part_spmv_; fr.count_a = ebe_ ? cnt_ebe_ : cnt_spmv_;
             fr.red = reduce_pq; fr.counter = d_last_cnt_;
-            hipLaunchKernelGGL((k_fixup<true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, d_part_fix_, fr);
-        } else if (with_dot)
+            if (mail) {
+                fr.mail = *mail;
+                hipLaunchKernelGGL((k_fixup<true, true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
+                                   nb_dofs_, d_part_fix_, fr);
+            } else
+                hipLaunchKernelGGL((k_fixup<true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
+                                   nb_dofs_, d_part_fix_, fr);
+        } else if (mail)
+            throw std::runtime_error("boundary_fixup: the mailbox all-reduce rides on the fused dot reduction only");
+        else if (with_dot)
             hipLaunchKernelGGL((k_fixup<true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
                                nb_dofs_, d_part_fix_, fr);
         else
@@ -1266,8 +1275,9 @@ public:
     }
     bool vec_fused_available() const override { return vec_fused_ok_; }
     bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rn, const double *xo,
-                    double *xn, const double *minv, double *p_next, bool reduce_sums) override
+                    double *xn, const double *minv, double *p_next, bool reduce_sums, const MailDesc *mail) override
     {
+        if (mail && (p_next != nullptr || !reduce_sums)) throw std::runtime_error("vec_update: the mailbox all-reduce rides on the last-workgroup reduction only");
         const bool fused = p_next != nullptr;
         if (fused && !vec_fused_ok_) throw std::runtime_error("vec_update: the fused form is not available on this device");
         cnt_vec_ = vec_blocks(n_);
@@ -1284,6 +1294,7 @@ public:
         if (reduce_sums && !fused) {
             last_counters();
             a.reduce_last = 1; a.last_counter = d_last_cnt_ + 16;
+            if (mail) { a.mail_on = 1; a.mail = *mail; }
         }
         const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));

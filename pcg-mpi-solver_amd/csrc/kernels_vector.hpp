@@ -1,6 +1,7 @@
 // Vector-phase, interface and reduction kernels of the PCG iteration (reference: pcg_solver.py:447-516, :307-334).
 #pragma once
 #include "hip_common.hpp"
+#include "kernels_mail.hpp"
 
 namespace pcg {
 
@@ -90,9 +91,11 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
 // y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
 // REDUCE (with DOT): the last workgroup to finish sums the apply's dot partials - pa[0 .. count_a) of the operator launches, then
 // this launch's - in k_reduce's fixed order into red[0]: the p.Ap of the multi-part loop without a reduce launch.
-struct FixReduce { const double *pa; int count_a; double *red; unsigned long long *counter; };
+// MAIL (with REDUCE, round 5): that workgroup then all-reduces the sum across the ranks through the mailboxes (kernels_mail.hpp):
+// red[0] is the GLOBAL p.Ap (:487-488) when the launch is done.
+struct FixReduce { const double *pa; int count_a; double *red; unsigned long long *counter; MailDesc mail; };
 
-template <bool DOT, bool REDUCE = false>
+template <bool DOT, bool REDUCE = false, bool MAIL = false>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
                                                   const int *__restrict__ fptr, const int *__restrict__ fpos,
                                                   const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
@@ -118,7 +121,15 @@ __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const 
             if (threadIdx.x == 0) __hip_atomic_store(partials + blockIdx.x, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (last_workgroup(fr.counter, &flag)) {
                 const double tot = reduce_fixed_256<true>(fr.pa, fr.count_a, partials, (int)gridDim.x, lds);
-                if (threadIdx.x == 0) fr.red[0] = tot;
+                if constexpr (!MAIL) {
+                    if (threadIdx.x == 0) fr.red[0] = tot;
+                } else {
+                    __shared__ double m_in[kMailSlotWords], m_out[kMailSlotWords], m_tmp[kMailMaxRanks * kMailSlotWords];
+                    if (threadIdx.x == 0) m_in[0] = tot;
+                    __syncthreads();
+                    mail_allreduce(fr.mail, m_in, 1, m_out, m_tmp);
+                    if (threadIdx.x == 0) fr.red[0] = m_out[0];
+                }
             }
         }
     }
@@ -225,6 +236,8 @@ struct VecArgs {
     unsigned spin_limit;                  // FUSED: polls of the grid barrier before a workgroup gives up (2^22 = seconds; tests: PCG_TEST_VEC_SPINS)
     int reduce_last;                      // !FUSED: the last workgroup to finish reduces the five sums into st[SQP..NINF] (multi-part loop)
     unsigned long long *last_counter;     // ... its arrival counter (0 between launches: the last arriver resets it)
+    int mail_on;                          // ... and all-reduces them across the ranks through the mailboxes (round 5)
+    MailDesc mail;
     int64_t n;
 };
 
@@ -368,6 +381,16 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
                 double s5[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) s5[k] = reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, (int)gridDim.x, nullptr, 0, lds);
+                if (a.mail_on) {                                   // :504-507 across the ranks, inside this launch 
+                    __shared__ double m_in[kMailSlotWords], m_out[kMailSlotWords], m_tmp[kMailMaxRanks * kMailSlotWords];
+                    if (tid == 0)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) m_in[k] = s5[k];
+                    __syncthreads();
+                    mail_allreduce(a.mail, m_in, 5, m_out, m_tmp);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) s5[k] = m_out[k];
+                }
                 if (tid == 0)
 #pragma unroll
                     for (int k = 0; k < 5; ++k) { a.st[ST_SQP + k] = s5[k]; if (a.mirror) a.mirror[ST_SQP + k] = s5[k]; }

@@ -188,14 +188,26 @@ struct pcg_engine {
     // y = A x with the interface sum (:242-336).  Interface rows first, exchange overlapped with
     // the interior rows, then the neighbour contributions are added in neighbour order (:333-334).
     // reduce_pq != null (multi-part loop, with_dot): the interface fix-up launch also reduces the apply's dot partials into that
-    // word and the interface rows' launch writes the send buffer itself (Backend::spmv pack_send) - returns true when p.Ap has
-    // been reduced that way (a part without neighbours, or dot partials outside the fused epilogues: the caller reduces)
-    bool apply(const double *x, double *y, bool with_dot, double *reduce_pq = nullptr)
+    // word and the interface rows' launch writes the send buffer itself (Backend::spmv pack_send).  mail (round 5, with reduce_pq):
+    // the same launch then all-reduces p.Ap across the ranks through the communicator's mailboxes.
+    // -> 0: the caller reduces the dot partials (a part without neighbours, or partials outside the fused epilogues);
+    //    1: reduce_pq[0] holds this rank's p.Ap;  2: reduce_pq[0] holds the GLOBAL p.Ap (no all-reduce call needed)
+    int apply(const double *x, double *y, bool with_dot, double *reduce_pq = nullptr, bool mail = false)
     {
         const bool fold = reduce_pq != nullptr && with_dot;
+        MailDesc md{};
+        // the descriptor is drawn exactly when the fix-up launch will carry the all-reduce: every all-reduce of the job - fused or
+        // not - takes ONE number of the communicator's sequence on every rank
+        auto fixup = [&](bool dot, bool fused_here) {
+            const bool m = mail && fold && fused_here;
+            if (m) md = comm->mailbox_next();
+            be->boundary_fixup(y, d_recv, x, dot, fold && fused_here ? reduce_pq : nullptr, m ? &md : nullptr);
+            return m ? 2 : (fold && fused_here ? 1 : 0);
+        };
         if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
             if (with_dot) be->begin_dot();
             bool fused;
+            int state = 0;
             if (!has_halo) {
                 fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0);
                 empty_exchange();
@@ -207,18 +219,18 @@ struct pcg_engine {
                 be->halo_pack(y, d_send);
                 halo_begin();
                 halo_end();
-                be->boundary_fixup(y, d_recv, x, with_dot && fused, fold && fused ? reduce_pq : nullptr);
+                state = fixup(with_dot && fused, fused);
             } else {
                 fused = be->ebe_apply(x, y, 0, 1, true, with_dot, n_bnd_dofs);
                 be->halo_pack(y, d_send);
                 halo_begin();
                 be->ebe_apply(x, y, 1, 2, false, with_dot, n_bnd_dofs);
                 halo_end();
-                be->boundary_fixup(y, d_recv, x, with_dot && fused, fold && fused ? reduce_pq : nullptr);   // interface dofs: + neighbours, their dot
+                state = fixup(with_dot && fused, fused);       // interface dofs: + neighbours, their dot
             }
             ebe_dot_fused = with_dot && fused;
             if (with_dot && !fused) be->dot_w(x, y);          // :487 (pattern types without the fused epilogue)
-            return fold && fused && has_halo;
+            return state;
         }
         if (with_dot) be->begin_dot();
         if (!has_halo) {
@@ -229,8 +241,7 @@ struct pcg_engine {
             halo_begin();                                     // :318-326
             be->spmv(x, y, n_bnd_slices, n_slices, with_dot);
             halo_end();                                       // :328
-            be->boundary_fixup(y, d_recv, x, with_dot, fold ? reduce_pq : nullptr);   // :332-334 (+ dot over the interface slices, + :487)
-            return fold;
+            return fixup(with_dot, true);                     // :332-334 (+ dot over the interface slices, + :487, + :488 with mailboxes)
         } else {
             be->spmv(x, y, 0, n_bnd_slices, false);
             be->halo_pack(y, d_send);                         // :307-309
@@ -239,7 +250,7 @@ struct pcg_engine {
             halo_end();                                       // :328
             be->boundary_fixup(y, d_recv, x, with_dot);       // :332-334 (+ dot over the interface slices)
         }
-        return false;
+        return 0;
     }
     void halo_sum(double *y)
     {
@@ -297,20 +308,28 @@ struct pcg_engine {
         // where round 3 ran ten stream operations (k_halo_pack, two k_reduce and k_publish on their own).  Same arithmetic, same
         // orders of summation: bit-identical histories (tests: gloo, the in-process communicator, the RCCL stand-in).
         const bool fold = multi() && be->iteration_fusion_available();
+        // round 5 (opt-in, pcg_comm_enable_mailbox): both all-reduces of the iteration inside the launches that produce their operands
+        const bool mail = fold && comm && comm->mailbox_enabled() && be->mailbox_kernels_available();
         int publish_with_p = -1;
         if (fold && pending_publish >= 0 && !p_ready) { publish_with_p = pending_publish; pending_publish = -1; }
         flush_publish();                                                    // (no update_p to carry it: a launch of its own)
         be->set_status_slot(slot);
         if (!p_ready) be->update_p(p_cur, p_prev, r_in, s.minv, d_st, rho_prev, first, publish_with_p);   // :447, :472-479
-        const bool pq_reduced = apply(p_cur, v_q, true, fold ? d_st + ST_PQ : nullptr);   // :482-484 (+ :487 when folded in)
+        const int pq_state = apply(p_cur, v_q, true, fold ? d_st + ST_PQ : nullptr, mail);   // :482-484 (+ :487 / :488 when folded in)
         int pq_src = 2;                                                     // :487-498 inside the vector launch
         if (multi() || (kind == 1 && !ebe_dot_fused)) {
-            if (!pq_reduced) reduce_apply_dot(d_st + ST_PQ);                // :487
-            allreduce(d_st + ST_PQ, 1);                                     // :488
+            if (pq_state == 0) reduce_apply_dot(d_st + ST_PQ);              // :487
+            if (pq_state < 2) allreduce(d_st + ST_PQ, 1);                   // :488
             pq_src = 1;
         }
-        if (be->vec_update(d_st, pq_src, p_cur, v_q, r_in, r_out, x_in, x_out, s.minv, p_next, fold)) {   // :501-516 (+ :447-479 of i+1)
+        MailDesc md5{};
+        if (mail) md5 = comm->mailbox_next();
+        if (be->vec_update(d_st, pq_src, p_cur, v_q, r_in, r_out, x_in, x_out, s.minv, p_next, fold, mail ? &md5 : nullptr)) {   // :501-516 (+ :447-479 of i+1)
             be->publish_status(false);                                      // the sums are already in the block and its mirror
+            return;
+        }
+        if (mail) {                                                         // :507 happened inside the launch: block and mirror hold the
+            be->publish_status(false);                                      // global sums, nothing rewrites them afterwards
             return;
         }
         if (!fold) be->reduce_update(d_st + ST_SQP);
@@ -466,6 +485,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
 
 void fill_result(pcg_engine *e, pcg_result *res)
 {
+    if (e->comm) e->comm->mailbox_check();          // a mailbox poll gave up during this solve: an error, not a result
     if (!res) return;
     auto &s = e->s;
     std::memset(res, 0, sizeof(*res));
@@ -976,6 +996,17 @@ int pcg_comm_set_timing(pcg_comm *c, int32_t on)
     return guarded("pcg_comm_set_timing", [&]() -> int {
         if (!c || !c->impl) return set_error("pcg_comm_set_timing: null");
         c->impl->set_timing(on != 0);
+        return 0;
+    });
+}
+
+int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out)
+{
+    return guarded("pcg_comm_enable_mailbox", [&]() -> int {
+        if (!c || !c->impl) return set_error("pcg_comm_enable_mailbox: null");
+        const bool ok = c->impl->enable_mailbox(on != 0);
+        if (enabled_out) *enabled_out = ok ? 1 : 0;
+        if (on && !ok) (void)set_error("pcg_comm_enable_mailbox: staying with ncclAllReduce - " + c->impl->mailbox_why());
         return 0;
     });
 }

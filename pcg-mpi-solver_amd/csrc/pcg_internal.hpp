@@ -247,6 +247,26 @@ enum { ST_RHO = 0, ST_PQ = 1, ST_ALPHA = 2, ST_STOP = 3, ST_SQP = 4, ST_SQX = 5,
        ST_RHO_NEXT = 7, ST_NINF = 8, ST_ERR = 9 /* the fused vector kernel's grid barrier timed out */, ST_COUNT = 16 };
 constexpr int kStatusSlots = 4;          // status ring of the solve loop's look-ahead (2 would do; 4 keeps slots apart)
 
+// ---- engine-side all-reduce through peer-mapped mailboxes (round 5, opt-in: pcg_comm_enable_mailbox) -------------------------
+// MPI_SUM (pcg_solver.py:622-628) without a collective kernel: every rank owns a small mailbox in device memory that every other
+// rank has mapped (same process: the pointer itself + peer access; other processes: hipIpcOpenMemHandle).  All-reduce number
+// `seq` of a communicator: a rank writes its values and then `seq` (release, system scope) into slot [seq & 1][its rank] of EVERY
+// rank's mailbox, polls the slots [seq & 1][0 .. n) of its own until each carries `seq` (acquire) and sums them IN RANK ORDER -
+// the same bits on every rank, and the order of the oracle's _allreduce.  Two parities suffice: a rank can start all-reduce
+// q + 1 while a peer still reads q, but nobody starts q + 2 before every rank has contributed to q + 1, i.e. finished reading q.
+// The exchange runs INSIDE the launch that produced the values (the last workgroup of k_fixup / k_vec<false>) or as a one-wave
+// kernel of its own (k_mail_allreduce) - no ncclAllReduce launch on the critical path of an iteration.
+constexpr int kMailMaxRanks = 16;
+constexpr int kMailSlotWords = 8;                  // 64 B per (parity, source rank): [0] = seq, [1 .. 7] = values
+constexpr int kMailMaxCount = kMailSlotWords - 1;
+struct MailDesc {                                  // passed BY VALUE to the kernels
+    double *peer[kMailMaxRanks];                   // peer[r]: rank r's mailbox as mapped here; peer[rank] = this rank's own
+    unsigned *err;                                 // host-visible word: != 0 after a poll gave up (the result is NaN then)
+    unsigned long long seq;                        // number of THIS all-reduce (1, 2, ...: every rank issues the same sequence)
+    int rank, n;
+    unsigned spin_limit;
+};
+
 struct HaloHost {
     int32_t n_peers = 0;
     std::vector<int32_t> peer_ids;
@@ -305,7 +325,10 @@ public:
     // interface rows: y[d] += sum recv[...] (neighbour order); optional dot over the boundary-slice rows
     // reduce_pq != null (with_dot): the LAST workgroup of this launch to finish also sums every dot partial of the apply - the
     // operator launches' and this one's, in reduce_dot()'s fixed order - into reduce_pq[0]: no reduce launch
-    virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq = nullptr) = 0;
+    // mail != null (with reduce_pq): that last workgroup then also all-reduces the sum ACROSS THE RANKS through the mailboxes -
+    // reduce_pq[0] is the global p.Ap when the launch is done, no all-reduce call follows
+    virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq = nullptr,
+                                const MailDesc *mail = nullptr) = 0;
     // forget the dot partials of earlier launches (call before an apply that wants the fused dot)
     virtual void begin_dot() = 0;
     // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
@@ -339,8 +362,12 @@ public:
     //          st[SQP..NINF] and forms the next search direction p_next = z + (rho' / rho) p (:475-479); returns true.
     //   reduce_sums (with p_next == null): the last workgroup to finish reduces the five partial sums into st[SQP..NINF] itself
     //          (reduce_update()'s fixed order): no reduce launch before the all-reduce
+    //   mail (with reduce_sums): ... and all-reduces them across the ranks through the mailboxes: st[SQP..NINF] and its mirror hold
+    //          the GLOBAL sums when the launch is done
     virtual bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r_old, double *r_new,
-                            const double *x_old, double *x_new, const double *minv, double *p_next, bool reduce_sums = false) = 0;
+                            const double *x_old, double *x_new, const double *minv, double *p_next, bool reduce_sums = false,
+                            const MailDesc *mail = nullptr) = 0;
+    virtual bool mailbox_kernels_available() const { return false; }       // the two launches above can take `mail`
     // the multi-part loop may fold pack / the two reductions / the status copy into the neighbouring launches (PCG_ITER_FUSED=0: no)
     virtual bool iteration_fusion_available() const { return false; }
     virtual bool vec_fused_available() const { return false; }
@@ -390,6 +417,14 @@ public:
     virtual void allreduce(double *buf, int count, void *compute_stream) = 0;
     virtual void set_timing(bool on) = 0;           // HIP events around the waits (the reference's dT_CommWait, :631-641)
     virtual CommStats stats() = 0;                  // synchronises the streams it reads events from
+    // Mailbox all-reduce (MailDesc above).  enable_mailbox() is COLLECTIVE: the ranks exchange their mailboxes' handles, map them,
+    // run one all-reduce of known values through them and agree on the outcome - false (on every rank) when any rank could not
+    // map a peer (no peer access, IPC refused, more than kMailMaxRanks ranks): allreduce() keeps using the collective library.
+    virtual bool enable_mailbox(bool on) { (void)on; return false; }
+    virtual bool mailbox_enabled() const { return false; }
+    virtual MailDesc mailbox_next() { return MailDesc{}; }   // the descriptor of the NEXT all-reduce (advances the sequence)
+    virtual void mailbox_check() {}                          // throws when a poll has timed out since the last call
+    virtual std::string mailbox_why() const { return "this communicator has no mailbox all-reduce"; }   // why enable_mailbox() said no
 };
 // defined by the HIP side of the product library; the CPU test double has no native communicator
 std::unique_ptr<Comm> make_rccl_comm(int device, int rank, int nranks, const void *unique_ids /* 2 x 128 B */);

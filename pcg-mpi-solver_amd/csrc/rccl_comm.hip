@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,8 @@
 #include <string>
 #include <vector>
 
+#define PCG_MAIL_STANDALONE_KERNEL
+#include "kernels_mail.hpp"
 #include "pcg_internal.hpp"
 
 #define HIP_CHECK(expr)                                                                                  \
@@ -149,6 +152,34 @@ class RcclComm : public Comm {
     bool allow_self_ = std::getenv("PCG_RCCL_ALLOW_SELF") != nullptr;
     EventRing t_halo_, t_red_;
     CommStats st_;
+    // ---- mailbox all-reduce (pcg_internal.hpp MailDesc, kernels_mail.hpp; opt-in through enable_mailbox) ------------------------
+    static constexpr size_t kBoxBytes = sizeof(double) * 2 * kMailMaxRanks * kMailSlotWords;
+    double *box_ = nullptr;                          // this rank's mailbox: uncached device memory, mapped by every peer
+    double *peer_box_[kMailMaxRanks] = {};           // every rank's mailbox as seen from here
+    bool peer_ipc_[kMailMaxRanks] = {};              // opened with hipIpcOpenMemHandle (to be closed)
+    unsigned *mail_err_ = nullptr;                   // pinned, mapped: a poll timed out
+    unsigned long long mail_seq_ = 0;
+    bool mail_on_ = false;
+    unsigned mail_spins_ = 1u << 21;                 // polls of ~0.1 - 1 us each: seconds
+    std::string mail_why_;                           // why enable_mailbox() said no (this rank's view)
+
+    void release_mailbox()
+    {
+        for (int r = 0; r < kMailMaxRanks; ++r) {
+            if (peer_ipc_[r] && peer_box_[r]) (void)hipIpcCloseMemHandle(peer_box_[r]);
+            peer_box_[r] = nullptr; peer_ipc_[r] = false;
+        }
+        if (box_) { (void)hipFree(box_); box_ = nullptr; }
+        if (mail_err_) { (void)hipHostFree(mail_err_); mail_err_ = nullptr; }
+        mail_on_ = false;
+    }
+    // sum over the ranks of `count` doubles at dev (in place) through the reduction communicator, host-synchronous
+    void boot_allreduce(double *dev, size_t count)
+    {
+        RcclApi &A = api();
+        NCCL_CHECK(A.AllReduce(dev, dev, count, ncclDouble, ncclSum, red_comm_, comm_stream_));
+        HIP_CHECK(hipStreamSynchronize(comm_stream_));
+    }
 
 public:
     RcclComm(int device, int rank, int nranks, const void *ids) : dev_(device), rank_(rank), size_(nranks)
@@ -176,6 +207,7 @@ public:
     {
         (void)hipSetDevice(dev_);
         if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
+        release_mailbox();
         t_halo_.destroy(); t_red_.destroy();
         try {
             RcclApi &A = api();
@@ -227,15 +259,138 @@ public:
         if (timing_) t_halo_.end(k, cs);                                    // ... to here = time blocked in the exchange
         open_fence_ = -1;
     }
+    // COLLECTIVE.  Every step that can fail locally only raises `fail`; the ranks compare notes through the reduction communicator
+    // (which works, or nothing does) and take the same decision - a rank never leaves the others inside a collective.
+    bool enable_mailbox(bool on) override
+    {
+        HIP_CHECK(hipSetDevice(dev_));
+        if (!on) { mail_on_ = false; return false; }
+        if (mail_on_) return true;
+        if (size_ > kMailMaxRanks) { mail_why_ = "more than 16 ranks"; return false; }
+        if (const char *e = std::getenv("PCG_MAIL_SPINS")) mail_spins_ = (unsigned)std::max(1, atoi(e));
+        constexpr int R = 72;                       // record per rank: ok, pid, host id, device, pointer in 4 x 16 bits, 64 handle bytes
+        double fail = 0;
+        auto soft = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && fail == 0) { fail = 1; mail_why_ = std::string(what) + " -> " + hipGetErrorString(e); (void)hipGetLastError(); }
+            return e == hipSuccess;
+        };
+        release_mailbox();
+        if (!soft(hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached)")) {
+            fail = 0; mail_why_.clear();
+            soft(hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(fine-grained)");
+        }
+        if (box_) soft(hipMemset(box_, 0, kBoxBytes), "hipMemset(mailbox)");
+        soft(hipHostMalloc((void **)&mail_err_, sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(mailbox error word)");
+        if (mail_err_) *mail_err_ = 0;
+        hipIpcMemHandle_t h;
+        std::memset(&h, 0, sizeof(h));
+        static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+        if (box_) soft(hipIpcGetMemHandle(&h, box_), "hipIpcGetMemHandle");
+        // ---- exchange: one all-reduce over size x R doubles, every rank fills its own record (bytes as exactly representable doubles)
+        std::vector<double> rec((size_t)size_ * R, 0.0);
+        double *mine = rec.data() + (size_t)rank_ * R;
+        const unsigned long long ptr = (unsigned long long)(uintptr_t)box_;
+        mine[0] = 1; mine[1] = (double)getpid(); mine[2] = (double)(unsigned)gethostid(); mine[3] = dev_;
+        for (int k = 0; k < 4; ++k) mine[4 + k] = (double)((ptr >> (16 * k)) & 0xffffull);
+        for (int k = 0; k < 64; ++k) mine[8 + k] = (double)((const unsigned char *)&h)[k];
+        double *d_rec = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d_rec, sizeof(double) * (rec.size() + 8)));
+        HIP_CHECK(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+        boot_allreduce(d_rec, rec.size());
+        HIP_CHECK(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        // ---- map every peer's mailbox
+        for (int r = 0; r < size_ && fail == 0; ++r) {
+            const double *q = rec.data() + (size_t)r * R;
+            if (r == rank_) { peer_box_[r] = box_; continue; }
+            if (q[0] != 1.0) { fail = 1; mail_why_ = "rank " + std::to_string(r) + " sent no record"; break; }
+            if (q[2] != mine[2]) { fail = 1; mail_why_ = "rank " + std::to_string(r) + " runs on another host"; break; }
+            const int pdev = (int)q[3];
+            if (q[1] == mine[1]) {                                      // same process (device group, threads): the pointer itself
+                unsigned long long p = 0;
+                for (int k = 0; k < 4; ++k) p |= (unsigned long long)q[4 + k] << (16 * k);
+                if (pdev != dev_) {
+                    int can = 0;
+                    soft(hipDeviceCanAccessPeer(&can, dev_, pdev), "hipDeviceCanAccessPeer");
+                    if (fail == 0 && !can) { fail = 1; mail_why_ = "no peer access from device " + std::to_string(dev_) + " to " + std::to_string(pdev); }
+                    if (fail == 0) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+                        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                        else soft(e, "hipDeviceEnablePeerAccess");
+                    }
+                }
+                peer_box_[r] = (double *)(uintptr_t)p;
+            } else {                                                    // another process: IPC mapping
+                hipIpcMemHandle_t ph;
+                for (int k = 0; k < 64; ++k) ((unsigned char *)&ph)[k] = (unsigned char)q[8 + k];
+                void *p = nullptr;
+                if (soft(hipIpcOpenMemHandle(&p, ph, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) { peer_box_[r] = (double *)p; peer_ipc_[r] = true; }
+            }
+        }
+        // ---- agree, then prove it: one all-reduce of known values through the mailboxes
+        double *d_flag = d_rec + rec.size();
+        HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
+        boot_allreduce(d_flag, 1);
+        double any = 0;
+        HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
+        bool good = any == 0;
+        if (good) {
+            double v[kMailMaxCount];
+            for (int k = 0; k < kMailMaxCount; ++k) v[k] = (double)((rank_ + 1) * (k + 1));
+            HIP_CHECK(hipMemcpy(d_rec, v, sizeof(v), hipMemcpyHostToDevice));
+            mail_on_ = true;
+            const MailDesc m = mailbox_next();
+            hipLaunchKernelGGL(k_mail_allreduce, dim3(1), dim3(64), 0, comm_stream_, d_rec, kMailMaxCount, m);
+            fail = hipGetLastError() != hipSuccess || hipStreamSynchronize(comm_stream_) != hipSuccess;
+            if (fail == 0) {
+                HIP_CHECK(hipMemcpy(v, d_rec, sizeof(v), hipMemcpyDeviceToHost));
+                for (int k = 0; k < kMailMaxCount; ++k)
+                    if (v[k] != (double)((k + 1) * size_ * (size_ + 1) / 2)) fail = 1;
+                if (*mail_err_) { fail = 1; *mail_err_ = 0; }
+                if (fail != 0) mail_why_ = "the mailbox self-test returned wrong sums (peer stores not visible?)";
+            } else {
+                mail_why_ = "the mailbox self-test kernel failed";
+            }
+            HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
+            boot_allreduce(d_flag, 1);
+            HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
+            good = any == 0;
+        }
+        (void)hipFree(d_rec);
+        if (!good) {
+            if (mail_why_.empty()) mail_why_ = "another rank could not map a mailbox";
+            release_mailbox();
+        }
+        return good;
+    }
+    bool mailbox_enabled() const override { return mail_on_; }
+    MailDesc mailbox_next() override
+    {
+        MailDesc m{};
+        for (int r = 0; r < size_; ++r) m.peer[r] = peer_box_[r];
+        m.err = mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.spin_limit = mail_spins_;
+        st_.n_allreduce++;                          // (every all-reduce draws exactly one descriptor, fused into a launch or not)
+        return m;
+    }
+    void mailbox_check() override
+    {
+        if (mail_err_ && *mail_err_) { *mail_err_ = 0; throw std::runtime_error("mailbox all-reduce: a peer's values never arrived (poll timed out)"); }
+    }
+    std::string mailbox_why() const override { return mail_why_; }
     void allreduce(double *buf, int count, void *compute_stream) override
     {
         RcclApi &A = api();
         hipStream_t cs = (hipStream_t)compute_stream;
         int k = -1;
         if (timing_) k = t_red_.begin(cs);
-        NCCL_CHECK(A.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, red_comm_, cs));   // :625
+        if (mail_on_ && count <= kMailMaxCount) {                       // :625 through the mailboxes: a one-wave kernel
+            const MailDesc m = mailbox_next();
+            hipLaunchKernelGGL(k_mail_allreduce, dim3(1), dim3(64), 0, cs, buf, count, m);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            NCCL_CHECK(A.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, red_comm_, cs));   // :625
+            st_.n_allreduce++;
+        }
         if (timing_) t_red_.end(k, cs);
-        st_.n_allreduce++;
     }
     void set_timing(bool on) override
     {

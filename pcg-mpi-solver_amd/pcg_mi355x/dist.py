@@ -137,6 +137,19 @@ class RcclComm:
         _lib.check(_lib.lib().pcg_comm_get_stats(self._h, C.byref(st)), "pcg_comm_get_stats")
         return {k: getattr(st, k) for k, _ in _lib.CommStats._fields_}
 
+    def enable_mailbox(self, on=True):
+        """Opt-in, COLLECTIVE (every rank, between solves): MPI_SUM (pcg_solver.py:622-628) through peer-mapped mailboxes inside the
+        engine's own launches instead of ncclAllReduce (include/pcg_mi355x.h pcg_comm_enable_mailbox).  -> True when every rank
+        mapped every peer and the self-test passed; False (on every rank) = ncclAllReduce stays, `mailbox_reason` says why."""
+        got = C.c_int32(0)
+        _lib.check(_lib.lib().pcg_comm_enable_mailbox(self._h, 1 if on else 0, C.byref(got)), "pcg_comm_enable_mailbox")
+        self.mailbox = bool(got.value)
+        self.mailbox_reason = None if (self.mailbox or not on) else (_lib.lib().pcg_last_error() or b"").decode(errors="replace")
+        return self.mailbox
+
+    mailbox = False
+    mailbox_reason = None
+
     def reraise(self):          # no callbacks, nothing to re-raise
         pass
 

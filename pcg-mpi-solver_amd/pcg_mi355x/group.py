@@ -182,6 +182,13 @@ class DeviceGroup:
     def set_timing(self, on=True):
         check(self._L.pcg_group_set_timing(self._h, 1 if on else 0), "pcg_group_set_timing")
 
+    def enable_mailbox(self, on=True):
+        """pcg_comm_enable_mailbox on every member (one process: the members see each other's mailboxes through plain peer
+        pointers) -> True when all of them switched."""
+        got = C.c_int32(0)
+        check(self._L.pcg_group_enable_mailbox(self._h, 1 if on else 0, C.byref(got)), "pcg_group_enable_mailbox")
+        return bool(got.value)
+
     def close(self):
         """Engines first, then the group (its communicators must outlive the engines they are attached to)."""
         for k, op in enumerate(self.ops):

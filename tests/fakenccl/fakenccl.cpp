@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kMaxRanks = 16;
 constexpr size_t kPairBytes = 8u << 20;             // capacity of one (source, destination) mailbox
-constexpr int kRedMax = 64;                         // doubles per all-reduce
+constexpr int kRedMax = 2048;                       // doubles per all-reduce (the mailbox bootstrap exchanges 72 per rank)
 
 struct Mailbox {
     std::atomic<uint64_t> full;                     // sequence number of the message in `data` (0 = empty)

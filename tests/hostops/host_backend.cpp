@@ -11,6 +11,7 @@
 #include <cstring>
 #include <stdexcept>
 
+#include "host_mail.hpp"
 #include "pcg_internal.hpp"
 
 namespace pcg {
@@ -307,9 +308,12 @@ public:
     {
         for (size_t m = 0; m < h_.send_idx.size(); ++m) send[m] = y[h_.send_idx[m]];
     }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq) override
+    bool mailbox_kernels_available() const override { return true; }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail) override
     {
-        struct ReduceAtExit { HostBackend *b; double *r; ~ReduceAtExit() { if (r) b->reduce_dot(r); } } reduce_at_exit{this, with_dot ? reduce_pq : nullptr};
+        if (mail && (h_.fix_dof.empty() || !with_dot || !reduce_pq)) throw std::runtime_error("boundary_fixup: mailbox all-reduce without the fused reduction");
+        struct ReduceAtExit { HostBackend *b; double *r; const MailDesc *m; ~ReduceAtExit() { if (r) { b->reduce_dot(r); if (m) host_mail_allreduce(*m, r, 1); } } }
+            reduce_at_exit{this, with_dot ? reduce_pq : nullptr, mail};
         for (size_t k = 0; k < h_.fix_dof.size(); ++k) {
             double v = y[h_.fix_dof[k]];
             for (int64_t q = h_.fix_ptr[k]; q < h_.fix_ptr[k + 1]; ++q) v += recv[h_.fix_pos[q]];
@@ -368,9 +372,12 @@ public:
     const int64_t vec_err_at_ = std::getenv("PCG_TEST_VEC_ERR_AT") ? std::atoll(std::getenv("PCG_TEST_VEC_ERR_AT")) : -1;
     void vec_fused_failed() override { fused_broken_ = true; st_[ST_ERR] = 0.0; }
     bool vec_update(double *st, int pq_src, const double *p, const double *q, const double *r, double *rnew, const double *xo,
-                    double *xn, const double *minv, double *p_next, bool reduce_sums) override
+                    double *xn, const double *minv, double *p_next, bool reduce_sums, const MailDesc *mail) override
     {
-        struct ReduceAtExit { HostBackend *b; double *st; bool on; ~ReduceAtExit() { if (on) b->reduce_update(st + ST_SQP); } } reduce_at_exit{this, st, reduce_sums && !p_next};
+        if (mail && (p_next || !reduce_sums)) throw std::runtime_error("vec_update: mailbox all-reduce without the last-workgroup reduction");
+        struct ReduceAtExit { HostBackend *b; double *st; bool on; const MailDesc *m;
+                              ~ReduceAtExit() { if (on) { b->reduce_update(st + ST_SQP); if (m) host_mail_allreduce(*m, st + ST_SQP, 5); } } }
+            reduce_at_exit{this, st, reduce_sums && !p_next, mail};
         const double rho = st[ST_RHO_NEXT];
         if (pq_src == 2) reduce_dot(st + ST_PQ);
         if (pq_src) scalar_alpha(st);

@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "host_mail.hpp"
 #include "pcg_internal.hpp"
 
 namespace pcg {
@@ -35,6 +36,8 @@ struct World {
     int arrived = 0, left = 0;
     int64_t gen = 0;
     int attached = 0;
+    std::vector<double *> mail;                                             // every rank's mailbox (enable_mailbox)
+    int mail_registered = 0;
 };
 
 std::mutex g_reg_m;
@@ -48,6 +51,11 @@ class LocalComm : public Comm {
     double *recv_ = nullptr;
     const HaloHost *halo_ = nullptr;
     CommStats st_;
+    // mailbox all-reduce (pcg_internal.hpp MailDesc; the protocol of csrc/kernels_mail.hpp on host memory)
+    std::vector<unsigned long long> box_;
+    bool mail_on_ = false;
+    unsigned long long mail_seq_ = 0;
+    unsigned mail_err_ = 0;
 
 public:
     LocalComm(int rank, int nranks, const void *ids) : rank_(rank), size_(nranks)
@@ -106,8 +114,42 @@ public:
         }
         halo_ = nullptr;
     }
+    bool enable_mailbox(bool on) override
+    {
+        if (!on) { mail_on_ = false; return false; }
+        if (mail_on_) return true;
+        if (size_ > kMailMaxRanks) return false;
+        box_.assign((size_t)2 * kMailMaxRanks * kMailSlotWords, 0ull);
+        std::unique_lock<std::mutex> lk(w_->m);
+        w_->mail.resize(size_, nullptr);
+        w_->mail[rank_] = reinterpret_cast<double *>(box_.data());
+        w_->mail_registered++;
+        w_->cv.notify_all();
+        if (!w_->cv.wait_for(lk, kTimeout, [&] { return w_->mail_registered >= size_; }))
+            throw std::runtime_error("local comm: a peer never registered its mailbox");
+        mail_on_ = true;
+        return true;
+    }
+    bool mailbox_enabled() const override { return mail_on_; }
+    MailDesc mailbox_next() override
+    {
+        MailDesc m{};
+        for (int r = 0; r < size_; ++r) m.peer[r] = w_->mail[r];
+        m.err = &mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.spin_limit = 0;
+        st_.n_allreduce++;
+        return m;
+    }
+    void mailbox_check() override
+    {
+        if (mail_err_) { mail_err_ = 0; throw std::runtime_error("local comm: a mailbox poll timed out"); }
+    }
     void allreduce(double *buf, int count, void *) override                                 // :622-628
     {
+        if (mail_on_) {
+            if (count > kMailMaxCount) throw std::runtime_error("local comm: mailbox all-reduce of more than 7 values");
+            host_mail_allreduce(mailbox_next(), buf, count);
+            return;
+        }
         st_.n_allreduce++;
         std::unique_lock<std::mutex> lk(w_->m);
         // a generation is open for deposits only after every rank has left the previous one

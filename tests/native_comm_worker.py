@@ -173,6 +173,12 @@ def main():
     from pcg_mi355x.dist import RcclComm
     _lib.use_library(os.environ.get("PCG_TEST_LIB") or None)      # (PCG_TEST_LIB: the CPU double, for the harness check of the no-GPU tier)
     timing = os.environ.get("PCG_TEST_COMM_TIMING", "1") == "1"
+    mailbox = os.environ.get("PCG_TEST_MAILBOX", "0") == "1"       # opt-in engine-side reduction (pcg_comm_enable_mailbox), collective
+
+    def with_mailbox(comm):
+        if mailbox and not comm.mailbox:
+            assert comm.enable_mailbox(), f"mailbox all-reduce refused: {comm.mailbox_reason}"
+        return comm
     if mode == "threads":
         cases, kinds, outdir = sys.argv[2].split(","), sys.argv[3].split(","), sys.argv[4]
         for case in cases:
@@ -186,7 +192,7 @@ def main():
                 def run(r):
                     try:
                         if comms[r] is None:
-                            comms[r] = RcclComm(r, world, 0, uid)          # collective: all threads are in here together
+                            comms[r] = with_mailbox(RcclComm(r, world, 0, uid))          # collective: all threads are in here together
                         P = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in parts[r].items()}
                         outs[r] = run_rank(P, probe[P["DofVector"]], comms[r], kind, 0, timing)
                     except BaseException as e:      # noqa: BLE001
@@ -219,6 +225,8 @@ def main():
                 devs = [int(d) for d in devs.split(",")] if devs else [0] * world
                 gs = GroupSolver(parts, devices=devs, operator=kind, timing=timing)
                 try:
+                    if mailbox:
+                        assert gs.group.enable_mailbox(), "mailbox all-reduce refused in the device group"
                     ys = gs.group.apply([probe[P["DofVector"]] for P in parts])
                     ds = gs.group.diag()
                     s0 = [c.stats() for c in gs.group.comms]
@@ -242,7 +250,7 @@ def main():
         device = int(sys.argv[8]) if len(sys.argv) > 8 else 0
         parts, probe = build(case)
         assert len(parts) == world
-        comm = RcclComm.from_file(rank, world, device, idfile, launch_id=os.path.basename(idfile))    # (a fresh file name per test launch)
+        comm = with_mailbox(RcclComm.from_file(rank, world, device, idfile, launch_id=os.path.basename(idfile)))    # (a fresh file name per test launch)
         P = parts[rank]
         o = run_rank(P, probe[P["DofVector"]], comm, kind, device, timing)
         np.savez(os.path.join(outdir, f"{case}_{kind}_rank{rank}.npz"), **o)

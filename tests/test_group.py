@@ -27,7 +27,7 @@ def _global(parts, key_or_list, n):
     return out
 
 
-def _run_case(case, kind, devices=None):
+def _run_case(case, kind, devices=None, mailbox=False):
     from pcg_mi355x.group import GroupSolver
     mesh, parts = golden_cases.build_case(case)
     g = golden(case)
@@ -35,6 +35,8 @@ def _run_case(case, kind, devices=None):
     probe = golden_cases.probe_for(mesh, parts)
     gs = GroupSolver(parts, devices=devices, operator=kind, timing=True)
     try:
+        if mailbox:
+            assert gs.group.enable_mailbox(), "the mailbox all-reduce did not come up"
         ys = gs.group.apply([probe[P["DofVector"]] for P in parts])
         ds = gs.group.diag()
         assert relerr(_global(parts, ys, n), g["y_probe"]) < 1e-13
@@ -85,8 +87,32 @@ def test_group_is_bit_identical_to_one_thread_per_part_over_the_callback_seam(ho
         assert np.array_equal(A["Un"], B["Un"])
 
 
+def mailbox_reduction_is_bit_identical(cases=("n9_p8", "oct_p3", "n13_t3_p4_ud", "n9_p2_flag4", "goct_p4"), kinds=("sell", "ebe")):
+    """Round 5, opt-in pcg_comm_enable_mailbox: MPI_SUM (pcg_solver.py:622-628) through peer-mapped mailboxes - p.Ap inside
+    the interface fix-up launch, the five sums inside the vector launch, every other all-reduce by a one-wave kernel - summed in rank
+    order like the collective it replaces in these runs: histories, exits and solutions bit for bit, every fixture still reproduced."""
+    for case in cases:
+        for kind in kinds:
+            parts_a, infos_a = _run_case(case, kind)
+            parts_b, infos_b = _run_case(case, kind, mailbox=True)
+            for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b):
+                assert (a.flag, a.iter, a.relres, a.iters_done) == (b.flag, b.iter, b.relres, b.iters_done), (case, kind)
+                assert np.array_equal(a.history, b.history), (case, kind)
+                assert np.array_equal(pa["Un"], pb["Un"]), (case, kind)
+
+
+def test_mailbox_reduction_is_bit_identical_on_the_test_double(hostops, monkeypatch):
+    mailbox_reduction_is_bit_identical()
+    monkeypatch.setenv("PCG_ITER_FUSED", "0")          # no last-workgroup reductions to ride on: every all-reduce by its own kernel
+    mailbox_reduction_is_bit_identical(cases=("n9_p8", "oct_p3"))
+    monkeypatch.delenv("PCG_ITER_FUSED")
+    monkeypatch.setenv("PCG_LOOK_AHEAD", "0")
+    mailbox_reduction_is_bit_identical(cases=("n9_p8",))
+
+
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
-def test_group_with_a_member_without_neighbours(hostops, kind):
+@pytest.mark.parametrize("mailbox", [False, True])
+def test_group_with_a_member_without_neighbours(hostops, kind, mailbox):
     """A disconnected component as its own part: the member takes part in every all-reduce but in no exchange - the native
     exchange is point-to-point like the reference's Isend/Recv loops over an empty NbrMPIdVector (pcg_solver.py:318-328).
     Against the oracle's run of the same three parts."""
@@ -98,6 +124,8 @@ def test_group_with_a_member_without_neighbours(hostops, kind):
     parts = island_parts()
     gs = GroupSolver(parts, operator=kind)
     try:
+        if mailbox:        # the island member has no fix-up launch to carry p.Ap: its all-reduce is the one-wave kernel, same sequence number
+            assert gs.group.enable_mailbox()
         gs.updateBC(); gs.updatePreconditioner(); gs.PCG()
         i0 = parts[0]["_pcg_mi355x_info"]
         assert i0.flag == out["flag"] == 0 and abs(i0.iter - out["iter"]) <= 1

@@ -114,6 +114,62 @@ def test_parts_as_threads_on_one_gpu(gpu_lib, tmp_path, cases):
             _check(case, kind, tmp_path, world)
 
 
+def _same_bits(case, kind, dir_a, dir_b, world):
+    for r in range(world):
+        a = np.load(os.path.join(dir_a, f"{case}_{kind}_rank{r}.npz"))
+        b = np.load(os.path.join(dir_b, f"{case}_{kind}_rank{r}.npz"))
+        for key in ("flag", "iter", "relres", "iters_done", "history", "Un", "y_probe", "diag", "Fext"):
+            assert np.array_equal(a[key], b[key]), (case, kind, r, key)
+
+
+@pytest.mark.parametrize("mode", ["threads", "group"])
+def test_mailbox_reduction_on_one_gpu(gpu_lib, tmp_path, mode):
+    """Round 5, opt-in pcg_comm_enable_mailbox (csrc/kernels_mail.hpp, rccl_comm.hip): MPI_SUM (pcg_solver.py:622-628) through peer-mapped
+    uncached device mailboxes - p.Ap inside k_fixup<DOT, REDUCE, MAIL>, the five sums inside k_vec<false>, the rest by k_mail_allreduce -
+    instead of ncclAllReduce.  2 - 8 ranks as threads of one process / as members of one device group (peer pointers), exchange still
+    through the native communicator: every fixture reproduced, and bit-identical to the run with the stand-in's rank-ordered
+    all-reduce (same order of summation)."""
+    cases = "n9_p8,oct_p3,n13_t3_p4_ud,n9_p2_flag4" if mode == "threads" else "n9_p8,goct_p4"
+    dirs = {}
+    for mb in ("0", "1"):
+        d = tmp_path / f"mb{mb}"
+        d.mkdir()
+        env = _env(True)
+        env["PCG_TEST_MAILBOX"] = mb
+        r = subprocess.run([sys.executable, WORKER, mode, cases, "sell,ebe", str(d)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        dirs[mb] = d
+    for case in cases.split(","):
+        world = len([f for f in os.listdir(dirs["1"]) if f.startswith(case + "_sell_rank")])
+        for kind in ("sell", "ebe"):
+            _check(case, kind, dirs["1"], world)
+            _same_bits(case, kind, dirs["0"], dirs["1"], world)
+
+
+@pytest.mark.parametrize("case,world,kind", [("n9_p2", 2, "sell"), ("oct_p3", 3, "ebe"), ("n9_p8", 8, "sell")])
+def test_mailbox_reduction_between_processes_sharing_one_gpu(gpu_lib, tmp_path, monkeypatch, case, world, kind):
+    """The production shape: one process per rank, the mailboxes mapped through hipIpcMemHandle (exchanged through the communicator
+    itself) - here all on device 0."""
+    dirs = {}
+    for mb in ("0", "1"):
+        d = tmp_path / f"mb{mb}"
+        d.mkdir()
+        monkeypatch.setenv("PCG_TEST_MAILBOX", mb)
+        _run_procs(case, kind, world, d, True, [0] * world)
+        dirs[mb] = d
+    _check(case, kind, dirs["1"], world)
+    _same_bits(case, kind, dirs["0"], dirs["1"], world)
+
+
+def test_mailbox_on_real_rccl_world_size_1(gpu_lib, tmp_path, monkeypatch):
+    """Real librccl carries the bootstrap exchange of the handles and the agreement all-reduces (world size 1 on this box)."""
+    monkeypatch.setenv("PCG_TEST_MAILBOX", "1")
+    r = subprocess.run([sys.executable, WORKER, "proc", "n9_p1", "ebe", str(tmp_path), "0", "1", str(tmp_path / "idmb")], env={**_env(False), "PCG_TEST_MAILBOX": "1"},
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    _check("n9_p1", "ebe", tmp_path, 1)
+
+
 def check_big_brick_report(rep, kinds, iters):
     """The gates of the multi-part parity test at a BASELINE size (also run at a small size on the CPU double, test_dist_gloo.py)."""
     assert rep["parts"] == 8
@@ -172,6 +228,17 @@ def test_real_rccl_across_gpus(gpu_lib, tmp_path, case, world):
         _check(case, kind, tmp_path, world)
 
 
+@pytest.mark.parametrize("case,world", [("n9_p2", 2), ("n13_t3_p4_ud", 4), ("n9_p8", 8)])
+def test_mailbox_reduction_across_gpus(gpu_lib, tmp_path, monkeypatch, case, world):
+    """The mailboxes between DIFFERENT GPUs (hipIpcMemHandle + peer access over xGMI), exchange on real RCCL; auto-skipped on the one-GPU box."""
+    if gpu_lib.lib().pcg_device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    monkeypatch.setenv("PCG_TEST_MAILBOX", "1")
+    for kind in ("sell", "ebe"):
+        _run_procs(case, kind, world, tmp_path, False, list(range(world)))
+        _check(case, kind, tmp_path, world)
+
+
 def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
     """`python bench.py --gpus 2` (no torchrun around it) spawns its two ranks itself.  On the 1-GPU box the ranks share
     the device (PCG_BENCH_SHARE_GPU=1) and talk through the RCCL stand-in; the line it prints has the driver's shape AND
@@ -197,3 +264,6 @@ def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
         assert 0 < o10[key]["roofline_iteration"]["frac"] < 1 and o10[key]["comm"]["exchanges_per_iter"] >= 1
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 2 and "2 parts" in cb["sample"]
+    mb = out["comm"]["mailbox"]                       # the engine-side reduction beside the RCCL windows: same sums in the same order here
+    assert mb["enabled"] and mb["assembled"]["value"] > 0 and mb["matrix_free"]["value"] > 0
+    assert (mb["assembled"]["solve"]["flag"], mb["assembled"]["solve"]["iter"]) == (out["solve"]["flag"], out["solve"]["iter"])

@@ -6,7 +6,8 @@ multi-part loop on the real RCCL at world size 1: its neighbours are folded into
 so the interface rows' launch, the pack, the grouped ncclSend / ncclRecv on the communication stream, the fix-up and both
 ncclAllReduce run as they would on 8 GPUs, minus the wire.  (The exchange returns the part's own partial sums, i.e. the operator
 is not the assembled one: timing only - the window is short and checked for an early exit.)
-usage: python tools/multi_part_iter.py [N] [steps] [kinds] [modes]      modes: PCG_ITER_FUSED values switched per solve (default 1,0)"""
+usage: python tools/multi_part_iter.py [N] [steps] [kinds] [modes]      modes: PCG_ITER_FUSED values switched per solve (default 1,0);
+       "m" = the five-launch form with the engine-side reduction (pcg_comm_enable_mailbox: no ncclAllReduce kernel; round 5)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -35,7 +36,8 @@ for kind in kinds:
     inv = op.build_jacobi()
     for rep in range(2):
         for fused in modes:
-            os.environ["PCG_ITER_FUSED"] = fused
+            os.environ["PCG_ITER_FUSED"] = "1" if fused == "m" else fused
+            assert comm.enable_mailbox(fused == "m") == (fused == "m"), comm.mailbox_reason
             op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
             op.solve_run(5)
             torch.cuda.synchronize(); t0 = time.perf_counter()
