@@ -170,6 +170,9 @@ def cpu_baseline_single(part, budget_s=10.0):
     import numpy as np
     import pcg_oracle
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    if len(part.get("NbrMPIdVector", ())) > 0:            # N > 1: rank 0's part has neighbours - not a system on its own
+        from pcg_mi355x.brick import Brick, make_parts
+        part = make_parts(Brick(70, seed=0))[0]
     P = {k: v for k, v in part.items() if not k.startswith("_pcg_mi355x")}
     P["GlobData"] = copy.deepcopy(part["GlobData"])
     P["Un"] = np.zeros(P["NDOF"])
@@ -183,7 +186,7 @@ def cpu_baseline_single(part, budget_s=10.0):
     out = pcg_oracle.pcg([P], use_c=True, record=False)
     t = time.perf_counter() - t0
     return {"value": m / t, "unit": "iterations/s", "cores": 1,
-            "sample": f"first {m} PCG iterations of the same system ({out['n_matvec']} EBE mat-vecs), 1 process x 1 thread",
+            "sample": f"first {m} PCG iterations of a {P['NDOF']}-dof system ({out['n_matvec']} EBE mat-vecs), 1 process x 1 thread", "dofs": int(P["NDOF"]),
             "matvec_ms": t_mv * 1e3}
 
 
@@ -220,10 +223,12 @@ def numpy_reference_point(part, budget_s=12.0):
     import numpy as np
     import pcg_oracle
     note = "the bench's own part"
-    if part["NDOF"] > 4_000_000:
+    if part["NDOF"] > 4_000_000 or len(part.get("NbrMPIdVector", ())) > 0:
         from pcg_mi355x.brick import Brick, make_parts
+        why = ("the bench's system is too large for a bounded NumPy sample" if part["NDOF"] > 4_000_000 else
+               "at N > 1 rank 0 holds one part of the system, and a part with neighbours is not a system on its own")
         part = make_parts(Brick(70, seed=0))[0]
-        note = "1 M-dof brick (N = 70) of the same generator: the bench's system is too large for a bounded NumPy sample"
+        note = f"1 M-dof brick (N = 70) of the same generator: {why}"
     P = {k: v for k, v in part.items() if not k.startswith("_pcg_mi355x")}
     P["GlobData"] = copy.deepcopy(part["GlobData"])
     P["Un"] = np.zeros(P["NDOF"])

@@ -628,38 +628,61 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         if (mix_shells && M.hex_group >= 0)
             std::stable_partition(L.begin(), L.end(), [&](const ElemRef &r) { return r.g == M.hex_group; });
         std::vector<int32_t> cnt_type(M.types.size(), 0);
-        size_t lo_ = 0;
-        int n_run_nodes = 0, n_hex = 0, n_tl = 0;
-        int32_t run_id = next_stamp++;
-        bool prev_hex = !L.empty() && L[0].g == M.hex_group;
-        for (size_t k = 0; k < L.size(); ++k) {
-            const auto &in = gs[L[k].g];
-            const bool is_hex = L[k].g == M.hex_group || (M.hex_tile_type >= 0 && type_of[L[k].g] == M.hex_tile_type);   // (counted against the hex slots)
-            const int t = is_hex ? -1 : type_of[L[k].g];
-            auto stamp_new = [&](int32_t id, bool mark) {            // nodes of element k the run `id` does not hold yet
-                int fresh = 0;
-                for (int l = 0; l < in.nd / 3; ++l) {
-                    const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
-                    if (stamp[node] != id) { if (mark) stamp[node] = id; ++fresh; }
+        // cut the Morton order into runs that respect the caps; `out(lo, hi)` takes each run (emit it, or just count it)
+        auto cut_runs = [&](int cap, auto &&out) {
+            std::fill(cnt_type.begin(), cnt_type.end(), 0);
+            size_t lo_ = 0;
+            int n_run_nodes = 0, n_hex = 0, n_tl = 0;
+            int32_t run_id = next_stamp++;
+            bool prev_hex = !L.empty() && L[0].g == M.hex_group;
+            for (size_t k = 0; k < L.size(); ++k) {
+                const auto &in = gs[L[k].g];
+                const bool is_hex = L[k].g == M.hex_group || (M.hex_tile_type >= 0 && type_of[L[k].g] == M.hex_tile_type);   // (counted against the hex slots)
+                const int t = is_hex ? -1 : type_of[L[k].g];
+                auto stamp_new = [&](int32_t id, bool mark) {            // nodes of element k the run `id` does not hold yet
+                    int fresh = 0;
+                    for (int l = 0; l < in.nd / 3; ++l) {
+                        const int64_t node = new_node(in.dof[(int64_t)(3 * l) * in.ne + L[k].e]);
+                        if (stamp[node] != id) { if (mark) stamp[node] = id; ++fresh; }
+                    }
+                    return fresh;
+                };
+                const int fresh = stamp_new(run_id, false);
+                const bool new_tile = !is_hex && cnt_type[t] % 16 == 0;
+                const bool kind_change = mix_shells && is_hex != prev_hex;
+                prev_hex = is_hex;
+                if (k > lo_ && (kind_change || n_run_nodes + fresh > cap || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
+                    out(lo_, k);
+                    lo_ = k;
+                    run_id = next_stamp++;
+                    n_run_nodes = n_hex = n_tl = 0;
+                    std::fill(cnt_type.begin(), cnt_type.end(), 0);
                 }
-                return fresh;
-            };
-            const int fresh = stamp_new(run_id, false);
-            const bool new_tile = !is_hex && cnt_type[t] % 16 == 0;
-            const bool kind_change = mix_shells && is_hex != prev_hex;
-            prev_hex = is_hex;
-            if (k > lo_ && (kind_change || n_run_nodes + fresh > node_cap || (is_hex && n_hex + 1 > hex_cap) || (new_tile && n_tl + 1 > tile_cap))) {
-                emit_or_split(lo_, k);
-                lo_ = k;
-                run_id = next_stamp++;
-                n_run_nodes = n_hex = n_tl = 0;
-                std::fill(cnt_type.begin(), cnt_type.end(), 0);
+                n_run_nodes += stamp_new(run_id, true);
+                if (is_hex) ++n_hex;
+                else { if (cnt_type[t] % 16 == 0) ++n_tl; ++cnt_type[t]; }
             }
-            n_run_nodes += stamp_new(run_id, true);
-            if (is_hex) ++n_hex;
-            else { if (cnt_type[t] % 16 == 0) ++n_tl; ++cnt_type[t]; }
+            if (lo_ < L.size()) out(lo_, L.size());
+        };
+        // Meshes whose chunks do not fill the GPU once (round 5): a launch then lasts as long as ONE chunk's chain of phases - staging,
+        // its tiles wave after wave, the write-out - however many CUs idle beside it (1 M-dof octree mesh: 661 chunks of ~25 tiles for
+        // 1 024 resident workgroups).  Smaller chunks shorten the chain: the node cap is lowered until the mesh makes about
+        // PCG_EBE_TARGET_CHUNKS chunks (default kMixedTargetChunks; 0 = off), never below kMixedMinNodeCap.  Large meshes keep 768.
+        int64_t target_chunks = kMixedTargetChunks;
+        if (const char *tv = std::getenv("PCG_EBE_TARGET_CHUNKS")) target_chunks = std::max(0, std::atoi(tv));
+        if (!std::getenv("PCG_EBE_NODE_CAP") && target_chunks > 0 && M.hex_tile_type >= 0) {
+            auto count = [&](int cap) { int64_t n = 0; cut_runs(cap, [&](size_t, size_t) { ++n; }); return n; };
+            if (count(node_cap) < target_chunks) {
+                int lo_cap = kMixedMinNodeCap / 16, hi_cap = node_cap / 16;          // smallest cap (x 16) whose chunk count stays <= target
+                while (lo_cap < hi_cap) {
+                    const int mid = (lo_cap + hi_cap) / 2;
+                    if (count(16 * mid) <= target_chunks) hi_cap = mid; else lo_cap = mid + 1;
+                }
+                node_cap = 16 * hi_cap;
+            }
         }
-        if (lo_ < L.size()) emit_or_split(lo_, L.size());
+        C.node_cap_used = node_cap;
+        cut_runs(node_cap, [&](size_t a, size_t b) { emit_or_split(a, b); });
     }
 
     // Chunks = octree-like cells: the spatially sorted element list of a group is split recursively at

@@ -140,6 +140,8 @@ constexpr int kMixedClass = 5;
 constexpr int kMixedHexSlots = 512;                // hex8 element slots of a mixed chunk (two passes of 256 threads)
 constexpr int64_t kMixedHexTilesBelow = 1200000;   // mixed chunks: below this many elements the 8-node type runs in matrix-core tiles too (ebe.cpp)
 constexpr int kMixedMaxTiles = 24;                 // 16-element tiles of the other pattern types per mixed chunk
+constexpr int kMixedTargetChunks = 0;              // mixed chunks, hex tiles: lower the node cap of small meshes until they make about this many chunks (0 = off)
+constexpr int kMixedMinNodeCap = 256;
 constexpr int kMixedFragAhead = 4;                 // k-steps whose matrix fragments k_ebe_mixed requests ahead of their instructions
 struct EbeClassHost {
     int32_t nnp = 8;                   // padded nodes per element; the kernel is instantiated for NDP = 3*nnp
@@ -220,6 +222,7 @@ struct EbeChunkedHost {
     std::vector<int32_t> sh_slot[2];   //            slots in ascending chunk order; node-major numbering: sh_slot[ph][q] ==
                                        //            (ph ? sh_ptr[0].back() : 0) + q, so a device kernel needs no slot list
     bool needs_zero = false;           // some node is touched by no chunk (isolated, or only by non-chunked groups)
+    int32_t node_cap_used = 0;         // mixed chunks: the node cap the planner cut the runs with (kChunkMaxNodes unless lowered for a small mesh)
     EbeClassHost cls[kChunkClasses];
     EbeMixedHost mixed;
     int32_t max_subcolors = 0;
