@@ -910,8 +910,8 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
                 for (int c = 1; c <= 16; ++c) fprintf(stderr, " %lld", (long long)hist[c]);
                 fprintf(stderr, "\n");
             }
-            fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots\n", (long long)n_nodes,
-                    (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots);
+            fprintf(stderr, "ebe plan: %lld nodes, %lld shared nodes with %lld boundary slots; %lld chunks (node cap of the mixed chunks %d)\n", (long long)n_nodes,
+                    (long long)(C.sh_node[0].size() + C.sh_node[1].size()), (long long)C.n_slots, (long long)C.n_chunks, C.node_cap_used);
         }
     }
 }

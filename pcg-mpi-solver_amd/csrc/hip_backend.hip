@@ -44,6 +44,18 @@ class HipBackend : public Backend {
     hipStream_t st2_[kChunkClasses] = {}, ls_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_[kChunkClasses] = {};
     int ebe_streams_mode_ = 0;                   // 1: PCG_EBE_STREAMS=1
+    // Round 5, multi-part loop (PCG_EBE_PHASE_STREAMS): the INTERIOR phase of a split matrix-free apply on a side stream beside the
+    // interface phase.  Kernel timeline of a 1.32 M-dof part (profiles/r05_multi_part_timeline_sessionC.md): the interface chunks (175
+    // workgroups on 256 CUs) last 21 us - one chunk's chain of phases, as long as a full launch - and the interior launch (24 us) used
+    // to wait behind them, the shared-node sums and the pack.  The two launches touch disjoint nodes and boundary slots and fit the
+    // GPU together (904 of 1 024 resident workgroups): side by side the interior phase would hide behind interface phase + exchange.
+    // MEASURED AND LOST (session d, same box, alternating processes): 122 - 125 us per iteration with the side stream against 115 - 117
+    // without (profiles/r05_ab_phase_streams_sessionD.log) - the fork and the join are two more cross-stream waits per apply, and a wait
+    // between streams costs this runtime more than the 17 us the overlap could return (the finding of PCG_EBE_STREAMS again).  Opt-in.
+    hipStream_t st_phase_ = nullptr;
+    hipEvent_t ev_phase_fork_ = nullptr, ev_phase_join_ = nullptr;
+    int ebe_phase_streams_ = 0;
+    bool phase_forked_ = false;
     // matrix
     int bs_ = 3;
     int64_t n_nodes_ = 0, n_ = 0, n_slices_ = 0, n_bnd_slices_ = 0;
@@ -171,6 +183,9 @@ public:
         }
         ls_ = st_;
         if (const char *e = getenv("PCG_EBE_STREAMS")) ebe_streams_mode_ = atoi(e) != 0 ? 1 : 0;
+        HIP_CHECK(hipStreamCreateWithFlags(&st_phase_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_phase_fork_, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_phase_join_, hipEventDisableTiming));
         if (const char *e = getenv("PCG_EBE_ROWS_LDS")) rows_lds_mode_ = atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("PCG_EBE_XCD")) ebe_xcd_ = std::max(0, atoi(e));
         d_part_ = (double *)alloc(sizeof(double) * 5 * kMaxPartials);
@@ -180,6 +195,8 @@ public:
         // CU, asked of the occupancy query here; PCG_VEC_FUSED=0 keeps the split form (k_vec<false> + k_reduce + k_update_p)
         d_vec_sync_ = (unsigned long long *)alloc(sizeof(unsigned long long) * kVecSyncWords);
         HIP_CHECK(hipMemsetAsync(d_vec_sync_, 0, sizeof(unsigned long long) * kVecSyncWords, st_));
+        d_vec_pub_ = (double *)alloc(sizeof(double) * 2 * 5 * kMaxPartials);         // in-band form: every slot starts as the sentinel
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d_vec_pub_, (int)kVecSentinelHalf, (size_t)2 * 2 * 5 * kMaxPartials, st_));
         {
             int per_cu = 0;
             const hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_vec<true>, kVecBlock, 0);
@@ -199,7 +216,7 @@ public:
         (void)hipSetDevice(dev_);
         for (void *p : {(void *)d_bidx_, (void *)d_dict_, (void *)d_slice_ptr_, (void *)d_cols_, (void *)d_cols16_, (void *)d_colbase_, (void *)d_vals_, (void *)d_diag_, (void *)d_flags_,
                         (void *)d_send_idx_, (void *)d_fptr_, (void *)d_fpos_, (void *)d_part_, (void *)d_part_spmv_,
-                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_last_cnt_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
+                        (void *)d_part_fix_, (void *)d_vec_sync_, (void *)d_vec_pub_, (void *)d_last_cnt_, (void *)d_ptr4_, (void *)d_ov_slice_ptr_, (void *)d_ov_rows_, (void *)d_ov_cols_,
                         (void *)d_ov_vals_, (void *)d_ov_mask_, (void *)d_win_slice_, (void *)d_win_ov_})
             if (p) (void)hipFree(p);
         for (auto &D : chc_)
@@ -221,6 +238,9 @@ public:
             for (auto e : ev_slot_) (void)hipEventDestroy(e);
         }
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        if (ev_phase_fork_) (void)hipEventDestroy(ev_phase_fork_);
+        if (ev_phase_join_) (void)hipEventDestroy(ev_phase_join_);
+        if (st_phase_) (void)hipStreamDestroy(st_phase_);
         for (int c = 1; c < kChunkClasses; ++c) {
             if (ev_join_[c]) (void)hipEventDestroy(ev_join_[c]);
             if (st2_[c]) (void)hipStreamDestroy(st2_[c]);
@@ -880,6 +900,18 @@ public:
         const bool rec = prof_ && ev_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(ev0_[ev_used_], st_));
         if (zero_first && ch_needs_zero_) HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n_, st_));
+        // split apply of the multi-part loop: ebe_apply(0, 1) .. pack, exchange begun .. ebe_apply(1, 2).  With phase streams the second
+        // call runs on st_phase_, ordered behind everything that was on st_ BEFORE the first call's launches (x is complete, y zeroed).
+        hipStream_t ks = st_;                                   // stream of this call's chunk and shared-node launches
+        if (plo == 0 && phi == 1) {
+            phase_forked_ = ebe_phase_streams_ != 0 && !prof_ && ebe_ranges_[0].empty() && ebe_ranges_[1].empty();
+            if (phase_forked_) HIP_CHECK(hipEventRecord(ev_phase_fork_, st_));
+        } else if (plo == 1 && phi == 2 && phase_forked_) {
+            HIP_CHECK(hipStreamWaitEvent(st_phase_, ev_phase_fork_, 0));
+            ks = st_phase_;
+        } else {
+            phase_forked_ = false;
+        }
         for (int ph = plo; ph < phi; ++ph) {                    // chunked groups: one launch per phase + shared-node sums
             int others = 0;
             for (int c = 1; c < kChunkClasses; ++c) others += chc_[c].count[ph] > 0;
@@ -893,7 +925,7 @@ public:
             for (int c = 0; c < kChunkClasses; ++c) {            // one launch per node-count class
                 const auto &D = chc_[c];
                 if (!D.count[ph]) continue;
-                ls_ = (fork && c > 0) ? st2_[c] : st_;
+                ls_ = (fork && c > 0) ? st2_[c] : ks;
                 const int np = launch_class(D, ph, x, y, fuse, d_part_ebe_ + cnt_ebe_, dot_lo);
                 if (fuse) cnt_ebe_ += np;
             }
@@ -902,19 +934,24 @@ public:
                 for (int c = 1; c < kChunkClasses; ++c)
                     if (chc_[c].count[ph]) {
                         HIP_CHECK(hipEventRecord(ev_join_[c], st2_[c]));
-                        HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[c], 0));
+                        HIP_CHECK(hipStreamWaitEvent(ks, ev_join_[c], 0));
                     }
             if (sh_count_[ph]) {
                 const int grid = (3 * sh_count_[ph] + kBlock - 1) / kBlock;
                 double *part = d_part_ebe_ + cnt_ebe_;
                 if (fuse)
-                    hipLaunchKernelGGL((k_ebe_shared<true>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
+                    hipLaunchKernelGGL((k_ebe_shared<true>), dim3(grid), dim3(kBlock), 0, ks, d_sh_node_[ph], d_sh_ptr_[ph],
                                        sh_slot0_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
                 else
-                    hipLaunchKernelGGL((k_ebe_shared<false>), dim3(grid), dim3(kBlock), 0, st_, d_sh_node_[ph], d_sh_ptr_[ph],
+                    hipLaunchKernelGGL((k_ebe_shared<false>), dim3(grid), dim3(kBlock), 0, ks, d_sh_node_[ph], d_sh_ptr_[ph],
                                        sh_slot0_[ph], d_ch_buf_, y, sh_count_[ph], x, d_flags_, part, (long long)dot_lo);
                 if (fuse) cnt_ebe_ += grid;
             }
+        }
+        if (ks != st_) {                                        // the interior phase joins: whatever follows on st_ sees all of y
+            HIP_CHECK(hipEventRecord(ev_phase_join_, ks));
+            HIP_CHECK(hipStreamWaitEvent(st_, ev_phase_join_, 0));
+            phase_forked_ = false;
         }
         for (int ph = plo; ph < phi; ++ph)                      // other pattern types: one launch per element colour
             for (const auto &r : ebe_ranges_[ph]) ebe_launch_range(r, x, y);
@@ -1222,9 +1259,13 @@ public:
             for (int s = 0; s < kStatusSlots; ++s) h_mirror_[(size_t)s * ST_COUNT + ST_ERR] = 0.0;
         vec_spin_limit_ = 1u << 22;
         if (const char *e = getenv("PCG_TEST_VEC_SPINS")) vec_spin_limit_ = (unsigned)std::max(0, atoi(e));   // tests: force the time-out path
+        vec_inband_ = true;
+        if (const char *e = getenv("PCG_VEC_INBAND")) vec_inband_ = atoi(e) != 0;      // grid barrier of the fused vector launch: in-band (round 5) / counters (A/B)
         vec_kreg_ = kVecKreg;
         if (const char *e = getenv("PCG_VEC_KREG")) vec_kreg_ = std::max(0, std::min(kVecKreg, atoi(e)));
         if (const char *e = getenv("PCG_VEC_FUSED")) vec_fused_ok_ = vec_fused_ok_ && atoi(e) != 0;
+        ebe_phase_streams_ = 0;
+        if (const char *e = getenv("PCG_EBE_PHASE_STREAMS")) ebe_phase_streams_ = atoi(e) != 0 ? 1 : 0;     // multi-part loop: interior phase beside the interface phase (A/B)
         iter_fused_ = true;
         if (const char *e = getenv("PCG_ITER_FUSED")) iter_fused_ = atoi(e) != 0;      // multi-part loop: pack / reductions / status copy folded in (A/B)
     }
@@ -1254,7 +1295,10 @@ public:
     bool iter_fused_ = true;
     // ---- vector phase (k_vec) --------------------------------------------------------------------------------------
     unsigned long long *d_vec_sync_ = nullptr;     // arrival counters of the fused form's grid barrier (monotonic)
-    unsigned long long vec_seq_ = 0;               // fused launches so far
+    unsigned long long vec_seq_ = 0;               // fused launches so far (counter form of the grid barrier)
+    double *d_vec_pub_ = nullptr;                  // in-band form of the grid barrier: the published sums, two parities (kernels_vector.hpp)
+    unsigned long long vec_seq_inband_ = 0;        // ... its launches so far (parity of the slots)
+    bool vec_inband_ = true;                       // PCG_VEC_INBAND=0: the counter form
     int vec_kreg_ = kVecKreg;
     bool vec_fused_hw_ = false, vec_fused_ok_ = false;   // the device admits the grid / and PCG_VEC_FUSED does not say 0
     bool vec_fused_broken_ = false;                      // a launch timed out at its grid barrier: split form for the rest of this engine's life
@@ -1299,14 +1343,20 @@ public:
         const bool rec = prof_vec_ && evv_used_ < kMaxEv;
         if (rec) HIP_CHECK(hipEventRecord(evv0_[evv_used_], st_));
         if (fused) {
-            a.seq = ++vec_seq_;
+            a.pub = d_vec_pub_;
+            a.inband = vec_inband_ && cnt_vec_ >= 5 && cnt_vec_ <= 256 ? 1 : 0;     // (each form keeps its own launch count: the counters are monotonic)
+            a.seq = a.inband ? ++vec_seq_inband_ : ++vec_seq_;
             // small systems (every chunk of a thread fits the preloading form: <= kVecPre per thread): operands requested before the
             // alpha prologue, p kept in registers (kernels_vector.hpp); PCG_VEC_NT bit 3 / PCG_VEC_KREG < kVecPre: the general form
             const bool pre = vec_kreg_ >= kVecPre && (n_ >> 1) <= (int64_t)kVecPre * cnt_vec_ * kVecBlock && !(vec_nt_ & 8);
             if (pre) hipLaunchKernelGGL((k_vec<true, true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
             else hipLaunchKernelGGL((k_vec<true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
         } else {
-            hipLaunchKernelGGL((k_vec<false>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+            // the split form of the multi-part loop (round 5): small parts - a GPU's share of 10 M dof on 8 - preload their operands too:
+            // the general form runs a thread's chunks one after the other, 2 - 3 dependent round trips at 1.3 M dof (27 us for 75 MB)
+            const bool pre = vec_kreg_ >= kVecPre && (n_ >> 1) <= (int64_t)kVecPre * cnt_vec_ * kVecBlock && !(vec_nt_ & 8);
+            if (pre) hipLaunchKernelGGL((k_vec<false, true>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
+            else hipLaunchKernelGGL((k_vec<false>), dim3(cnt_vec_), dim3(kVecBlock), 0, st_, a);
         }
         HIP_CHECK(hipGetLastError());
         if (rec) { HIP_CHECK(hipEventRecord(evv1_[evv_used_], st_)); ++evv_used_; }

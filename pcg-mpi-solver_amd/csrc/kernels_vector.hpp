@@ -43,6 +43,29 @@ __device__ __forceinline__ double reduce_fixed_256(const double *pa, int count_a
     return r;
 }
 
+// The same sum, in the same order, of ONE value per thread already in registers (thread t < count holds pa[t]; count <= 256):
+// the in-band grid barrier of k_vec<FUSED> polls the published sums themselves and feeds them in from here.
+__device__ __forceinline__ double reduce_fixed_256_regs(double mine, int count, double *lds /* 5 */)
+{
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (tid < count) s0 += mine;
+        const double w = wave_sum((s0 + s1) + (s2 + s3));
+        if ((tid & 63) == 0) lds[tid >> 6] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t = lds[0];
+        t += lds[1]; t += lds[2]; t += lds[3];
+        lds[4] = t;
+    }
+    __syncthreads();
+    const double r = lds[4];
+    __syncthreads();
+    return r;
+}
+
 // out[v] = sum_{b<count_a} pa[v*stride + b] (+ sum_{b<count_b} pb[b] when pb != null), v = blockIdx.x: one block per value.
 // mirror (may be null): host-visible copy of the words written, so the host needs no device->host copy.
 __global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ pa, int count_a, int stride,
@@ -216,6 +239,11 @@ constexpr int kVecBlock = 1024;
 constexpr int kVecWaves = kVecBlock / 64;
 constexpr int kVecKreg = 20;              // 10.1 M dof on 256 CUs: 19.3 chunks per thread
 constexpr int kVecSyncWords = 16 * 8;     // 8 shard counters, 128 B apart
+// In-band grid barrier (round 5): a slot of `pub` holds this NaN pattern (both halves equal: one 32-bit fill writes it) until its
+// workgroup publishes a sum there; a reader polls the SLOT - no arrival counter, no second round trip for the value.  A sum that
+// happened to be this very NaN would read as "not there yet" until the poll times out (reported like any barrier time-out).
+constexpr unsigned kVecSentinelHalf = 0x7ff85ea1u;
+constexpr unsigned long long kVecSentinel = ((unsigned long long)kVecSentinelHalf << 32) | kVecSentinelHalf;
 
 struct VecArgs {
     double *st, *mirror;
@@ -230,6 +258,8 @@ struct VecArgs {
     const double *pa, *pb;                // pq_src 2: the operator's dot partials (interior launches; boundary fix-up)
     int count_a, count_b;
     unsigned long long *sync;             // FUSED: monotonic arrival counters
+    double *pub;                          // FUSED, in-band barrier (round 5): 2 x 5 x kMaxPartials doubles, kVecSentinel between uses
+    int inband;                           // ... 1 = the published sums are their own arrival flags (5 <= grid <= 256)
     unsigned long long seq;               // FUSED: number of this launch (1, 2, ...): targets = arrivals per launch x seq
     int pq_src, nt;
     int kreg;                             // FUSED: chunks of z kept in registers, <= kVecKreg (tests lower it: PCG_VEC_KREG)
@@ -267,7 +297,6 @@ constexpr int kVecPre = 4;                // FUSED, small systems: chunks per th
 template <bool FUSED, bool PRE = false>
 __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
 {
-    static_assert(FUSED || !PRE, "the preloading form belongs to the fused launch");
     __shared__ double lds[5 * kVecWaves + 8];
     const int tid = threadIdx.x;
     // Small systems (at most kVecPre chunks per thread: up to 2.1 M dof on 256 CUs - BASELINE configs[1], and a GPU's share of the
@@ -295,6 +324,13 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
                 }
             }
         }
+    }
+    if constexpr (FUSED) {
+        // in-band barrier: this launch publishes into the slots of parity seq & 1; its own slots of the OTHER parity - read for the
+        // last time by the launch before (complete: same stream) - go back to the sentinel for the launch after.  Frozen or not.
+        if (a.inband && tid < 5)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.pub) + ((size_t)((a.seq + 1) & 1) * 5 + tid) * kMaxPartials + blockIdx.x,
+                               kVecSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     double stop = a.st[ST_STOP], alpha = a.st[ST_ALPHA];
     const double rho = a.st[ST_RHO_NEXT];
@@ -329,28 +365,26 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
         return zz;
     };
     if (stop == 0.0) {                                             // frozen when pq / alpha broke down (:492-498)
-        if constexpr (FUSED) {
-            if constexpr (pre) {
+        if constexpr (pre) {                                       // (round 5: the split form of the multi-part loop preloads as well)
 #pragma unroll
-                for (int k = 0; k < kVecPre; ++k) {
-                    const int64_t t = t0 + k * T;
-                    if (t < n2) {                                  // chunk() on the operands already in registers
-                        double2 rr = pre_r[k], xo2, zz;
-                        zz.x = update_one(alpha, pre_p[k].x, pre_q[k].x, rr.x, pre_x[k].x, xo2.x, pre_m[k].x, pre_f[k].x, u);
-                        zz.y = update_one(alpha, pre_p[k].y, pre_q[k].y, rr.y, pre_x[k].y, xo2.y, pre_m[k].y, pre_f[k].y, u);
-                        if (nts) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
-                        else { rn2[t] = rr; xn2[t] = xo2; }
-                        z[k] = zz;
-                    }
+            for (int k = 0; k < kVecPre; ++k) {
+                const int64_t t = t0 + k * T;
+                if (t < n2) {                                      // chunk() on the operands already in registers
+                    double2 rr = pre_r[k], xo2, zz;
+                    zz.x = update_one(alpha, pre_p[k].x, pre_q[k].x, rr.x, pre_x[k].x, xo2.x, pre_m[k].x, pre_f[k].x, u);
+                    zz.y = update_one(alpha, pre_p[k].y, pre_q[k].y, rr.y, pre_x[k].y, xo2.y, pre_m[k].y, pre_f[k].y, u);
+                    if (nts) { ntstore(rn2 + t, rr); ntstore(xn2 + t, xo2); }
+                    else { rn2[t] = rr; xn2[t] = xo2; }
+                    if constexpr (FUSED) z[k] = zz;
                 }
-            } else {
+            }
+        } else if constexpr (FUSED) {
 #pragma unroll
             for (int k = 0; k < kVecKreg; ++k) {
                 const int64_t t = t0 + k * T;
                 if (k < a.kreg && t < n2) z[k < (int)(sizeof(z) / sizeof(z[0])) ? k : 0] = chunk(t);
             }
             for (int64_t t = t0 + a.kreg * T; t < n2; t += T) (void)chunk(t);
-            }
         } else {
             for (int64_t t = t0; t < n2; t += T) (void)chunk(t);
         }
@@ -403,6 +437,44 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
         // monotonic over the launches of an engine (target = arrivals per launch x launch number; nothing is reset in between),
         // so a frozen launch still counts its arrivals.
         const int G = gridDim.x, ns = G < 8 ? G : 8, shard = blockIdx.x % ns;
+        const bool inband = a.inband != 0;                         // (uniform over the grid: chosen by the launcher, 5 <= G <= 256)
+        double got_rho = 0.0, got_k = 0.0;                         // in-band: thread t < G ends up with workgroup t's rho' / row-k sum
+        const int krow = blockIdx.x < 5 ? (int)blockIdx.x : 3;     // workgroups 0..4 also total one of the five sums each
+        if (inband) {
+            // ---- in-band grid barrier (round 5): the published sums are their own arrival flags.  Thread 0 stores the five sums
+            // (plain copies to `partials` as well: the host's recovery path reads those after a time-out) and nobody waits for the
+            // stores; threads t < G of EVERY workgroup poll slot t of the rho' row (workgroups 0..4: of their own row too) until the
+            // sentinel is gone.  One round trip between "my sums are out" and "I have everybody's", where the counter form has
+            // three (stores acknowledged -> arrival counted -> arrival seen -> sums read).
+            const unsigned long long *pub = reinterpret_cast<const unsigned long long *>(a.pub) + (size_t)(a.seq & 1) * 5 * kMaxPartials;
+            if (tid == 0 && stop == 0.0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    __hip_atomic_store(a.pub + ((size_t)(a.seq & 1) * 5 + k) * kMaxPartials + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.partials[(size_t)k * kMaxPartials + blockIdx.x] = v[k];
+                }
+            }
+            if (tid < 256) {
+                bool ok = true;
+                if (stop == 0.0) {
+                    const bool act = tid < G;
+                    unsigned long long w3 = act ? kVecSentinel : 0ull, wk = act && krow != 3 ? kVecSentinel : 0ull;
+                    unsigned spins = 0;
+                    for (;;) {
+                        if (w3 == kVecSentinel) w3 = __hip_atomic_load(pub + (size_t)3 * kMaxPartials + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wk == kVecSentinel) wk = __hip_atomic_load(pub + (size_t)krow * kMaxPartials + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(w3 != kVecSentinel && wk != kVecSentinel)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) { ok = false; break; }   // seconds: a workgroup of the grid is not resident
+                    }
+                    got_rho = __longlong_as_double((long long)w3);
+                    got_k = krow != 3 ? __longlong_as_double((long long)wk) : got_rho;
+                }
+                if ((tid & 63) == 0) lds[5 * kVecWaves + 1 + (tid >> 6)] = ok ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) lds[5 * kVecWaves] = (lds[5 * kVecWaves + 1] != 0.0 && lds[5 * kVecWaves + 2] != 0.0 && lds[5 * kVecWaves + 3] != 0.0 && lds[5 * kVecWaves + 4] != 0.0) ? 1.0 : 0.0;
+        } else
         if (tid < 64) {
             if (tid == 0) {
                 if (stop == 0.0)
@@ -441,11 +513,11 @@ __global__ __launch_bounds__(kVecBlock) void k_vec(const VecArgs a)
         }
         // ---- every workgroup: rho' from the G partials, same order everywhere -> same beta everywhere (:462, :475);
         // the five sums of the status block are written by workgroups 0..4, one each (by workgroup 0 alone on a tiny grid)
-        const double rho_next = reduce_fixed_256<true>(a.partials + (size_t)3 * kMaxPartials, G, nullptr, 0, lds);
+        const double rho_next = inband ? reduce_fixed_256_regs(got_rho, G, lds) : reduce_fixed_256<true>(a.partials + (size_t)3 * kMaxPartials, G, nullptr, 0, lds);
         if (G >= 5) {
             if (blockIdx.x < 5) {
                 const int k = blockIdx.x;
-                const double sk = k == 3 ? rho_next : reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, G, nullptr, 0, lds);
+                const double sk = k == 3 ? rho_next : inband ? reduce_fixed_256_regs(got_k, G, lds) : reduce_fixed_256<true>(a.partials + (size_t)k * kMaxPartials, G, nullptr, 0, lds);
                 if (tid == 0) { a.st[ST_SQP + k] = sk; if (a.mirror) a.mirror[ST_SQP + k] = sk; }
             }
         } else if (blockIdx.x == 0) {

@@ -308,7 +308,15 @@ public:
             if (q[1] == mine[1]) {                                      // same process (device group, threads): the pointer itself
                 unsigned long long p = 0;
                 for (int k = 0; k < 4; ++k) p |= (unsigned long long)q[4 + k] << (16 * k);
-                if (pdev != dev_) {
+                if (pdev == dev_) {
+                    // Two ranks of ONE process on ONE device (a test stand-in, never production): every rank's reduction kernel polls
+                    // for its peers' posts, so all of them must be running at once - and HIP multiplexes a process's streams onto a few
+                    // hardware queues per device: a polling kernel can sit in front of the kernel it waits for (session c of round 5
+                    // hung this way with 8 ranks x 2 streams).  Separate processes have queues of their own.
+                    fail = 1; mail_why_ = "ranks " + std::to_string(rank_) + " and " + std::to_string(r) + " of one process share a device: their reduction kernels are not guaranteed to run concurrently";
+                    break;
+                }
+                {
                     int can = 0;
                     soft(hipDeviceCanAccessPeer(&can, dev_, pdev), "hipDeviceCanAccessPeer");
                     if (fail == 0 && !can) { fail = 1; mail_why_ = "no peer access from device " + std::to_string(dev_) + " to " + std::to_string(pdev); }

@@ -175,9 +175,16 @@ def main():
     timing = os.environ.get("PCG_TEST_COMM_TIMING", "1") == "1"
     mailbox = os.environ.get("PCG_TEST_MAILBOX", "0") == "1"       # opt-in engine-side reduction (pcg_comm_enable_mailbox), collective
 
+    refusal_ok = os.environ.get("PCG_TEST_MAILBOX_REFUSAL_OK", "0") == "1"     # ranks of ONE process on ONE device: the engine must decline
+
     def with_mailbox(comm):
         if mailbox and not comm.mailbox:
-            assert comm.enable_mailbox(), f"mailbox all-reduce refused: {comm.mailbox_reason}"
+            got = comm.enable_mailbox()
+            if refusal_ok:
+                assert not got and "share a device" in (comm.mailbox_reason or ""), (got, comm.mailbox_reason)
+                if comm.rank == 0: print("MAILBOX REFUSED:", comm.mailbox_reason, flush=True)
+            else:
+                assert got, f"mailbox all-reduce refused: {comm.mailbox_reason}"
         return comm
     if mode == "threads":
         cases, kinds, outdir = sys.argv[2].split(","), sys.argv[3].split(","), sys.argv[4]
@@ -226,7 +233,12 @@ def main():
                 gs = GroupSolver(parts, devices=devs, operator=kind, timing=timing)
                 try:
                     if mailbox:
-                        assert gs.group.enable_mailbox(), "mailbox all-reduce refused in the device group"
+                        got = gs.group.enable_mailbox()
+                        if refusal_ok and len(set(devs)) < len(devs):
+                            assert not got, "members of one process on one device must decline the mailbox all-reduce"
+                            print("MAILBOX REFUSED: device group with members on one device", flush=True)
+                        else:
+                            assert got, "mailbox all-reduce refused in the device group"
                     ys = gs.group.apply([probe[P["DofVector"]] for P in parts])
                     ds = gs.group.diag()
                     s0 = [c.stats() for c in gs.group.comms]

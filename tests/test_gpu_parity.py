@@ -201,15 +201,19 @@ def _vec_iteration(op, alpha, rho, p, q, r, x, m, fused):
     return rr, xn, pn, sums
 
 
-@pytest.mark.parametrize("N,kreg", [(9, None), (10, None), (41, None), (41, "0"), (41, "1")])
-def test_fused_vector_phase_is_bit_identical(gpu_lib, monkeypatch, N, kreg):
+@pytest.mark.parametrize("N,kreg,inband", [(9, None, None), (10, None, None), (41, None, None), (41, "0", None), (41, "1", None), (41, None, "0"), (75, None, None), (75, None, "0")])
+def test_fused_vector_phase_is_bit_identical(gpu_lib, monkeypatch, N, kreg, inband):
     """k_vec<FUSED> (one launch: update, grid barrier, fixed-order reduction, beta, p') against the split form of the multi-GPU
     loop (k_vec<!FUSED>, k_reduce, k_update_p) and against NumPy: r', x', p' bit-equal to the un-fused IEEE expressions
     (:501, :516, :447, :479), the five sums EQUAL between the two forms (same thread -> chunk map, same reduction order) and
-    within 1e-13 of NumPy.  kreg: chunks of z a thread keeps in registers (0 / 1 force the recompute-from-r' tail path)."""
+    within 1e-13 of NumPy.  kreg: chunks of z a thread keeps in registers (0 / 1 force the recompute-from-r' tail path).
+    inband (round 5): the grid barrier of the fused launch - "0" = arrival counters, default = the published sums are their own
+    arrival flags (5 <= workgroups <= 256: N = 41 has 101 workgroups, N = 75 all 256; N = 9 / 10 keep the counters)."""
     from pcg_mi355x.operator import from_refmeshpart
     if kreg is not None:
         monkeypatch.setenv("PCG_VEC_KREG", kreg)
+    if inband is not None:
+        monkeypatch.setenv("PCG_VEC_INBAND", inband)
     b = Brick(N)
     P = make_parts(b)[0]
     op = from_refmeshpart(P)
@@ -235,9 +239,11 @@ def test_fused_vector_phase_is_bit_identical(gpu_lib, monkeypatch, N, kreg):
             assert abs(a - c) <= 1e-13 * max(1.0, abs(c))
     assert np.array_equal(out[True][3], out[False][3]), (out[True][3], out[False][3])
     assert np.array_equal(out[True][2], out[False][2])
-    # twice the same launch: the arrival counters are monotonic over the launches of an engine
-    again = _vec_iteration(op, alpha, rho, p, q, r, x, m, True)
-    assert all(np.array_equal(a, c) for a, c in zip(again, out[True])) and rho_next == again[3][3]
+    # the same launch again, three times (both parities of the in-band slots): the arrival counters are monotonic over the launches
+    # of an engine, the in-band slots go back to the sentinel one launch after their use
+    for _ in range(3):
+        again = _vec_iteration(op, alpha, rho, p, q, r, x, m, True)
+        assert all(np.array_equal(a, c) for a, c in zip(again, out[True])) and rho_next == again[3][3]
     op.close()
 
 

@@ -123,21 +123,25 @@ def _same_bits(case, kind, dir_a, dir_b, world):
 
 
 @pytest.mark.parametrize("mode", ["threads", "group"])
-def test_mailbox_reduction_on_one_gpu(gpu_lib, tmp_path, mode):
-    """Round 5, opt-in pcg_comm_enable_mailbox (csrc/kernels_mail.hpp, rccl_comm.hip): MPI_SUM (pcg_solver.py:622-628) through peer-mapped
-    uncached device mailboxes - p.Ap inside k_fixup<DOT, REDUCE, MAIL>, the five sums inside k_vec<false>, the rest by k_mail_allreduce -
-    instead of ncclAllReduce.  2 - 8 ranks as threads of one process / as members of one device group (peer pointers), exchange still
-    through the native communicator: every fixture reproduced, and bit-identical to the run with the stand-in's rank-ordered
-    all-reduce (same order of summation)."""
-    cases = "n9_p8,oct_p3,n13_t3_p4_ud,n9_p2_flag4" if mode == "threads" else "n9_p8,goct_p4"
+def test_mailbox_is_declined_when_ranks_of_one_process_share_a_device(gpu_lib, tmp_path, mode):
+    """Round 5, opt-in pcg_comm_enable_mailbox (csrc/kernels_mail.hpp, rccl_comm.hip): every rank's reduction kernel polls for its peers'
+    posts, so all of them must be RUNNING at once.  Several ranks of ONE process on ONE device (threads / a device group on this
+    one-GPU box) cannot promise that - HIP multiplexes a process's streams onto a few hardware queues per device, a polling kernel can
+    sit in front of the kernel it waits for (sessions b / c of round 5: the self-test timed out, with more queues the solve hung).  The
+    engine declines collectively (`mailbox_reason`), stays with ncclAllReduce and reproduces every fixture with the same bits.  The
+    mailboxes themselves are tested between PROCESSES (below: hipIpcMemHandle, up to 8 ranks on this GPU), at world size 1 on real
+    RCCL, and between devices where there are several (test_mailbox_reduction_across_gpus)."""
+    cases = "n9_p8,oct_p3" if mode == "threads" else "n9_p8"
     dirs = {}
     for mb in ("0", "1"):
         d = tmp_path / f"mb{mb}"
         d.mkdir()
         env = _env(True)
         env["PCG_TEST_MAILBOX"] = mb
-        r = subprocess.run([sys.executable, WORKER, mode, cases, "sell,ebe", str(d)], env=env, capture_output=True, text=True, timeout=900)
+        env["PCG_TEST_MAILBOX_REFUSAL_OK"] = "1"
+        r = subprocess.run([sys.executable, WORKER, mode, cases, "sell,ebe", str(d)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert (mb == "1") == ("MAILBOX REFUSED" in r.stdout), r.stdout[-2000:]
         dirs[mb] = d
     for case in cases.split(","):
         world = len([f for f in os.listdir(dirs["1"]) if f.startswith(case + "_sell_rank")])
