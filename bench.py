@@ -941,6 +941,26 @@ def main():
                     mailbox_ab[key] = {"value": args.steps / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / args.steps * 1e3,
                                        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in mm["per_rank_s"]], "solve": mm["final"], "comm": mm["comm"]}
                     mm["op"].close()
+                # ... and the engine-side EXCHANGE on top (opt-in pcg_enable_direct_exchange: the pack kernel stores straight into the
+                # neighbours' peer-mapped receive buffers, the fix-up waits for their arrival words; the matrix-free engine is built
+                # without an interface-first phase) - then no collective kernel is left in the iteration.  PCG_DIRECT_EXCHANGE=1 makes every
+                # operator built from here on enable it at set_comm (collective: every rank runs this same code).
+                os.environ["PCG_DIRECT_EXCHANGE"] = "1"
+                try:
+                    direct = {"note": "interface exchange as stores into peer-mapped receive buffers (k_halo_put + arrival words) AND mailbox all-reduces: no "
+                                      "collective kernel in the iteration; matrix-free engine with one phase (one element launch)"}
+                    for kind, key in (("sell", "assembled"), ("ebe", "matrix_free")):
+                        mm = measure(kind)
+                        direct[key] = {"value": args.steps / mm["elapsed"], "unit": "iterations/s", "ms_per_step": mm["elapsed"] / args.steps * 1e3,
+                                       "per_rank_ms_per_step": [t / args.steps * 1e3 for t in mm["per_rank_s"]], "solve": mm["final"], "comm": mm["comm"],
+                                       "enabled": bool(mm["op"].direct_exchange), "reason": mm["op"].direct_exchange_reason}
+                        mm["op"].close()
+                    mailbox_ab["direct_exchange"] = direct
+                except Exception as ex:      # noqa: BLE001
+                    log(f"[rank {rank}] direct-exchange A/B failed: {ex!r}")
+                    mailbox_ab["direct_exchange"] = {"error": repr(ex)}
+                finally:
+                    os.environ.pop("PCG_DIRECT_EXCHANGE", None)
                 comm.enable_mailbox(False)
             else:
                 mailbox_ab = {"enabled": False, "reason": comm.mailbox_reason}

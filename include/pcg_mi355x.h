@@ -50,8 +50,9 @@ typedef struct pcg_asm pcg_asm;
  * 3 = pcg_comm_hooks.collective_exchange, pcg_result.vec_ms_sum / vec_count (round 3; a library of version < 3 called the
  * hooks of a part without neighbours unconditionally - since 3 only with collective_exchange != 0);
  * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4);
- * 5 = pcg_comm_enable_mailbox(), pcg_group_enable_mailbox() (round 5; no struct changed). */
-#define PCG_ABI_VERSION 5
+ * 5 = pcg_comm_enable_mailbox(), pcg_group_enable_mailbox() (round 5; no struct changed);
+ * 6 = pcg_enable_direct_exchange() (round 5; no struct changed). */
+#define PCG_ABI_VERSION 6
 int pcg_abi_version(void);
 const char *pcg_last_error(void);
 const char *pcg_backend_name(void);          /* "hip-gfx950" for the product library */
@@ -118,7 +119,9 @@ int pcg_create_scalar_copy(pcg_engine *src, pcg_engine **out);
 /* node_coords (n_nodes x 3, ORIGINAL node numbering, may be NULL: RefMeshPart['NodeCoordVec'],
  * partition_mesh.py:357) only steers the spatial clustering of elements into workgroup chunks.
  * flags bit0: disable the chunked (LDS-tiled) form and use one colour per launch for every group;
- *       bit1: one element per thread (256-element chunks) instead of two (512-element chunks). */
+ *       bit1: one element per thread (256-element chunks) instead of two (512-element chunks);
+ *       bit2 (ABI 6): ONE phase - the elements on the interface are not launched first; the exchange then follows the whole operator
+ *             (for pcg_enable_direct_exchange: one element launch instead of two, each as long as a chunk's chain of phases). */
 int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_elem_group *groups,
                    const int64_t *node_perm, int64_t n_boundary_nodes, const double *node_coords, int32_t flags,
                    pcg_engine **out);
@@ -212,6 +215,19 @@ int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out);
  * A poll that never sees a peer's contribution gives up after seconds, delivers NaN (the solve ends on it) and the next
  * pcg_solve_* call on that communicator returns an error - nothing hangs.  on = 0 switches back to ncclAllReduce (collective too). */
 int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out);
+/* Engine-side neighbour exchange (round 5, OPT-IN; RCCL's grouped ncclSend / ncclRecv stays the default): the reference's
+ * Isend / Recv / Waitall over the interface dofs (pcg_solver.py:307-328) as stores over xGMI.  The engine's receive buffer and one
+ * arrival word per neighbour live in uncached device memory that its neighbours map (hipIpcMemHandle / peer pointers, exchanged
+ * through the communicator like the mailboxes); in the applies of the PCG iteration the pack kernel then writes this rank's
+ * partial sums STRAIGHT into its neighbours' buffers and posts a sequence number (release, system scope), and the interface
+ * fix-up waits for its neighbours' numbers (acquire) before it adds in neighbour order - same values, same order, same bits; one
+ * stream, no collective kernel, no event between streams.  Set-up applies and the true-residual branch keep ncclSend / ncclRecv.
+ * Call it after pcg_set_halo and pcg_set_comm_native, between solves.  COLLECTIVE: every rank of the engine's communicator calls it
+ * for its engine of the same job, neighbours or not.  *enabled_out = 1 on every rank or 0 on every rank (any rank that cannot map a
+ * neighbour - no peer access, IPC refused, another host, two ranks of one process on one device - keeps all on RCCL; pcg_last_error()
+ * says why, the call returns 0).  A wait that never sees a neighbour gives up after seconds and the next pcg_solve_* call returns an
+ * error.  on = 0 drops the mapping (collective too: no rank may keep writing into a buffer its neighbour has freed). */
+int pcg_enable_direct_exchange(pcg_engine *e, int32_t on, int32_t *enabled_out);
 
 /* ---- operator-level calls (host vectors, length n) ----------------------------------------- */
 int pcg_apply(pcg_engine *e, const double *x, double *y);            /* y = A x, interface-summed */

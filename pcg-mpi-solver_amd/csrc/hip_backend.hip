@@ -1169,15 +1169,25 @@ public:
     }
     // last-workgroup reductions of the multi-part loop (k_fixup<true, true>, k_vec<false> with reduce_last): arrival counters, put
     // back to 0 by the last arriver of every launch
-    unsigned long long *d_last_cnt_ = nullptr;      // [0]: k_fixup, [16]: k_vec (128 B apart)
+    unsigned long long *d_last_cnt_ = nullptr;      // [0]: k_fixup, [16]: k_vec, [32]: k_halo_put (128 B apart)
     void last_counters()
     {
         if (d_last_cnt_) return;
-        d_last_cnt_ = (unsigned long long *)alloc(sizeof(unsigned long long) * 32);
-        HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long) * 32, st_));
+        d_last_cnt_ = (unsigned long long *)alloc(sizeof(unsigned long long) * 48);
+        HIP_CHECK(hipMemsetAsync(d_last_cnt_, 0, sizeof(unsigned long long) * 48, st_));
     }
     bool mailbox_kernels_available() const override { return true; }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail) override
+    bool direct_kernels_available() const override { return true; }
+    void halo_put(const double *y, const DirectDesc &d) override
+    {
+        if (!halo_count_) return;
+        last_counters();
+        int grid = (int)std::min<int64_t>((halo_count_ + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_halo_put, dim3(grid), dim3(kBlock), 0, st_, y, d_send_idx_, halo_count_, d, d_last_cnt_ + 32);
+        HIP_CHECK(hipGetLastError());
+    }
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail,
+                        const DirectDesc *direct) override
     {
         if (!nb_dofs_) {
             if (mail) throw std::runtime_error("boundary_fixup: a part without interface dofs cannot carry the mailbox all-reduce");
@@ -1185,6 +1195,7 @@ public:
             return;
         }
         int grid = (int)std::min<int64_t>((nb_dofs_ + kBlock - 1) / kBlock, 1024);
+        const FixWait fw = fix_wait_of(direct);
         FixReduce fr{};
         if (with_dot && reduce_pq) {
             last_counters();
@@ -1193,18 +1204,18 @@ public:
             if (mail) {
                 fr.mail = *mail;
                 hipLaunchKernelGGL((k_fixup<true, true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                                   nb_dofs_, d_part_fix_, fr);
+                                   nb_dofs_, d_part_fix_, fr, fw);
             } else
                 hipLaunchKernelGGL((k_fixup<true, true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                                   nb_dofs_, d_part_fix_, fr);
+                                   nb_dofs_, d_part_fix_, fr, fw);
         } else if (mail)
             throw std::runtime_error("boundary_fixup: the mailbox all-reduce rides on the fused dot reduction only");
         else if (with_dot)
             hipLaunchKernelGGL((k_fixup<true>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, d_part_fix_, fr);
+                               nb_dofs_, d_part_fix_, fr, fw);
         else
             hipLaunchKernelGGL((k_fixup<false>), dim3(grid), dim3(kBlock), 0, st_, y, recv, d_fptr_, d_fpos_, xdot, d_flags_,
-                               nb_dofs_, d_part_fix_, fr);
+                               nb_dofs_, d_part_fix_, fr, fw);
         HIP_CHECK(hipGetLastError());
         if (with_dot) cnt_fix_ = grid;
     }

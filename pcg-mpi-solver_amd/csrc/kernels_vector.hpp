@@ -111,6 +111,43 @@ __global__ __launch_bounds__(kBlock) void k_halo_pack(const double *__restrict__
         send[m] = y[idx[m]];
 }
 
+// Direct exchange (pcg_internal.hpp DirectDesc; round 5, opt-in): :307-309 AND :318-326 in one launch - entry m of the packed list goes
+// straight into the receive buffer of the neighbour whose segment holds m (a store over xGMI into uncached memory mapped here); every
+// workgroup makes its stores visible system-wide before it counts itself in, and the last one posts this rank's arrival word at every
+// neighbour (release, system scope: whoever sees the number sees the values).
+__global__ __launch_bounds__(kBlock) void k_halo_put(const double *__restrict__ y, const int *__restrict__ idx, int64_t count,
+                                                     const DirectDesc d, unsigned long long *counter)
+{
+    for (int64_t m = blockIdx.x * (int64_t)kBlock + threadIdx.x; m < count; m += (int64_t)gridDim.x * kBlock) {
+        int j = 0;
+        while (j + 1 < d.n_peers && m >= d.seg[j + 1]) ++j;           // (<= 26 neighbours; the segments are contiguous runs of m)
+        d.peer_recv[j][m - d.seg[j]] = y[idx[m]];
+    }
+    __threadfence_system();
+    __shared__ int flag;
+    if (last_workgroup(counter, &flag)) {
+        __threadfence_system();
+        if ((int)threadIdx.x < d.n_peers)
+            __hip_atomic_store(d.peer_flag[threadIdx.x], d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The other side: until every neighbour has posted exchange w.seq (acquire).  Called by every thread of a workgroup at the start of
+// k_fixup.  A poll that runs out of patience (seconds) reports through w.err; the launch goes on with whatever is in the buffer and
+// the host ends the solve on the report (DirectLink::check).
+__device__ __forceinline__ void wait_for_neighbours(const FixWait &w)
+{
+    if (w.n <= 0) return;
+    if ((int)threadIdx.x < w.n) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(w.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > w.spin_limit) { __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+    __syncthreads();
+}
+
 // y[d] += recv[...] in neighbour order for the interface dofs; optional dot over all boundary-slice dofs
 // REDUCE (with DOT): the last workgroup to finish sums the apply's dot partials - pa[0 .. count_a) of the operator launches, then
 // this launch's - in k_reduce's fixed order into red[0]: the p.Ap of the multi-part loop without a reduce launch.
@@ -122,8 +159,9 @@ template <bool DOT, bool REDUCE = false, bool MAIL = false>
 __global__ __launch_bounds__(kBlock) void k_fixup(double *__restrict__ y, const double *__restrict__ recv,
                                                   const int *__restrict__ fptr, const int *__restrict__ fpos,
                                                   const double *__restrict__ xdot, const uint8_t *__restrict__ flags,
-                                                  int64_t nb, double *__restrict__ partials, FixReduce fr)
+                                                  int64_t nb, double *__restrict__ partials, FixReduce fr, const FixWait fw)
 {
+    wait_for_neighbours(fw);                                       // direct exchange: `recv` is being filled by the neighbours' launches
     double dot = 0.0;
     for (int64_t d = blockIdx.x * (int64_t)kBlock + threadIdx.x; d < nb; d += (int64_t)gridDim.x * kBlock) {
         double v = y[d];

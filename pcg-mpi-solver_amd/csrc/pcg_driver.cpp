@@ -68,6 +68,11 @@ struct pcg_engine {
     Comm *comm = nullptr;                 // native RCCL communicator (not owned; pcg_comm handle), takes precedence
     pcg_comm *comm_handle = nullptr;      // ... its handle: either side may be destroyed first (detach())
     CommStats comm0;                      // its counters at pcg_solve_begin
+    // direct exchange (round 5, opt-in pcg_enable_direct_exchange; pcg_internal.hpp DirectDesc): this engine's peer-mapped receive
+    // buffer.  Used by the applies of the ITERATION only (the all-reduce behind every one of them is what orders a neighbour's next
+    // write behind this rank's reads); set-up applies and the true-residual branch stay on ncclSend / ncclRecv.
+    std::unique_ptr<DirectLink> direct;
+    bool ebe_one_phase = false;           // matrix-free engine built without an interface-first phase (pcg_create_ebe flags bit 2)
     bool multi() const { return comm != nullptr || has_hooks; }
     bool jacobi_built = false;
     bool profiling = false;
@@ -120,6 +125,7 @@ struct pcg_engine {
 
     void detach_comm()
     {
+        direct.reset();                   // (mapped through the communicator's ranks)
         if (comm_handle) {
             auto &v = comm_handle->attached;
             v.erase(std::remove(v.begin(), v.end(), this), v.end());
@@ -198,10 +204,14 @@ struct pcg_engine {
         MailDesc md{};
         // the descriptor is drawn exactly when the fix-up launch will carry the all-reduce: every all-reduce of the job - fused or
         // not - takes ONE number of the communicator's sequence on every rank
+        // direct exchange: the applies of the iteration (fold) when the engine holds a link; `dd` = this exchange's descriptor
+        const bool dx = fold && has_halo && comm && direct && be->direct_kernels_available();
+        DirectDesc dd{};
+        if (dx) dd = direct->next();
         auto fixup = [&](bool dot, bool fused_here) {
             const bool m = mail && fold && fused_here;
             if (m) md = comm->mailbox_next();
-            be->boundary_fixup(y, d_recv, x, dot, fold && fused_here ? reduce_pq : nullptr, m ? &md : nullptr);
+            be->boundary_fixup(y, dx ? direct->recv() : d_recv, x, dot, fold && fused_here ? reduce_pq : nullptr, m ? &md : nullptr, dx ? &dd : nullptr);
             return m ? 2 : (fold && fused_here ? 1 : 0);
         };
         if (kind == 1) {                                      // matrix-free: phase 0 = elements on the interface
@@ -211,7 +221,14 @@ struct pcg_engine {
             if (!has_halo) {
                 fused = be->ebe_apply(x, y, 0, 2, true, with_dot, 0);
                 empty_exchange();
-            } else if (!be->ebe_can_split()) {
+            } else if (dx) {
+                // ONE element launch per phase back to back (a launch lasts one chunk's chain of phases however few chunks it has:
+                // nothing is gained by starting the exchange after the interface chunks alone), the packed values straight into the
+                // neighbours' buffers, the fix-up waits for theirs: one stream, no collective kernel (profiles/r05_multi_part_timeline_*)
+                fused = be->ebe_apply(x, y, 0, 2, true, with_dot, n_bnd_dofs);
+                be->halo_put(y, dd);                          // :307-309 + :318-326
+                state = fixup(with_dot && fused, fused);       // :328 (its wait) + :332-334
+            } else if (!be->ebe_can_split() || ebe_one_phase) {
                 // Pattern types outside the chunked form add into y with '+=' (one colour per launch) while chunk and
                 // shared-node stores assign: a phase-0 colour launch followed by a phase-1 chunk store would lose
                 // contributions.  Such mixed parts run the whole operator first, then exchange (no overlap).
@@ -236,6 +253,11 @@ struct pcg_engine {
         if (!has_halo) {
             be->spmv(x, y, 0, n_slices, with_dot);
             empty_exchange();
+        } else if (dx) {
+            be->spmv(x, y, 0, n_bnd_slices, false);           // interface rows
+            be->halo_put(y, dd);                              // :307-309 + :318-326: straight into the neighbours' buffers
+            be->spmv(x, y, n_bnd_slices, n_slices, with_dot); // the interior rows hide the wire
+            return fixup(with_dot, true);                     // :328 (its wait) + :332-334
         } else if (be->iteration_fusion_available()) {
             be->spmv(x, y, 0, n_bnd_slices, false, d_send);   // interface rows + :307-309 in one launch
             halo_begin();                                     // :318-326
@@ -486,6 +508,7 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
 void fill_result(pcg_engine *e, pcg_result *res)
 {
     if (e->comm) e->comm->mailbox_check();          // a mailbox poll gave up during this solve: an error, not a result
+    if (e->direct) e->direct->check();              // ... or a neighbour's values never arrived
     if (!res) return;
     auto &s = e->s;
     std::memset(res, 0, sizeof(*res));
@@ -800,7 +823,10 @@ int pcg_create_ebe(int32_t device, int64_t n_nodes, int32_t n_groups, const pcg_
         auto e = std::unique_ptr<pcg_engine>(new pcg_engine());
         e->be = make_backend(device);
         EbeHost m;
-        build_ebe(n_nodes, n_groups, groups, node_perm, n_boundary_nodes, node_coords, (flags & 1) == 0, (flags & 2) ? 1 : 2, m);
+        // flags bit 2: ONE phase - no interface-first launch.  For engines that exchange AFTER the whole operator (the direct
+        // exchange): a launch lasts one chunk's chain of phases however few chunks it has, so two launches cost two chains.
+        e->ebe_one_phase = (flags & 4) != 0;
+        build_ebe(n_nodes, n_groups, groups, node_perm, e->ebe_one_phase ? 0 : n_boundary_nodes, node_coords, (flags & 1) == 0, (flags & 2) ? 1 : 2, m);
         e->kind = 1;
         e->n_nodes = n_nodes;
         e->n = 3 * n_nodes;
@@ -869,6 +895,7 @@ int pcg_set_halo(pcg_engine *e, int32_t n_peers, const int32_t *peer_ids, const 
     return guarded("pcg_set_halo", e, [&]() -> int {
         if (!e || n_peers < 0) return set_error("pcg_set_halo: bad argument");
         HaloHost &h = e->halo;
+        e->direct.reset();                 // (the layout it was mapped for is gone)
         h = HaloHost();
         h.n_peers = n_peers;
         if (n_peers == 0) { e->has_halo = false; return 0; }
@@ -1007,6 +1034,29 @@ int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out)
         const bool ok = c->impl->enable_mailbox(on != 0);
         if (enabled_out) *enabled_out = ok ? 1 : 0;
         if (on && !ok) (void)set_error("pcg_comm_enable_mailbox: staying with ncclAllReduce - " + c->impl->mailbox_why());
+        return 0;
+    });
+}
+
+int pcg_enable_direct_exchange(pcg_engine *e, int32_t on, int32_t *enabled_out)
+{
+    return guarded("pcg_enable_direct_exchange", e, [&]() -> int {
+        if (!e) return set_error("pcg_enable_direct_exchange: null");
+        if (enabled_out) *enabled_out = 0;
+        e->direct.reset();
+        if (!on) return 0;
+        if (!e->comm) return set_error("pcg_enable_direct_exchange: the engine has no native communicator (pcg_set_comm_native)");
+        if (e->s.active) return set_error("pcg_enable_direct_exchange: a solve is in progress");
+        std::string why;
+        if (!e->be->direct_kernels_available()) why = "this back end has no direct-exchange kernels";
+        // collective: EVERY rank enters, with its own halo (possibly empty)
+        auto link = e->comm->direct_link(e->has_halo ? e->halo : HaloHost(), why);
+        if (!link || !e->be->direct_kernels_available()) {
+            (void)set_error("pcg_enable_direct_exchange: staying with ncclSend / ncclRecv - " + why);
+            return 0;
+        }
+        e->direct = std::move(link);
+        if (enabled_out) *enabled_out = 1;
         return 0;
     });
 }

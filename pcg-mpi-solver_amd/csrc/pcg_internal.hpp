@@ -3,6 +3,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -270,6 +271,48 @@ struct MailDesc {                                  // passed BY VALUE to the ker
     unsigned spin_limit;
 };
 
+// ---- engine-side neighbour exchange through peer-mapped receive buffers (round 5, opt-in: pcg_enable_direct_exchange) ---------
+// The reference's Isend / Recv / Waitall (pcg_solver.py:318-328) without a collective kernel and without a second stream: every
+// engine owns its receive buffer + one arrival word per neighbour in uncached device memory that its neighbours have mapped (same
+// mapping machinery as the mailboxes).  Exchange number `seq` of an engine: the pack kernel (k_halo_put) writes this rank's partial
+// sums STRAIGHT into every neighbour's receive buffer (stores over xGMI), its last workgroup then posts `seq` into this rank's
+// arrival word at every neighbour (release, system scope); the fix-up kernel polls its own arrival words until every neighbour has
+// posted `seq` (acquire) and adds in neighbour order as before.  One stream, two launches, no ncclSend / ncclRecv kernel, no events.
+// Safe without a second buffer: a neighbour starts exchange q + 1 only after an all-reduce that needs this rank's p.Ap of
+// iteration q, which is formed after the fix-up of q has read the buffer (the driver uses it for the applies of the iteration only).
+constexpr int kDirectMaxPeers = 32;
+struct DirectDesc {                                // passed BY VALUE to k_halo_put
+    double *peer_recv[kDirectMaxPeers];            // [j]: where this rank's segment lives inside neighbour j's receive buffer (mapped here)
+    unsigned long long *peer_flag[kDirectMaxPeers];   // [j]: this rank's arrival word at neighbour j
+    const unsigned long long *my_flags;            // this rank's arrival words, one per neighbour (neighbour order)
+    long long seg[kDirectMaxPeers + 1];            // send_ptr: segment j = packed entries [seg[j], seg[j + 1])
+    unsigned *err;                                 // host-visible word: != 0 after a poll gave up
+    unsigned long long seq;                        // number of THIS exchange (1, 2, ...)
+    int n_peers;
+    unsigned spin_limit;
+};
+struct FixWait {                                   // passed BY VALUE to k_fixup: n == 0 = the receive buffer is complete at launch (RCCL path)
+    const unsigned long long *flags;
+    unsigned *err;
+    unsigned long long seq;
+    int n;
+    unsigned spin_limit;
+};
+inline FixWait fix_wait_of(const DirectDesc *d)
+{
+    FixWait w{};
+    if (d) { w.flags = d->my_flags; w.err = d->err; w.seq = d->seq; w.n = d->n_peers; w.spin_limit = d->spin_limit; }
+    return w;
+}
+struct HaloHost;
+class DirectLink {                                 // one per engine; created collectively by Comm::direct_link
+public:
+    virtual ~DirectLink() {}
+    virtual double *recv() = 0;                    // the receive buffer the fix-up reads from now on (uncached, mapped by the neighbours)
+    virtual DirectDesc next() = 0;                 // the descriptor of the NEXT exchange (advances the sequence)
+    virtual void check() = 0;                      // throws when a poll has timed out since the last call
+};
+
 struct HaloHost {
     int32_t n_peers = 0;
     std::vector<int32_t> peer_ids;
@@ -325,13 +368,19 @@ public:
     // format packs with a launch of its own, the result is the same
     virtual void spmv(const double *x, double *y, int64_t slice_lo, int64_t slice_hi, bool with_dot, double *pack_send = nullptr) = 0;
     virtual void halo_pack(const double *y, double *send) = 0;
+    // direct exchange (DirectDesc above): pack AND deliver - the packed values go straight into the neighbours' receive buffers,
+    // the last workgroup posts the arrival words
+    virtual void halo_put(const double *y, const DirectDesc &d) { (void)y; (void)d; throw std::runtime_error("this back end has no direct exchange"); }
+    virtual bool direct_kernels_available() const { return false; }
     // interface rows: y[d] += sum recv[...] (neighbour order); optional dot over the boundary-slice rows
     // reduce_pq != null (with_dot): the LAST workgroup of this launch to finish also sums every dot partial of the apply - the
     // operator launches' and this one's, in reduce_dot()'s fixed order - into reduce_pq[0]: no reduce launch
     // mail != null (with reduce_pq): that last workgroup then also all-reduces the sum ACROSS THE RANKS through the mailboxes -
     // reduce_pq[0] is the global p.Ap when the launch is done, no all-reduce call follows
+    // direct != null: `recv` is filled by the neighbours' k_halo_put of exchange direct->seq - every workgroup first waits for their
+    // arrival words
     virtual void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq = nullptr,
-                                const MailDesc *mail = nullptr) = 0;
+                                const MailDesc *mail = nullptr, const DirectDesc *direct = nullptr) = 0;
     // forget the dot partials of earlier launches (call before an apply that wants the fused dot)
     virtual void begin_dot() = 0;
     // red[0] = sum of the SpMV-dot partials (interior launch, then boundary fix-up; fixed order)
@@ -428,6 +477,10 @@ public:
     virtual MailDesc mailbox_next() { return MailDesc{}; }   // the descriptor of the NEXT all-reduce (advances the sequence)
     virtual void mailbox_check() {}                          // throws when a poll has timed out since the last call
     virtual std::string mailbox_why() const { return "this communicator has no mailbox all-reduce"; }   // why enable_mailbox() said no
+    // Direct exchange (DirectDesc above).  COLLECTIVE over every rank of the communicator, neighbours or not: the ranks publish
+    // their buffers' handles and segment layouts, map their neighbours' and agree on the outcome.  -> null (on every rank, `why`
+    // says why) when any rank could not map a neighbour; the exchange then stays on ncclSend / ncclRecv.
+    virtual std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) { (void)h; why = "this communicator has no direct exchange"; return nullptr; }
 };
 // defined by the HIP side of the product library; the CPU test double has no native communicator
 std::unique_ptr<Comm> make_rccl_comm(int device, int rank, int nranks, const void *unique_ids /* 2 x 128 B */);

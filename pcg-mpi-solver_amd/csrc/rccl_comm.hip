@@ -25,6 +25,7 @@
 #include <rccl/rccl.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -137,6 +138,40 @@ struct EventRing {
     void end(int k, hipStream_t s) { HIP_CHECK(hipEventRecord(b[k], s)); used[k] = 1; }
     void drain() { for (int k = 0; k < (int)a.size(); ++k) harvest(k); }
     void destroy() { for (auto e : a) (void)hipEventDestroy(e); for (auto e : b) (void)hipEventDestroy(e); a.clear(); b.clear(); }
+};
+
+// One engine's side of the direct exchange (pcg_internal.hpp DirectDesc): its receive buffer + arrival words, and its neighbours'
+// buffers as mapped here.  Created by RcclComm::direct_link (collective); owned by the engine.
+class RcclDirectLink : public DirectLink {
+public:
+    int dev = 0;
+    double *buf = nullptr;                            // [receive buffer: total doubles][pad to 128 B][arrival words: kDirectMaxPeers]
+    size_t flags_off = 0;                             // byte offset of the arrival words inside buf
+    void *peer_base[kDirectMaxPeers] = {};            // neighbour j's buffer as mapped here
+    bool peer_ipc[kDirectMaxPeers] = {};
+    unsigned *err = nullptr;                          // pinned, mapped
+    DirectDesc d{};
+    unsigned long long seq = 0;
+    CommStats *stats = nullptr;                       // the communicator's counters (the engine drops the link before the communicator goes)
+    ~RcclDirectLink() override
+    {
+        (void)hipSetDevice(dev);
+        for (int j = 0; j < kDirectMaxPeers; ++j)
+            if (peer_ipc[j] && peer_base[j]) (void)hipIpcCloseMemHandle(peer_base[j]);
+        if (buf) (void)hipFree(buf);
+        if (err) (void)hipHostFree(err);
+    }
+    double *recv() override { return buf; }
+    DirectDesc next() override
+    {
+        d.seq = ++seq;
+        if (stats) stats->n_halo++;                   // one exchange per operator apply, whichever way it travels
+        return d;
+    }
+    void check() override
+    {
+        if (err && *err) { *err = 0; throw std::runtime_error("direct exchange: a neighbour's values never arrived (poll timed out)"); }
+    }
 };
 
 class RcclComm : public Comm {
@@ -384,6 +419,112 @@ public:
         if (mail_err_ && *mail_err_) { *mail_err_ = 0; throw std::runtime_error("mailbox all-reduce: a peer's values never arrived (poll timed out)"); }
     }
     std::string mailbox_why() const override { return mail_why_; }
+
+    // COLLECTIVE over every rank (neighbours or not), same discipline as enable_mailbox(): local failures only raise `fail`, the ranks
+    // compare notes through the reduction communicator and take the same decision.
+    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) override
+    {
+        HIP_CHECK(hipSetDevice(dev_));
+        why.clear();
+        constexpr int R = 73 + 3 * kDirectMaxPeers;      // ok, pid, host, device, pointer 4 x 16 bits, 64 handle bytes, n_peers, (peer, offset, count) x 32
+        double fail = 0;
+        auto soft = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && fail == 0) { fail = 1; why = std::string(what) + " -> " + hipGetErrorString(e); (void)hipGetLastError(); }
+            return e == hipSuccess;
+        };
+        auto link = std::make_unique<RcclDirectLink>();
+        link->dev = dev_;
+        link->stats = &st_;
+        if (size_ > kMailMaxRanks) { fail = 1; why = "more than 16 ranks"; }
+        if (h.n_peers > kDirectMaxPeers) { fail = 1; why = "more than 32 neighbours"; }
+        const int64_t total = h.n_peers > 0 ? h.send_ptr[(size_t)h.n_peers] : 0;
+        link->flags_off = ((size_t)total * sizeof(double) + 127) / 128 * 128;
+        const size_t bytes = link->flags_off + sizeof(unsigned long long) * kDirectMaxPeers;
+        if (!soft(hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached)")) {
+            fail = 0; why.clear();
+            soft(hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(fine-grained)");
+        }
+        if (link->buf) soft(hipMemset(link->buf, 0, bytes), "hipMemset(direct buffer)");
+        soft(hipHostMalloc((void **)&link->err, sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(direct error word)");
+        if (link->err) *link->err = 0;
+        hipIpcMemHandle_t hd;
+        std::memset(&hd, 0, sizeof(hd));
+        if (link->buf) soft(hipIpcGetMemHandle(&hd, link->buf), "hipIpcGetMemHandle");
+        std::vector<double> rec((size_t)size_ * R, 0.0);
+        double *mine = rec.data() + (size_t)rank_ * R;
+        const unsigned long long ptr = (unsigned long long)(uintptr_t)link->buf;
+        mine[0] = 1; mine[1] = (double)getpid(); mine[2] = (double)(unsigned)gethostid(); mine[3] = dev_;
+        for (int k = 0; k < 4; ++k) mine[4 + k] = (double)((ptr >> (16 * k)) & 0xffffull);
+        for (int k = 0; k < 64; ++k) mine[8 + k] = (double)((const unsigned char *)&hd)[k];
+        mine[72] = (double)std::min<int>(h.n_peers, kDirectMaxPeers);
+        for (int j = 0; j < h.n_peers && j < kDirectMaxPeers; ++j) {
+            mine[73 + 3 * j] = (double)h.peer_ids[(size_t)j];
+            mine[74 + 3 * j] = (double)h.send_ptr[(size_t)j];
+            mine[75 + 3 * j] = (double)(h.send_ptr[(size_t)j + 1] - h.send_ptr[(size_t)j]);
+        }
+        double *d_rec = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d_rec, sizeof(double) * (rec.size() + 8)));
+        HIP_CHECK(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+        boot_allreduce(d_rec, rec.size());
+        HIP_CHECK(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        // ---- map every NEIGHBOUR's buffer; find this rank's segment and arrival word in it
+        DirectDesc &d = link->d;
+        d = DirectDesc{};
+        d.n_peers = h.n_peers; d.err = link->err; d.spin_limit = mail_spins_;
+        if (const char *e = std::getenv("PCG_MAIL_SPINS")) d.spin_limit = (unsigned)std::max(1, atoi(e));
+        d.my_flags = link->buf ? (const unsigned long long *)((char *)link->buf + link->flags_off) : nullptr;
+        for (int j = 0; j <= h.n_peers && j <= kDirectMaxPeers; ++j) d.seg[j] = h.send_ptr.empty() ? 0 : h.send_ptr[(size_t)j];
+        for (int j = 0; j < h.n_peers && fail == 0; ++j) {
+            const int p = h.peer_ids[(size_t)j];
+            if (p < 0 || p >= size_ || (p == rank_ && !allow_self_)) { fail = 1; why = "neighbour part id is not a peer rank"; break; }
+            const double *q = rec.data() + (size_t)p * R;
+            if (q[0] != 1.0) { fail = 1; why = "rank " + std::to_string(p) + " sent no record"; break; }
+            if (q[2] != mine[2]) { fail = 1; why = "rank " + std::to_string(p) + " runs on another host"; break; }
+            int k_me = -1;                                               // this rank's place in p's neighbour list
+            for (int k = 0; k < (int)q[72]; ++k)
+                if ((int)q[73 + 3 * k] == rank_) { k_me = k; break; }
+            const int64_t cnt = h.send_ptr[(size_t)j + 1] - h.send_ptr[(size_t)j];
+            if (k_me < 0 || (int64_t)q[75 + 3 * k_me] != cnt) { fail = 1; why = "rank " + std::to_string(p) + " does not list this rank with the same interface size"; break; }
+            size_t p_total = 0;
+            for (int k = 0; k < (int)q[72]; ++k) p_total += (size_t)q[75 + 3 * k];
+            const size_t p_flags_off = (p_total * sizeof(double) + 127) / 128 * 128;
+            void *base = nullptr;
+            if (p == rank_) base = link->buf;                            // (tests: a part that is its own neighbour)
+            else if (q[1] == mine[1]) {                                  // same process: the pointer itself
+                if ((int)q[3] == dev_) { fail = 1; why = "ranks " + std::to_string(rank_) + " and " + std::to_string(p) + " of one process share a device: their kernels are not guaranteed to run concurrently"; break; }
+                int can = 0;
+                soft(hipDeviceCanAccessPeer(&can, dev_, (int)q[3]), "hipDeviceCanAccessPeer");
+                if (fail == 0 && !can) { fail = 1; why = "no peer access from device " + std::to_string(dev_) + " to " + std::to_string((int)q[3]); }
+                if (fail == 0) {
+                    const hipError_t e = hipDeviceEnablePeerAccess((int)q[3], 0);
+                    if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    else soft(e, "hipDeviceEnablePeerAccess");
+                }
+                unsigned long long pp = 0;
+                for (int k = 0; k < 4; ++k) pp |= (unsigned long long)q[4 + k] << (16 * k);
+                base = (void *)(uintptr_t)pp;
+            } else {
+                hipIpcMemHandle_t ph;
+                for (int k = 0; k < 64; ++k) ((unsigned char *)&ph)[k] = (unsigned char)q[8 + k];
+                if (soft(hipIpcOpenMemHandle(&base, ph, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) link->peer_ipc[j] = true;
+            }
+            if (fail != 0) break;
+            link->peer_base[j] = base;
+            d.peer_recv[j] = (double *)base + (size_t)q[74 + 3 * k_me];
+            d.peer_flag[j] = (unsigned long long *)((char *)base + p_flags_off) + k_me;
+        }
+        double *d_flag = d_rec + rec.size();
+        HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
+        boot_allreduce(d_flag, 1);
+        double any = 0;
+        HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(d_rec);
+        if (any != 0) {
+            if (why.empty()) why = "another rank could not map a neighbour's buffer";
+            return nullptr;
+        }
+        return link;
+    }
     void allreduce(double *buf, int count, void *compute_stream) override
     {
         RcclApi &A = api();

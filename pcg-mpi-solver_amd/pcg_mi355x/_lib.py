@@ -53,7 +53,7 @@ class CommStats(C.Structure):
                 ("n_allreduce", C.c_int64), ("n_halo_timed", C.c_int64), ("n_allreduce_timed", C.c_int64)]
 
 
-ABI_VERSION = 5            # include/pcg_mi355x.h PCG_ABI_VERSION: the struct layouts above belong to this version
+ABI_VERSION = 6            # include/pcg_mi355x.h PCG_ABI_VERSION: the struct layouts above belong to this version
 RCCL_ID_BYTES = 256
 FORMAT_DICTIONARY = 0x100
 
@@ -90,6 +90,7 @@ _SIGS = {
     "pcg_set_comm_native": (C.c_int, [_P, _P]),
     "pcg_comm_set_timing": (C.c_int, [_P, C.c_int32]),
     "pcg_comm_enable_mailbox": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
+    "pcg_enable_direct_exchange": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     "pcg_comm_get_stats": (C.c_int, [_P, C.POINTER(CommStats)]),
     "pcg_apply": (C.c_int, [_P, _P, _P]),
     "pcg_diag": (C.c_int, [_P, _P]),

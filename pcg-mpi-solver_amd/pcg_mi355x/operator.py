@@ -89,9 +89,12 @@ class Operator:
             n_elem = sum(int(np.asarray(g["ElemList_Ck"]).shape[0]) for g in ebe_groups)
             # (1 M dof / 328 k elements: 0.034 ms per apply with 717 chunks of 512 vs 0.040 with 1433 of 256; 59 k elements: 256 wins)
             ept = os.environ.get("PCG_EBE_EPT", "1" if n_elem < 256 * 512 else "2")
+            # one phase (flags bit 2): no interface-first launch - for jobs that exchange AFTER the whole operator, i.e. with the direct
+            # exchange (PCG_DIRECT_EXCHANGE=1 on every rank implies it; PCG_EBE_ONE_PHASE=0|1 overrides)
+            one_phase = os.environ.get("PCG_EBE_ONE_PHASE", "1" if os.environ.get("PCG_DIRECT_EXCHANGE") == "1" else "0") == "1"
             check(L.pcg_create_ebe(device, self.n_nodes, len(ebe_groups), arr, perm.ctypes.data if perm is not None else None,
                                    int(n_boundary_nodes), xyz.ctypes.data if xyz is not None else None,
-                                   (0 if ebe_chunked else 1) | (2 if ept == "1" else 0), C.byref(h)), "pcg_create_ebe")
+                                   (0 if ebe_chunked else 1) | (2 if ept == "1" else 0) | (4 if one_phase else 0), C.byref(h)), "pcg_create_ebe")
             self.nnzb = self.nnz = 0
         else:
             self.kind = "sell"
@@ -229,9 +232,25 @@ class Operator:
             return
         if getattr(comm, "native", False):
             check(self._L.pcg_set_comm_native(self._h, comm.handle), "pcg_set_comm_native")
+            if os.environ.get("PCG_DIRECT_EXCHANGE") == "1":       # opt-in for a whole job (every rank sets it): see enable_direct_exchange
+                self.enable_direct_exchange()
             return
         self._hooks = comm.make_hooks(self)
         check(self._L.pcg_set_comm(self._h, C.byref(self._hooks)), "pcg_set_comm")
+
+    direct_exchange = False
+    direct_exchange_reason = None
+
+    def enable_direct_exchange(self, on=True):
+        """Opt-in, COLLECTIVE (every rank's engine of the job, between solves, after set_halo and set_comm with a native
+        communicator): the interface exchange of the PCG iteration (pcg_solver.py:307-328) as stores into the neighbours'
+        peer-mapped receive buffers instead of grouped ncclSend / ncclRecv (include/pcg_mi355x.h pcg_enable_direct_exchange).
+        -> True when every rank mapped its neighbours; False (on every rank) = RCCL stays, `direct_exchange_reason` says why."""
+        got = C.c_int32(0)
+        check(self._L.pcg_enable_direct_exchange(self._h, 1 if on else 0, C.byref(got)), "pcg_enable_direct_exchange")
+        self.direct_exchange = bool(got.value)
+        self.direct_exchange_reason = None if (self.direct_exchange or not on) else (self._L.pcg_last_error() or b"").decode(errors="replace")
+        return self.direct_exchange
 
     def stream_ptr(self):
         return self._L.pcg_stream(self._h)

@@ -309,8 +309,10 @@ public:
         for (size_t m = 0; m < h_.send_idx.size(); ++m) send[m] = y[h_.send_idx[m]];
     }
     bool mailbox_kernels_available() const override { return true; }
-    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail) override
+    void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail,
+                        const DirectDesc *direct) override
     {
+        if (direct) throw std::runtime_error("boundary_fixup: the CPU test double has no direct exchange");
         if (mail && (h_.fix_dof.empty() || !with_dot || !reduce_pq)) throw std::runtime_error("boundary_fixup: mailbox all-reduce without the fused reduction");
         struct ReduceAtExit { HostBackend *b; double *r; const MailDesc *m; ~ReduceAtExit() { if (r) { b->reduce_dot(r); if (m) host_mail_allreduce(*m, r, 1); } } }
             reduce_at_exit{this, with_dot ? reduce_pq : nullptr, mail};

@@ -28,8 +28,10 @@ def run_rank(P, x_probe, comm, kind, device, timing):
     import pcg_mi355x as pm
     from pcg_mi355x.operator import from_refmeshpart
     out = {"rank": comm.rank, "dofs": P["DofVector"]}
-    op = from_refmeshpart(P, device=device, comm=comm, kind=kind)
+    op = from_refmeshpart(P, device=device, comm=comm, kind=kind)     # (PCG_EBE_ONE_PHASE=1 in the environment: no interface-first launch)
     try:
+        if os.environ.get("PCG_TEST_DIRECT", "0") == "1":          # opt-in engine-side exchange (pcg_enable_direct_exchange), collective
+            assert op.enable_direct_exchange(), f"direct exchange refused: {op.direct_exchange_reason}"
         out["y_probe"] = op.apply(x_probe)
         out["diag"] = op.diag()
         fext, udi = op.update_bc(P["RefLoadVector"], P["Ud"], 1.0)

@@ -165,6 +165,34 @@ def test_mailbox_reduction_between_processes_sharing_one_gpu(gpu_lib, tmp_path, 
     _same_bits(case, kind, dirs["0"], dirs["1"], world)
 
 
+@pytest.mark.parametrize("case,world,kind", [("n9_p2", 2, "sell"), ("oct_p3", 3, "ebe"), ("n9_p8", 8, "ebe"), ("n13_t3_p4_ud", 4, "sell")])
+def test_direct_exchange_between_processes_sharing_one_gpu(gpu_lib, tmp_path, monkeypatch, case, world, kind):
+    """Round 5, opt-in pcg_enable_direct_exchange: the interface exchange of the PCG iteration (pcg_solver.py:307-328) as stores into the
+    neighbours' peer-mapped receive buffers (k_halo_put) + arrival words the fix-up waits for, instead of grouped ncclSend / ncclRecv -
+    one process per rank, the buffers mapped through hipIpcMemHandle, all ranks on device 0.  Alone and together with the mailbox
+    all-reduce (then no collective kernel is left in the iteration): every fixture reproduced, bit-identical to the RCCL path."""
+    dirs = {}
+    for tag, direct, mb in (("rccl", "0", "0"), ("direct", "1", "0"), ("direct_mail", "1", "1")):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.setenv("PCG_TEST_DIRECT", direct)
+        monkeypatch.setenv("PCG_TEST_MAILBOX", mb)
+        _run_procs(case, kind, world, d, True, [0] * world)
+        dirs[tag] = d
+    for tag in ("direct", "direct_mail"):
+        _check(case, kind, dirs[tag], world)
+        _same_bits(case, kind, dirs["rccl"], dirs[tag], world)
+    if kind == "ebe":
+        # the form the direct exchange is meant for: a matrix-free engine built WITHOUT an interface-first phase (pcg_create_ebe flags
+        # bit 2) - one element launch, then the put, then the fix-up.  Another order of the dot partials: checked against the fixture.
+        d = tmp_path / "one_phase"
+        d.mkdir()
+        monkeypatch.setenv("PCG_EBE_ONE_PHASE", "1")
+        _run_procs(case, kind, world, d, True, [0] * world)
+        monkeypatch.delenv("PCG_EBE_ONE_PHASE")
+        _check(case, kind, d, world)
+
+
 def test_mailbox_on_real_rccl_world_size_1(gpu_lib, tmp_path, monkeypatch):
     """Real librccl carries the bootstrap exchange of the handles and the agreement all-reduces (world size 1 on this box)."""
     monkeypatch.setenv("PCG_TEST_MAILBOX", "1")
@@ -268,6 +296,10 @@ def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
         assert 0 < o10[key]["roofline_iteration"]["frac"] < 1 and o10[key]["comm"]["exchanges_per_iter"] >= 1
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 2 and "2 parts" in cb["sample"]
+    dx = out["comm"]["mailbox"].get("direct_exchange")    # ... and the engine-side exchange on top (one-phase matrix-free engine)
+    assert dx and "error" not in dx, dx
+    for key in ("assembled", "matrix_free"):
+        assert dx[key]["enabled"] and dx[key]["value"] > 0 and dx[key]["solve"]["flag"] == 0, dx[key]
     mb = out["comm"]["mailbox"]                       # the engine-side reduction beside the RCCL windows: same sums in the same order here
     assert mb["enabled"] and mb["assembled"]["value"] > 0 and mb["matrix_free"]["value"] > 0
     assert (mb["assembled"]["solve"]["flag"], mb["assembled"]["solve"]["iter"]) == (out["solve"]["flag"], out["solve"]["iter"])

@@ -7,7 +7,9 @@ so the interface rows' launch, the pack, the grouped ncclSend / ncclRecv on the 
 ncclAllReduce run as they would on 8 GPUs, minus the wire.  (The exchange returns the part's own partial sums, i.e. the operator
 is not the assembled one: timing only - the window is short and checked for an early exit.)
 usage: python tools/multi_part_iter.py [N] [steps] [kinds] [modes]      modes: PCG_ITER_FUSED values switched per solve (default 1,0);
-       "m" = the five-launch form with the engine-side reduction (pcg_comm_enable_mailbox: no ncclAllReduce kernel; round 5)"""
+       "m" = the five-launch form with the engine-side reduction (pcg_comm_enable_mailbox: no ncclAllReduce kernel; round 5);
+       "d" = the engine-side EXCHANGE (pcg_enable_direct_exchange: stores into the neighbour's mapped buffer, no ncclSend / ncclRecv kernel, one
+       stream), "dm" = both: no collective kernel left in the iteration"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pcg-mpi-solver_amd")]
@@ -36,8 +38,9 @@ for kind in kinds:
     inv = op.build_jacobi()
     for rep in range(2):
         for fused in modes:
-            os.environ["PCG_ITER_FUSED"] = "1" if fused == "m" else fused
-            assert comm.enable_mailbox(fused == "m") == (fused == "m"), comm.mailbox_reason
+            os.environ["PCG_ITER_FUSED"] = "1" if fused in ("m", "d", "dm") else fused
+            assert comm.enable_mailbox(fused in ("m", "dm")) == (fused in ("m", "dm")), comm.mailbox_reason
+            assert op.enable_direct_exchange(fused in ("d", "dm")) == (fused in ("d", "dm")), op.direct_exchange_reason
             op.solve_begin(fext, None, inv, 1e-30, 100000, P["GlobData"]["GlobNDofEff"])
             op.solve_run(5)
             torch.cuda.synchronize(); t0 = time.perf_counter()
