@@ -309,10 +309,25 @@ public:
         for (size_t m = 0; m < h_.send_idx.size(); ++m) send[m] = y[h_.send_idx[m]];
     }
     bool mailbox_kernels_available() const override { return true; }
+    // direct exchange (csrc/kernels_vector.hpp k_halo_put / wait_for_neighbours) on host memory: every part runs on its own host thread
+    bool direct_kernels_available() const override { return true; }
+    void halo_put(const double *y, const DirectDesc &d) override
+    {
+        for (int j = 0; j < d.n_peers; ++j)
+            for (long long m = d.seg[j]; m < d.seg[j + 1]; ++m) d.peer_recv[j][m - d.seg[j]] = y[h_.send_idx[(size_t)m]];
+        for (int j = 0; j < d.n_peers; ++j) __atomic_store_n(d.peer_flag[j], d.seq, __ATOMIC_RELEASE);
+    }
     void boundary_fixup(double *y, const double *recv, const double *xdot, bool with_dot, double *reduce_pq, const MailDesc *mail,
                         const DirectDesc *direct) override
     {
-        if (direct) throw std::runtime_error("boundary_fixup: the CPU test double has no direct exchange");
+        if (direct)
+            for (int j = 0; j < direct->n_peers; ++j) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (__atomic_load_n(direct->my_flags + j, __ATOMIC_ACQUIRE) < direct->seq) {
+                    std::this_thread::yield();
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { __atomic_store_n(direct->err, 1u, __ATOMIC_RELAXED); break; }
+                }
+            }
         if (mail && (h_.fix_dof.empty() || !with_dot || !reduce_pq)) throw std::runtime_error("boundary_fixup: mailbox all-reduce without the fused reduction");
         struct ReduceAtExit { HostBackend *b; double *r; const MailDesc *m; ~ReduceAtExit() { if (r) { b->reduce_dot(r); if (m) host_mail_allreduce(*m, r, 1); } } }
             reduce_at_exit{this, with_dot ? reduce_pq : nullptr, mail};

@@ -38,6 +38,26 @@ struct World {
     int attached = 0;
     std::vector<double *> mail;                                             // every rank's mailbox (enable_mailbox)
     int mail_registered = 0;
+    // direct exchange (direct_link): the k-th call of every rank forms generation k; a rank's record = its buffer + segment layout
+    struct DirectRec { unsigned long long *buf = nullptr; size_t flags_word = 0; std::vector<int32_t> peers; std::vector<int64_t> off, cnt; };
+    std::map<int64_t, std::vector<DirectRec>> direct;                       // generation -> records by rank
+    std::map<int64_t, int> direct_registered, direct_done, direct_failed;   // per generation: records in, look-ups finished, look-ups failed
+};
+
+// One engine's side of the direct exchange on the CPU double (csrc/rccl_comm.hip RcclDirectLink): host memory, the same descriptor.
+class LocalDirectLink : public DirectLink {
+public:
+    std::vector<unsigned long long> store;            // [receive buffer: total doubles][arrival words: kDirectMaxPeers]
+    DirectDesc d{};
+    unsigned long long seq = 0;
+    unsigned err = 0;
+    CommStats *stats = nullptr;
+    double *recv() override { return reinterpret_cast<double *>(store.data()); }
+    DirectDesc next() override { d.seq = ++seq; if (stats) stats->n_halo++; return d; }
+    void check() override
+    {
+        if (err) { err = 0; throw std::runtime_error("local comm: a direct-exchange wait timed out"); }
+    }
 };
 
 std::mutex g_reg_m;
@@ -56,6 +76,7 @@ class LocalComm : public Comm {
     bool mail_on_ = false;
     unsigned long long mail_seq_ = 0;
     unsigned mail_err_ = 0;
+    int64_t direct_calls_ = 0;
 
 public:
     LocalComm(int rank, int nranks, const void *ids) : rank_(rank), size_(nranks)
@@ -142,6 +163,60 @@ public:
     void mailbox_check() override
     {
         if (mail_err_) { mail_err_ = 0; throw std::runtime_error("local comm: a mailbox poll timed out"); }
+    }
+    // COLLECTIVE like the product's (every rank's k-th call belongs to generation k): the ranks publish buffer + layout, then every
+    // rank looks up its segment and arrival word at each neighbour
+    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) override
+    {
+        why.clear();
+        auto link = std::make_unique<LocalDirectLink>();
+        link->stats = &st_;
+        const int64_t total = h.n_peers > 0 ? h.send_ptr[(size_t)h.n_peers] : 0;
+        link->store.assign((size_t)total + kDirectMaxPeers, 0ull);
+        const int64_t gen = ++direct_calls_;
+        bool bad = h.n_peers > kDirectMaxPeers;
+        std::unique_lock<std::mutex> lk(w_->m);
+        auto &recs = w_->direct[gen];
+        recs.resize((size_t)size_);
+        World::DirectRec &me = recs[(size_t)rank_];
+        me.buf = link->store.data();
+        me.flags_word = (size_t)total;
+        for (int j = 0; j < h.n_peers; ++j) {
+            me.peers.push_back(h.peer_ids[(size_t)j]);
+            me.off.push_back(h.send_ptr[(size_t)j]);
+            me.cnt.push_back(h.send_ptr[(size_t)j + 1] - h.send_ptr[(size_t)j]);
+        }
+        w_->direct_registered[gen]++;
+        w_->cv.notify_all();
+        if (!w_->cv.wait_for(lk, kTimeout, [&] { return w_->direct_registered[gen] >= size_; }))
+            throw std::runtime_error("local comm: a peer never entered direct_link");
+        DirectDesc &d = link->d;
+        d = DirectDesc{};
+        d.n_peers = h.n_peers; d.err = &link->err; d.spin_limit = 0;
+        d.my_flags = link->store.data() + total;
+        for (int j = 0; j <= h.n_peers && j <= kDirectMaxPeers; ++j) d.seg[j] = h.send_ptr.empty() ? 0 : h.send_ptr[(size_t)j];
+        for (int j = 0; j < h.n_peers && !bad; ++j) {
+            const int p = h.peer_ids[(size_t)j];
+            if (p < 0 || p >= size_ || p == rank_) { bad = true; why = "neighbour part id is not a peer rank"; break; }
+            const World::DirectRec &q = recs[(size_t)p];
+            int k_me = -1;
+            for (size_t k = 0; k < q.peers.size(); ++k)
+                if (q.peers[k] == rank_) { k_me = (int)k; break; }
+            if (k_me < 0 || q.cnt[(size_t)k_me] != me.cnt[(size_t)j]) { bad = true; why = "a neighbour does not list this rank with the same interface size"; break; }
+            d.peer_recv[j] = reinterpret_cast<double *>(q.buf) + q.off[(size_t)k_me];
+            d.peer_flag[j] = q.buf + q.flags_word + k_me;
+        }
+        // agree: every rank takes the same decision (a second rendezvous on the generation)
+        if (bad) w_->direct_failed[gen]++;
+        w_->direct_done[gen]++;
+        w_->cv.notify_all();
+        if (!w_->cv.wait_for(lk, kTimeout, [&] { return w_->direct_done[gen] >= size_; }))
+            throw std::runtime_error("local comm: a peer never finished direct_link");
+        if (w_->direct_failed[gen] != 0) {
+            if (why.empty()) why = "another rank could not map a neighbour's buffer";
+            return nullptr;
+        }
+        return link;
     }
     void allreduce(double *buf, int count, void *) override                                 // :622-628
     {

@@ -162,3 +162,34 @@ def test_big_multi_part_harness_on_the_test_double(oracle_c, tmp_path):
     r = subprocess.run([sys.executable, WORKER, "bigbrick", "21", "sell,ebe", out, "30"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     check_big_brick_report(json.load(open(out)), ("sell", "ebe"), 30)
+
+
+def test_direct_exchange_on_the_test_double(tmp_path):
+    """Round 5, opt-in pcg_enable_direct_exchange on the CPU double (tests/hostops: LocalComm::direct_link, HostBackend::halo_put and the
+    fix-up's wait - the protocol of csrc/kernels_vector.hpp k_halo_put / wait_for_neighbours on host memory, one host thread per part):
+    the DRIVER's sequencing of the direct exchange (pcg_driver.cpp apply: iteration applies through the peer-mapped buffer, set-up and
+    true-residual applies through the ordinary exchange, look-ahead drops in between) on 2 - 8 parts, every fixture reproduced and
+    bit-identical to the ordinary exchange, alone and with the mailbox all-reduce; the one-phase matrix-free engine against the fixture."""
+    import os
+    import subprocess
+    import sys
+    import conftest
+    from test_native_comm import WORKER, _check, _same_bits
+    cases = "n9_p8,oct_p3,n13_t3_p4_ud,n9_p2_flag4,goct_sym_p3"
+    dirs = {}
+    for tag, direct, mb, one in (("plain", "0", "0", "0"), ("direct", "1", "0", "0"), ("direct_mail", "1", "1", "0"), ("one_phase", "1", "1", "1")):
+        d = tmp_path / tag
+        d.mkdir()
+        env = dict(os.environ, PCG_TEST_LIB=conftest.build_hostops(), PCG_TEST_DIRECT=direct, PCG_TEST_MAILBOX=mb, PCG_EBE_ONE_PHASE=one,
+                   PCG_TEST_COMM_TIMING="0")
+        env.pop("PCG_RCCL_LIB", None)
+        r = subprocess.run([sys.executable, WORKER, "threads", cases, "ebe" if one == "1" else "sell,ebe", str(d)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        dirs[tag] = d
+    for case in cases.split(","):
+        world = len([f for f in os.listdir(dirs["plain"]) if f.startswith(case + "_sell_rank")])
+        for kind in ("sell", "ebe"):
+            for tag in ("direct", "direct_mail"):
+                _check(case, kind, dirs[tag], world)
+                _same_bits(case, kind, dirs["plain"], dirs[tag], world)
+        _check(case, "ebe", dirs["one_phase"], world)
