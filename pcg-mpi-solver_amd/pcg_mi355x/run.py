@@ -178,6 +178,11 @@ def main(argv=None):
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N > 1: native = RCCL calls issued by the engine (default); torch = torch.distributed callbacks")
     ap.add_argument("--speed-test", action="store_true")
+    ap.add_argument("--engine-side", action="store_true",
+                    help="N > 1, native communicator (round 5, opt-in): MPI_SUM through peer-mapped mailboxes inside the engine's own launches "
+                         "(pcg_comm_enable_mailbox) and the interface exchange of the iteration as stores into the neighbours' mapped "
+                         "receive buffers (pcg_enable_direct_exchange; matrix-free engines without the interface-first launch) - no collective "
+                         "kernel in the PCG loop.  Falls back to RCCL, on every rank together, where a peer cannot be mapped")
     ap.add_argument("--group", action="store_true",
                     help="ONE process drives all --n-parts GPUs (device group, C ABI pcg_group_*) instead of one process per GPU")
     args = ap.parse_args(argv)
@@ -211,6 +216,11 @@ def main(argv=None):
         if args.comm == "native":
             comm = RcclComm.from_torch(dev)
             comm.set_timing(True)                          # the reference always keeps its calc / comm-wait split (:631-641)
+            if args.engine_side:                           # collective: every rank runs these same lines
+                got = comm.enable_mailbox(True)
+                os.environ["PCG_DIRECT_EXCHANGE"] = "1"    # Operator.set_comm enables the direct exchange (and says why when it cannot)
+                if rank == 0:
+                    print(f">engine-side all-reduce: {'on' if got else 'declined - ' + str(comm.mailbox_reason)}; engine-side exchange: requested")
         else:
             comm = TorchComm(device=torch.device("cuda", dev))
     solver.configure(comm=comm, device=dev, operator=args.operator)
@@ -260,6 +270,8 @@ def main(argv=None):
               f">flag {flag[1:]}, iterations {it[1:]}, relres {relres[1:]}")
     op = part.pop("_pcg_mi355x_operator", None)
     if op is not None:
+        if args.engine_side and rank == 0 and world > 1:
+            print(f">engine-side exchange: {'on' if op.direct_exchange else 'declined - ' + str(op.direct_exchange_reason)}")
         op.close()
     if world > 1:
         dist.barrier()

@@ -251,9 +251,16 @@ def _oracle_load_steps(model, ele_part, deltas):
 
 
 @pytest.mark.gpu
+def test_load_step_driver_with_the_engine_side_forms_on_gpu(gpu_lib, tmp_path):
+    """`python -m pcg_mi355x.run --engine-side` (round 5): the same two load steps on 3 ranks with the mailbox all-reduce and the direct
+    exchange switched on by the driver (processes sharing the GPU map each other through hipIpcMemHandle), matrix-free."""
+    test_load_step_driver_on_gpu(gpu_lib, "part_octree_p3", 3, "ebe", tmp_path, extra=("--engine-side",))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 @pytest.mark.parametrize("name,ranks", [("part_brick_p1", 1), ("part_octree_p3", 3), ("part_octree_p3", -3)])
-def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
+def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path, extra=()):
     """SURVEY 8(f)-4 on the HIP engine: MDF -> `python -m pcg_mi355x.run` with TWO load steps (warm start from the
     previous Un, :358,:378) -> U_<k>.mpidat / TimeData in the layout export_vtk.py reads, vs the oracle's loop.
     3 ranks: one process per part with the engine's native communicator; on the 1-GPU box they share the device and talk
@@ -285,9 +292,11 @@ def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
                 "--master-port", str(29700 + (kind == "ebe"))]
     cmd += ["-m", "pcg_mi355x.run", "--mdf", path, "--settings", str(tmp_path / "GlobSettings.zpkl"), "--results", results,
-            "--operator", kind] + (["--group", "--n-parts", str(ranks)] if group else [])
+            "--operator", kind] + (["--group", "--n-parts", str(ranks)] if group else []) + list(extra)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    if extra:
+        assert ">engine-side all-reduce: on" in r.stdout and ">engine-side exchange: on" in r.stdout, r.stdout[-2000:]
     sols, its = _oracle_load_steps(model, ele_part, deltas)
     td = np.load(os.path.join(results, "PlotData", "TimeData.npz"))
     dof = pio.read_result_vector(os.path.join(results, "ResVecData", "Dof"))
