@@ -51,7 +51,7 @@ typedef struct pcg_asm pcg_asm;
  * hooks of a part without neighbours unconditionally - since 3 only with collective_exchange != 0);
  * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4);
  * 5 = pcg_comm_enable_mailbox(), pcg_group_enable_mailbox() (round 5; no struct changed);
- * 6 = pcg_enable_direct_exchange() (round 5; no struct changed). */
+ * 6 = pcg_enable_direct_exchange(), pcg_group_enable_direct_exchange(), pcg_create_ebe flags bit 2 (round 5; no struct changed). */
 #define PCG_ABI_VERSION 6
 int pcg_abi_version(void);
 const char *pcg_last_error(void);
@@ -312,6 +312,7 @@ int pcg_group_solve(pcg_group *g, const double *const *b, const double *const *x
                     int64_t hist_cap, pcg_result *res /* n_dev results, may be NULL */);
 int pcg_group_set_timing(pcg_group *g, int32_t on);           /* pcg_comm_set_timing on every member */
 int pcg_group_enable_mailbox(pcg_group *g, int32_t on, int32_t *enabled_out);   /* pcg_comm_enable_mailbox on every member (one process: direct peer pointers) */
+int pcg_group_enable_direct_exchange(pcg_group *g, int32_t on, int32_t *enabled_out);   /* pcg_enable_direct_exchange on every member's attached engine (ABI 6) */
 
 /* ---- measurement / unit-test entry points --------------------------------------------------- */
 /* Back-to-back local SpMV launches timed with HIP events on the engine stream. */

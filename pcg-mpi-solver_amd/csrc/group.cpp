@@ -273,4 +273,17 @@ int pcg_group_enable_mailbox(pcg_group *g, int32_t on, int32_t *enabled_out)
     return rc;
 }
 
+int pcg_group_enable_direct_exchange(pcg_group *g, int32_t on, int32_t *enabled_out)
+{
+    if (!g) return set_error("pcg_group_enable_direct_exchange: null");
+    if (g->need_engines("pcg_group_enable_direct_exchange")) return -1;
+    std::vector<int32_t> got((size_t)g->n, 0);
+    const int rc = g->run_all("pcg_group_enable_direct_exchange", [&](int k) { return pcg_enable_direct_exchange(g->eng[k], on, &got[(size_t)k]); });
+    if (enabled_out) {
+        *enabled_out = 1;
+        for (int32_t v : got) if (!v) *enabled_out = 0;
+    }
+    return rc;
+}
+
 }  // extern "C"

@@ -117,6 +117,7 @@ _SIGS = {
     "pcg_group_solve": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P]),
     "pcg_group_set_timing": (C.c_int, [_P, C.c_int32]),
     "pcg_group_enable_mailbox": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
+    "pcg_group_enable_direct_exchange": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     "pcg_bench_spmv": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "pcg_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "pcg_operator_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

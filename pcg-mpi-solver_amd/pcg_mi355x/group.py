@@ -189,6 +189,13 @@ class DeviceGroup:
         check(self._L.pcg_group_enable_mailbox(self._h, 1 if on else 0, C.byref(got)), "pcg_group_enable_mailbox")
         return bool(got.value)
 
+    def enable_direct_exchange(self, on=True):
+        """pcg_enable_direct_exchange on every member's engine (the members map each other's receive buffers through plain peer
+        pointers; members on ONE device decline, like the mailboxes) -> True when all of them switched."""
+        got = C.c_int32(0)
+        check(self._L.pcg_group_enable_direct_exchange(self._h, 1 if on else 0, C.byref(got)), "pcg_group_enable_direct_exchange")
+        return bool(got.value)
+
     def close(self):
         """Engines first, then the group (its communicators must outlive the engines they are attached to)."""
         for k, op in enumerate(self.ops):

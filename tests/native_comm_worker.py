@@ -238,6 +238,7 @@ def main():
                         got = gs.group.enable_mailbox()
                         if refusal_ok and len(set(devs)) < len(devs):
                             assert not got, "members of one process on one device must decline the mailbox all-reduce"
+                            assert not gs.group.enable_direct_exchange(), "... and the direct exchange (pcg_group_enable_direct_exchange)"
                             print("MAILBOX REFUSED: device group with members on one device", flush=True)
                         else:
                             assert got, "mailbox all-reduce refused in the device group"

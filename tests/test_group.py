@@ -27,7 +27,7 @@ def _global(parts, key_or_list, n):
     return out
 
 
-def _run_case(case, kind, devices=None, mailbox=False):
+def _run_case(case, kind, devices=None, mailbox=False, direct=False):
     from pcg_mi355x.group import GroupSolver
     mesh, parts = golden_cases.build_case(case)
     g = golden(case)
@@ -37,6 +37,8 @@ def _run_case(case, kind, devices=None, mailbox=False):
     try:
         if mailbox:
             assert gs.group.enable_mailbox(), "the mailbox all-reduce did not come up"
+        if direct:
+            assert gs.group.enable_direct_exchange(), "the direct exchange did not come up"
         ys = gs.group.apply([probe[P["DofVector"]] for P in parts])
         ds = gs.group.diag()
         assert relerr(_global(parts, ys, n), g["y_probe"]) < 1e-13
@@ -99,6 +101,24 @@ def mailbox_reduction_is_bit_identical(cases=("n9_p8", "oct_p3", "n13_t3_p4_ud",
                 assert (a.flag, a.iter, a.relres, a.iters_done) == (b.flag, b.iter, b.relres, b.iters_done), (case, kind)
                 assert np.array_equal(a.history, b.history), (case, kind)
                 assert np.array_equal(pa["Un"], pb["Un"]), (case, kind)
+
+
+def test_direct_exchange_in_a_device_group_on_the_test_double(hostops, monkeypatch):
+    """Round 5, opt-in pcg_group_enable_direct_exchange: the members of ONE process exchange their interface values by writing into each
+    other's receive buffers (DirectDesc) instead of through the communicator's send / receive - alone, with the mailboxes, with the
+    look-ahead off: histories, exits and solutions bit for bit those of the ordinary exchange, every fixture still reproduced."""
+    for case, kind in (("n9_p8", "sell"), ("n9_p8", "ebe"), ("oct_p3", "ebe"), ("n13_t3_p4_ud", "sell"), ("n9_p2_flag4", "ebe"), ("goct_p4", "ebe")):
+        parts_a, infos_a = _run_case(case, kind)
+        for mb in (False, True):
+            parts_b, infos_b = _run_case(case, kind, mailbox=mb, direct=True)
+            for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b):
+                assert (a.flag, a.iter, a.relres, a.iters_done) == (b.flag, b.iter, b.relres, b.iters_done), (case, kind, mb)
+                assert np.array_equal(a.history, b.history), (case, kind, mb)
+                assert np.array_equal(pa["Un"], pb["Un"]), (case, kind, mb)
+    monkeypatch.setenv("PCG_LOOK_AHEAD", "0")
+    parts_a, infos_a = _run_case("n9_p8", "ebe")
+    parts_b, infos_b = _run_case("n9_p8", "ebe", mailbox=True, direct=True)
+    assert all(np.array_equal(a.history, b.history) and np.array_equal(pa["Un"], pb["Un"]) for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b))
 
 
 def test_mailbox_reduction_is_bit_identical_on_the_test_double(hostops, monkeypatch):
