@@ -271,6 +271,19 @@ def test_mailbox_reduction_across_gpus(gpu_lib, tmp_path, monkeypatch, case, wor
         _check(case, kind, tmp_path, world)
 
 
+@pytest.mark.parametrize("case,world", [("n9_p2", 2), ("n13_t3_p4_ud", 4), ("n9_p8", 8)])
+def test_direct_exchange_across_gpus(gpu_lib, tmp_path, monkeypatch, case, world):
+    """The direct exchange between DIFFERENT GPUs (stores over xGMI into hipIpcMemHandle-mapped receive buffers) with the mailbox
+    all-reduce on top - no collective kernel in the iteration; set-up applies on real RCCL; auto-skipped on the one-GPU box."""
+    if gpu_lib.lib().pcg_device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    monkeypatch.setenv("PCG_TEST_MAILBOX", "1")
+    monkeypatch.setenv("PCG_TEST_DIRECT", "1")
+    for kind in ("sell", "ebe"):
+        _run_procs(case, kind, world, tmp_path, False, list(range(world)))
+        _check(case, kind, tmp_path, world)
+
+
 def test_bench_launches_its_own_ranks(gpu_lib, tmp_path):
     """`python bench.py --gpus 2` (no torchrun around it) spawns its two ranks itself.  On the 1-GPU box the ranks share
     the device (PCG_BENCH_SHARE_GPU=1) and talk through the RCCL stand-in; the line it prints has the driver's shape AND
