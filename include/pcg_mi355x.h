@@ -212,8 +212,8 @@ int pcg_comm_get_stats(pcg_comm *c, pcg_comm_stats *out);
  * COLLECTIVE: every rank of the communicator calls it, between solves.  *enabled_out = 1 on every rank or 0 on every rank: when any
  * rank cannot map a peer (no peer access, IPC refused, ranks on different hosts, more than 16 ranks) or the self-test all-reduce
  * returns wrong sums, all ranks keep using ncclAllReduce and pcg_last_error() says why (the call itself still returns 0).
- * A poll that never sees a peer's contribution gives up after seconds, delivers NaN (the solve ends on it) and the next
- * pcg_solve_* call on that communicator returns an error - nothing hangs.  on = 0 switches back to ncclAllReduce (collective too). */
+ * A poll that never sees a peer's contribution gives up after seconds and delivers NaN; the host checks the report after every
+ * iteration and the running pcg_solve_* call returns an error - nothing hangs, nothing iterates on to MaxIter.  on = 0 switches back to ncclAllReduce (collective too). */
 int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out);
 /* Engine-side neighbour exchange (round 5, OPT-IN; RCCL's grouped ncclSend / ncclRecv stays the default): the reference's
  * Isend / Recv / Waitall over the interface dofs (pcg_solver.py:307-328) as stores over xGMI.  The engine's receive buffer and one
@@ -225,8 +225,8 @@ int pcg_comm_enable_mailbox(pcg_comm *c, int32_t on, int32_t *enabled_out);
  * Call it after pcg_set_halo and pcg_set_comm_native, between solves.  COLLECTIVE: every rank of the engine's communicator calls it
  * for its engine of the same job, neighbours or not.  *enabled_out = 1 on every rank or 0 on every rank (any rank that cannot map a
  * neighbour - no peer access, IPC refused, another host, two ranks of one process on one device - keeps all on RCCL; pcg_last_error()
- * says why, the call returns 0).  A wait that never sees a neighbour gives up after seconds and the next pcg_solve_* call returns an
- * error.  on = 0 drops the mapping (collective too: no rank may keep writing into a buffer its neighbour has freed). */
+ * says why, the call returns 0).  A wait that never sees a neighbour gives up after seconds; the host checks the report after every
+ * iteration and the running pcg_solve_* call returns an error.  on = 0 drops the mapping (collective too: no rank may keep writing into a buffer its neighbour has freed). */
 int pcg_enable_direct_exchange(pcg_engine *e, int32_t on, int32_t *enabled_out);
 
 /* ---- operator-level calls (host vectors, length n) ----------------------------------------- */

@@ -430,6 +430,10 @@ bool iterate_once(pcg_engine *e, double *hist, int64_t hist_cap, bool may_look_a
     }
     if (e->pending_publish == slot) e->flush_publish();        // no look-ahead carried iteration i's status copy: issue it now
     e->be->wait_status(slot, e->h_st);
+    // engine-side communication: a wait that gave up inside this iteration's launches (a peer that never posted: seconds per wait) ends
+    // the solve HERE with an error - not MaxIter iterations later, each paying the same time-out (NaN sums pass every test of :492-527)
+    if (e->comm) e->comm->mailbox_check();
+    if (e->direct) e->direct->check();
     const double *st = e->h_st;
     bool fused_done = fused;
     if (st[ST_ERR] != 0) {
