@@ -140,3 +140,56 @@ def test_multi_process_cpu_baseline_matches_one_process(oracle_c):
     o3 = mp_baseline.run("octree:tiny", 3, 20, use_c=False)
     assert o1["n_matvec"] == o3["n_matvec"] == 22 and abs(o1["relres_after"] / o3["relres_after"] - 1) < 1e-9
     assert o3["neighbours_max"] >= 1 and o3["dofs_per_rank_max"] < o1["dofs_per_rank_max"]
+
+
+def _bench_module():
+    import importlib.util
+    from util import ROOT
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_one_core_cpu_points_accept_a_part_with_neighbours(oracle_c):
+    """Round 5, found by the first N > 1 line with a CPU baseline: at N > 1 rank 0 holds ONE part of the system, and a part with
+    neighbours is not a system on its own (the oracle's exchange looked for part 1: KeyError).  The one-core points then time a
+    single-part brick of the same generator and say so."""
+    from pcg_mi355x.brick import Brick, make_parts
+    bench = _bench_module()
+    b = Brick(9, seed=0)
+    part = make_parts(b, (np.arange(b.n_elem) % 2).astype(np.int32))[0]
+    assert len(part["NbrMPIdVector"]) == 1
+    r = bench.numpy_reference_point(part, budget_s=0.5)
+    assert r["value"] > 0 and r["dofs"] == 3 * 70 ** 3 and "part with neighbours" in r["sample"]
+    r = bench.cpu_baseline_single(part, budget_s=0.5)
+    assert r["value"] > 0 and r["dofs"] == 3 * 70 ** 3
+
+
+def test_bench_launcher_accepts_the_watchdog_line(monkeypatch, capsys):
+    """Round 5: when the optional objects of an N > 1 line stall, rank 0's watchdog prints the headline it has and ends the job; the ranks'
+    launcher then exits non-zero.  launch_ranks() must hand that line on as it is - no retry over the torch callbacks, exit code 0."""
+    import json
+    import subprocess
+    import types
+    bench = _bench_module()
+    line = json.dumps({"metric": "m", "value": 123.0, "n_gpus": 2, "extras": "the optional objects after the headline windows (octree series, ...) did not finish"})
+    calls = []
+
+    class FakePopen:
+        def __init__(self, cmd, **kw):
+            calls.append(cmd)
+            self.returncode = 1
+            self.pid = 0
+
+        def communicate(self, timeout=None):
+            return line + "\n", "some rank was killed\n"
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    rc = bench.launch_ranks(types.SimpleNamespace(gpus=2, comm="native"))
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(calls) == 1 and json.loads(out[-1])["value"] == 123.0
+    # an ordinary failure (no line, or a line without the watchdog's mark) is still retried over the torch callbacks
+    line = ""
+    calls.clear()
+    rc = bench.launch_ranks(types.SimpleNamespace(gpus=2, comm="native"))
+    assert len(calls) == 2 and rc != 0
