@@ -875,7 +875,7 @@ def test_mixed_chunked_and_colour_groups_with_neighbours_on_gpu(gpu_lib):
 def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     """The RCCL comm hooks on the GPU (world_size 1 on the 1-GPU box): device-pointer views, the
     engine stream as ExternalStream, all_reduce in place.  Must equal the hook-free run."""
-    outs = run_dist("n9_p1", 1, "nccl", "product", tmp_path, 29631)
+    outs = run_dist("n9_p1", 1, "nccl", "product", tmp_path)
     g = golden("n9_p1")
     o = outs[0]
     assert int(o["n_allreduce"]) > 200

@@ -103,33 +103,6 @@ def mailbox_reduction_is_bit_identical(cases=("n9_p8", "oct_p3", "n13_t3_p4_ud",
                 assert np.array_equal(pa["Un"], pb["Un"]), (case, kind)
 
 
-def test_direct_exchange_in_a_device_group_on_the_test_double(hostops, monkeypatch):
-    """Round 5, opt-in pcg_group_enable_direct_exchange: the members of ONE process exchange their interface values by writing into each
-    other's receive buffers (DirectDesc) instead of through the communicator's send / receive - alone, with the mailboxes, with the
-    look-ahead off: histories, exits and solutions bit for bit those of the ordinary exchange, every fixture still reproduced."""
-    for case, kind in (("n9_p8", "sell"), ("n9_p8", "ebe"), ("oct_p3", "ebe"), ("n13_t3_p4_ud", "sell"), ("n9_p2_flag4", "ebe"), ("goct_p4", "ebe")):
-        parts_a, infos_a = _run_case(case, kind)
-        for mb in (False, True):
-            parts_b, infos_b = _run_case(case, kind, mailbox=mb, direct=True)
-            for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b):
-                assert (a.flag, a.iter, a.relres, a.iters_done) == (b.flag, b.iter, b.relres, b.iters_done), (case, kind, mb)
-                assert np.array_equal(a.history, b.history), (case, kind, mb)
-                assert np.array_equal(pa["Un"], pb["Un"]), (case, kind, mb)
-    monkeypatch.setenv("PCG_LOOK_AHEAD", "0")
-    parts_a, infos_a = _run_case("n9_p8", "ebe")
-    parts_b, infos_b = _run_case("n9_p8", "ebe", mailbox=True, direct=True)
-    assert all(np.array_equal(a.history, b.history) and np.array_equal(pa["Un"], pb["Un"]) for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b))
-
-
-def test_mailbox_reduction_is_bit_identical_on_the_test_double(hostops, monkeypatch):
-    mailbox_reduction_is_bit_identical()
-    monkeypatch.setenv("PCG_ITER_FUSED", "0")          # no last-workgroup reductions to ride on: every all-reduce by its own kernel
-    mailbox_reduction_is_bit_identical(cases=("n9_p8", "oct_p3"))
-    monkeypatch.delenv("PCG_ITER_FUSED")
-    monkeypatch.setenv("PCG_LOOK_AHEAD", "0")
-    mailbox_reduction_is_bit_identical(cases=("n9_p8",))
-
-
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 @pytest.mark.parametrize("mailbox", [False, True])
 def test_group_with_a_member_without_neighbours(hostops, kind, mailbox):

@@ -12,7 +12,7 @@ import pytest
 import partition_cases as pc
 from pcg_mi355x import mdf, partition
 from pcg_mi355x.io import read_partition, write_partition
-from util import GOLDEN, golden, relerr, check_solution_against_golden
+from util import GOLDEN, golden, relerr, check_solution_against_golden, free_port, dump_failed_run
 
 
 def assert_same_part(flat_ref, part, prefix):
@@ -139,8 +139,7 @@ def test_mdf_to_solution_matches_reference_pipeline(hostops, name, kind, tmp_pat
         check_solution_against_golden(g, int(gd["TimeList_Flag"][1]), int(gd["TimeList_Iter"][1]), float(gd["TimeList_RelRes"][1]),
                                       un, None, tol_iter=tol_iter)
     else:
-        port = 29620 + list(pc.CASES).index(name) * 2 + (kind == "ebe")
-        res = run_dist("partition:" + name, n_parts, "gloo", "hostops", tmp_path, port, extra=(kind,))
+        res = run_dist("partition:" + name, n_parts, "gloo", "hostops", tmp_path, extra=(kind,))
         un = np.zeros(model["GlobNDof"])
         for r in reversed(res):
             un[r["DofVector"]] = r["Un"]
@@ -158,7 +157,7 @@ def test_partition_files_feed_a_multi_rank_solve(hostops, tmp_path):
     mdf.write_mdf(str(tmp_path / "model"), model)
     prefix = prepare.prepare(str(tmp_path / "model"), str(tmp_path / "scratch"), 3, ele_part=ele_part, log=lambda m: None)
     assert sorted(f for f in os.listdir(prefix) if f.endswith(".mpidat")) == ["3_0.mpidat", "3_1.mpidat", "3_2.mpidat"]
-    res = run_dist("files:" + prefix, 3, "gloo", "hostops", tmp_path, 29690)
+    res = run_dist("files:" + prefix, 3, "gloo", "hostops", tmp_path)
     un = np.zeros(model["GlobNDof"])
     for r in reversed(res):
         un[r["DofVector"]] = r["Un"]
@@ -251,16 +250,13 @@ def _oracle_load_steps(model, ele_part, deltas):
 
 
 @pytest.mark.gpu
-def test_load_step_driver_with_the_engine_side_forms_on_gpu(gpu_lib, tmp_path):
-    """`python -m pcg_mi355x.run --engine-side` (round 5): the same two load steps on 3 ranks with the mailbox all-reduce and the direct
-    exchange switched on by the driver (processes sharing the GPU map each other through hipIpcMemHandle), matrix-free."""
-    test_load_step_driver_on_gpu(gpu_lib, "part_octree_p3", 3, "ebe", tmp_path, extra=("--engine-side",))
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["sell", "ebe"])
 @pytest.mark.parametrize("name,ranks", [("part_brick_p1", 1), ("part_octree_p3", 3), ("part_octree_p3", -3)])
-def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path, extra=()):
+def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path):
+    run_load_step_driver(gpu_lib, name, ranks, kind, tmp_path)
+
+
+def run_load_step_driver(gpu_lib, name, ranks, kind, tmp_path, extra=()):
     """SURVEY 8(f)-4 on the HIP engine: MDF -> `python -m pcg_mi355x.run` with TWO load steps (warm start from the
     previous Un, :358,:378) -> U_<k>.mpidat / TimeData in the layout export_vtk.py reads, vs the oracle's loop.
     3 ranks: one process per part with the engine's native communicator; on the 1-GPU box they share the device and talk
@@ -290,10 +286,11 @@ def test_load_step_driver_on_gpu(gpu_lib, name, ranks, kind, tmp_path, extra=())
         if gpu_lib.lib().pcg_device_count() < ranks:
             env.update(PCG_RUN_SHARE_GPU="1", PCG_RCCL_LIB=conftest.build_fakenccl())
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-                "--master-port", str(29700 + (kind == "ebe"))]
+                "--master-port", str(free_port())]
     cmd += ["-m", "pcg_mi355x.run", "--mdf", path, "--settings", str(tmp_path / "GlobSettings.zpkl"), "--results", results,
             "--operator", kind] + (["--group", "--n-parts", str(ranks)] if group else []) + list(extra)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    dump_failed_run(f"load_step_{name}_{ranks}_{kind}" + "_".join(extra).replace("-", ""), r)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     if extra:
         assert ">engine-side all-reduce: on" in r.stdout and ">engine-side exchange: on" in r.stdout, r.stdout[-2000:]

@@ -63,14 +63,14 @@ def test_brick_matrices_are_not_split(hostops, monkeypatch):
     assert a == b
 
 
-@pytest.mark.parametrize("case,nproc,port", [("goct_p4", 4, 29671), ("oct_p3", 3, 29672)])
-def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc, port):        # (the windowed form: the default)
+@pytest.mark.parametrize("case,nproc", [("goct_p4", 4), ("oct_p3", 3)])
+def test_split_matrix_multi_rank(tmp_path, monkeypatch, case, nproc):        # (the windowed form: the default)
     """Interface rows first, interior rows behind the exchange: the overflow part is split at the same row, every rank runs
     base + overflow for each range (forced split: the fixtures are small)."""
     import conftest
     conftest.build_hostops()
     monkeypatch.setenv("PCG_SELL_SPLIT", "1")
-    outs = run_dist(case, nproc, "gloo", "hostops", tmp_path, port)
+    outs = run_dist(case, nproc, "gloo", "hostops", tmp_path)
     g = golden(case)
     n = len(g["Fext"])
     U = np.zeros(n); Y = np.zeros(n)
