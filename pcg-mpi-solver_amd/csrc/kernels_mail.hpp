@@ -12,8 +12,8 @@ namespace pcg {
 // ranks, valid for every thread.  tmp: kMailMaxRanks * kMailSlotWords doubles of shared memory.
 // Thread t < n serves peer t in both directions: it posts this rank's values into rank t's mailbox (values first, then the sequence
 // number with release semantics at system scope: whoever sees the number sees the values) and waits for rank t's values in this
-// rank's own mailbox.  A poll that runs out of patience (seconds) reports through m.err and delivers NaN: the solve ends on it,
-// nothing hangs.
+// rank's own mailbox.  A poll that lasts longer than m.timeout_ticks of the 100 MHz wall clock (default 30 s, PCG_MAIL_TIMEOUT_S)
+// reports through m.err and delivers NaN: the solve ends on it, nothing hangs.
 __device__ __forceinline__ void mail_allreduce(const MailDesc &m, const double *in, int count, double *out, double *tmp)
 {
     const int tid = threadIdx.x;
@@ -24,11 +24,11 @@ __device__ __forceinline__ void mail_allreduce(const MailDesc &m, const double *
             __hip_atomic_store(post + 1 + k, (unsigned long long)__double_as_longlong(in[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(post, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long *box = reinterpret_cast<const unsigned long long *>(m.peer[m.rank]) + ((size_t)par * kMailMaxRanks + tid) * kMailSlotWords;
-        unsigned spins = 0;
+        const unsigned long long t0 = (unsigned long long)wall_clock64();
         bool ok = true;
         while (__hip_atomic_load(box, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != m.seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > m.spin_limit) { ok = false; break; }
+            if (m.timeout_ticks && (unsigned long long)wall_clock64() - t0 > m.timeout_ticks) { ok = false; break; }   // wall clock, not a poll count
         }
         for (int k = 0; k < count; ++k) {
             const unsigned long long w = __hip_atomic_load(box + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -139,10 +139,13 @@ __device__ __forceinline__ void wait_for_neighbours(const FixWait &w)
 {
     if (w.n <= 0) return;
     if ((int)threadIdx.x < w.n) {
-        unsigned spins = 0;
+        const unsigned long long t0 = (unsigned long long)wall_clock64();
         while (__hip_atomic_load(w.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > w.spin_limit) { __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if (w.timeout_ticks && (unsigned long long)wall_clock64() - t0 > w.timeout_ticks) {
+                __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
     __syncthreads();

@@ -1167,6 +1167,11 @@ int pcg_solve_begin(pcg_engine *e, const double *b, const double *x0, const doub
         s = pcg_engine::Solve();
         s.active = true;
         e->pending_publish = -1;
+        // engine-side communication forms (opt-in, frozen): one all-reduce of the collective library in front of the solve's first
+        // engine-side wait, carrying "a poll of mine timed out" - the ranks start their polling kernels together, and after a time-out
+        // anywhere they all return to the collective library here instead of staying on sequence numbers that no longer agree
+        if (e->comm && (e->comm->mailbox_enabled() || e->direct))
+            if (e->comm->engine_side_sync(be.stream(), true, e->direct && e->direct->faulted())) e->direct.reset();
         be.set_status_slot(0);
         be.zero(e->d_st, sizeof(double) * ST_COUNT);                        // STOP is sticky within a solve
         s.t_comm0 = e->t_comm;

@@ -268,7 +268,7 @@ struct MailDesc {                                  // passed BY VALUE to the ker
     unsigned *err;                                 // host-visible word: != 0 after a poll gave up (the result is NaN then)
     unsigned long long seq;                        // number of THIS all-reduce (1, 2, ...: every rank issues the same sequence)
     int rank, n;
-    unsigned spin_limit;
+    unsigned long long timeout_ticks;              // wall_clock64() ticks (100 MHz) a poll may last; 0 = no limit (the CPU double)
 };
 
 // ---- engine-side neighbour exchange through peer-mapped receive buffers (round 5, opt-in: pcg_enable_direct_exchange) ---------
@@ -289,19 +289,19 @@ struct DirectDesc {                                // passed BY VALUE to k_halo_
     unsigned *err;                                 // host-visible word: != 0 after a poll gave up
     unsigned long long seq;                        // number of THIS exchange (1, 2, ...)
     int n_peers;
-    unsigned spin_limit;
+    unsigned long long timeout_ticks;              // as MailDesc
 };
 struct FixWait {                                   // passed BY VALUE to k_fixup: n == 0 = the receive buffer is complete at launch (RCCL path)
     const unsigned long long *flags;
     unsigned *err;
     unsigned long long seq;
     int n;
-    unsigned spin_limit;
+    unsigned long long timeout_ticks;
 };
 inline FixWait fix_wait_of(const DirectDesc *d)
 {
     FixWait w{};
-    if (d) { w.flags = d->my_flags; w.err = d->err; w.seq = d->seq; w.n = d->n_peers; w.spin_limit = d->spin_limit; }
+    if (d) { w.flags = d->my_flags; w.err = d->err; w.seq = d->seq; w.n = d->n_peers; w.timeout_ticks = d->timeout_ticks; }
     return w;
 }
 struct HaloHost;
@@ -311,6 +311,7 @@ public:
     virtual double *recv() = 0;                    // the receive buffer the fix-up reads from now on (uncached, mapped by the neighbours)
     virtual DirectDesc next() = 0;                 // the descriptor of the NEXT exchange (advances the sequence)
     virtual void check() = 0;                      // throws when a poll has timed out since the last call
+    virtual bool faulted() const { return false; } // a poll of this link has ever timed out (Comm::engine_side_sync then retires the forms)
 };
 
 struct HaloHost {
@@ -477,6 +478,13 @@ public:
     virtual MailDesc mailbox_next() { return MailDesc{}; }   // the descriptor of the NEXT all-reduce (advances the sequence)
     virtual void mailbox_check() {}                          // throws when a poll has timed out since the last call
     virtual std::string mailbox_why() const { return "this communicator has no mailbox all-reduce"; }   // why enable_mailbox() said no
+    // COLLECTIVE, at the start of every solve while an engine-side form is on (round 6): one all-reduce of the collective
+    // library on `compute_stream` in front of the solve's first engine-side wait - the ranks' polling kernels then start within
+    // microseconds of each other however uneven the set-up was - carrying "a poll of mine has timed out since the last call" (mailbox
+    // or `link_fault`).  -> true on EVERY rank when any rank reported one: the mailbox is switched off here and the caller drops its
+    // direct link, i.e. the ranks return to ncclAllReduce / ncclSend / ncclRecv TOGETHER instead of staying on sequence numbers that
+    // no longer agree.  `engine_side_on` must be the same on every rank (enable_mailbox / direct_link are collective).
+    virtual bool engine_side_sync(void *compute_stream, bool engine_side_on, bool link_fault) { (void)compute_stream; (void)engine_side_on; (void)link_fault; return false; }
     // Direct exchange (DirectDesc above).  COLLECTIVE over every rank of the communicator, neighbours or not: the ranks publish
     // their buffers' handles and segment layouts, map their neighbours' and agree on the outcome.  -> null (on every rank, `why`
     // says why) when any rank could not map a neighbour; the exchange then stays on ncclSend / ncclRecv.

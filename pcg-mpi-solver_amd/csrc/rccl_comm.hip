@@ -168,10 +168,12 @@ public:
         if (stats) stats->n_halo++;                   // one exchange per operator apply, whichever way it travels
         return d;
     }
+    bool fault = false;
     void check() override
     {
-        if (err && *err) { *err = 0; throw std::runtime_error("direct exchange: a neighbour's values never arrived (poll timed out)"); }
+        if (err && *err) { *err = 0; fault = true; throw std::runtime_error("direct exchange: a neighbour's values never arrived (poll timed out)"); }
     }
+    bool faulted() const override { return fault || (err && *err); }
 };
 
 class RcclComm : public Comm {
@@ -195,7 +197,12 @@ class RcclComm : public Comm {
     unsigned *mail_err_ = nullptr;                   // pinned, mapped: a poll timed out
     unsigned long long mail_seq_ = 0;
     bool mail_on_ = false;
-    unsigned mail_spins_ = 1u << 21;                 // polls of ~0.1 - 1 us each: seconds
+    // a poll may last this long by the 100 MHz wall clock (wall_clock64) before it gives up: 30 s unless PCG_MAIL_TIMEOUT_S says otherwise.
+    // (Round 5 counted polls - 2^21 of them, 0.2 - 2 s depending on the box - and a rank that arrived later than that, after an uneven
+    // set-up or under a profiler, turned into a hard solve error where ncclAllReduce would simply have waited: ADVICE r5.)
+    unsigned long long mail_timeout_ticks_ = 3000000000ull;
+    bool mail_fault_ = false;                        // a mailbox poll has timed out since the last engine_side_sync
+    double *d_sync_ = nullptr;                       // one double for engine_side_sync
     std::string mail_why_;                           // why enable_mailbox() said no (this rank's view)
 
     void release_mailbox()
@@ -206,6 +213,7 @@ class RcclComm : public Comm {
         }
         if (box_) { (void)hipFree(box_); box_ = nullptr; }
         if (mail_err_) { (void)hipHostFree(mail_err_); mail_err_ = nullptr; }
+        if (d_sync_) { (void)hipFree(d_sync_); d_sync_ = nullptr; }
         mail_on_ = false;
     }
     // sum over the ranks of `count` doubles at dev (in place) through the reduction communicator, host-synchronous
@@ -302,7 +310,7 @@ public:
         if (!on) { mail_on_ = false; return false; }
         if (mail_on_) return true;
         if (size_ > kMailMaxRanks) { mail_why_ = "more than 16 ranks"; return false; }
-        if (const char *e = std::getenv("PCG_MAIL_SPINS")) mail_spins_ = (unsigned)std::max(1, atoi(e));
+        read_timeout();
         constexpr int R = 72;                       // record per rank: ok, pid, host id, device, pointer in 4 x 16 bits, 64 handle bytes
         double fail = 0;
         auto soft = [&](hipError_t e, const char *what) {
@@ -406,17 +414,40 @@ public:
         return good;
     }
     bool mailbox_enabled() const override { return mail_on_; }
+    void read_timeout()
+    {
+        if (const char *e = std::getenv("PCG_MAIL_TIMEOUT_S")) mail_timeout_ticks_ = (unsigned long long)(std::max(1e-3, atof(e)) * 1e8);
+    }
+    bool engine_side_sync(void *compute_stream, bool engine_side_on, bool link_fault) override
+    {
+        if (!engine_side_on) return false;
+        RcclApi &A = api();
+        hipStream_t cs = (hipStream_t)compute_stream;
+        HIP_CHECK(hipSetDevice(dev_));
+        if (!d_sync_) HIP_CHECK(hipMalloc((void **)&d_sync_, sizeof(double)));
+        double v = (mail_fault_ || link_fault || (mail_err_ && *mail_err_)) ? 1.0 : 0.0;
+        HIP_CHECK(hipMemcpyAsync(d_sync_, &v, sizeof(double), hipMemcpyHostToDevice, cs));
+        NCCL_CHECK(A.AllReduce(d_sync_, d_sync_, 1, ncclDouble, ncclSum, red_comm_, cs));     // always the collective library, never the mailbox
+        HIP_CHECK(hipMemcpyAsync(&v, d_sync_, sizeof(double), hipMemcpyDeviceToHost, cs));
+        HIP_CHECK(hipStreamSynchronize(cs));
+        mail_fault_ = false;
+        if (v == 0.0) return false;
+        mail_on_ = false;                           // every rank takes this branch together
+        mail_why_ = "switched off after a poll timed out on some rank";
+        if (mail_err_) *mail_err_ = 0;
+        return true;
+    }
     MailDesc mailbox_next() override
     {
         MailDesc m{};
         for (int r = 0; r < size_; ++r) m.peer[r] = peer_box_[r];
-        m.err = mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.spin_limit = mail_spins_;
+        m.err = mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.timeout_ticks = mail_timeout_ticks_;
         st_.n_allreduce++;                          // (every all-reduce draws exactly one descriptor, fused into a launch or not)
         return m;
     }
     void mailbox_check() override
     {
-        if (mail_err_ && *mail_err_) { *mail_err_ = 0; throw std::runtime_error("mailbox all-reduce: a peer's values never arrived (poll timed out)"); }
+        if (mail_err_ && *mail_err_) { *mail_err_ = 0; mail_fault_ = true; throw std::runtime_error("mailbox all-reduce: a peer's values never arrived (poll timed out)"); }
     }
     std::string mailbox_why() const override { return mail_why_; }
 
@@ -470,8 +501,8 @@ public:
         // ---- map every NEIGHBOUR's buffer; find this rank's segment and arrival word in it
         DirectDesc &d = link->d;
         d = DirectDesc{};
-        d.n_peers = h.n_peers; d.err = link->err; d.spin_limit = mail_spins_;
-        if (const char *e = std::getenv("PCG_MAIL_SPINS")) d.spin_limit = (unsigned)std::max(1, atoi(e));
+        read_timeout();
+        d.n_peers = h.n_peers; d.err = link->err; d.timeout_ticks = mail_timeout_ticks_;
         d.my_flags = link->buf ? (const unsigned long long *)((char *)link->buf + link->flags_off) : nullptr;
         for (int j = 0; j <= h.n_peers && j <= kDirectMaxPeers; ++j) d.seg[j] = h.send_ptr.empty() ? 0 : h.send_ptr[(size_t)j];
         for (int j = 0; j < h.n_peers && fail == 0; ++j) {

@@ -156,7 +156,7 @@ public:
     {
         MailDesc m{};
         for (int r = 0; r < size_; ++r) m.peer[r] = w_->mail[r];
-        m.err = &mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.spin_limit = 0;
+        m.err = &mail_err_; m.seq = ++mail_seq_; m.rank = rank_; m.n = size_; m.timeout_ticks = 0;
         st_.n_allreduce++;
         return m;
     }
@@ -192,7 +192,7 @@ public:
             throw std::runtime_error("local comm: a peer never entered direct_link");
         DirectDesc &d = link->d;
         d = DirectDesc{};
-        d.n_peers = h.n_peers; d.err = &link->err; d.spin_limit = 0;
+        d.n_peers = h.n_peers; d.err = &link->err; d.timeout_ticks = 0;
         d.my_flags = link->store.data() + total;
         for (int j = 0; j <= h.n_peers && j <= kDirectMaxPeers; ++j) d.seg[j] = h.send_ptr.empty() ? 0 : h.send_ptr[(size_t)j];
         for (int j = 0; j < h.n_peers && !bad; ++j) {

@@ -4,6 +4,7 @@ are frozen (no evidence can be had for them on a 1-GPU pool
 never again hide the tests of the default path (a2 split-SELL, f3 partition set-up, f4 load-step driver) behind `-x`.
 
 What they replace in the reference: MPI_SUM (pcg_solver.py:622-628) and the Isend / Recv / Waitall interface sum (:318-334)."""
+import json
 import os
 import subprocess
 import sys
@@ -192,3 +193,18 @@ def test_load_step_driver_with_the_engine_side_forms_on_gpu(gpu_lib, tmp_path):
     exchange switched on by the driver (processes sharing the GPU map each other through hipIpcMemHandle), matrix-free."""
     from test_partition import run_load_step_driver
     run_load_step_driver(gpu_lib, "part_octree_p3", 3, "ebe", tmp_path, extra=("--engine-side",))
+
+
+@gpu
+def test_bench_engine_side_ab_is_opt_in(gpu_lib, tmp_path):
+    """`bench.py --gpus 2 --ab-engine-side`: the mailbox all-reduce and the direct exchange measured BESIDE the headline (which stays on
+    RCCL) - only on request; same iteration counts as the RCCL windows."""
+    from test_native_comm import run_bench_two_ranks
+    out, full, _ = run_bench_two_ranks(tmp_path, extra=("--ab-engine-side", "--no-octree"))
+    ab = full["comm"]["engine_side_ab"]
+    assert ab["enabled"] and ab["assembled"]["value"] > 0 and ab["matrix_free"]["value"] > 0
+    assert (ab["assembled"]["solve"]["flag"], ab["assembled"]["solve"]["iter"]) == (full["solve"]["flag"], full["solve"]["iter"])
+    dx = ab["direct_exchange"]
+    for key in ("assembled", "matrix_free"):
+        assert dx[key]["enabled"] and dx[key]["value"] > 0 and dx[key]["solve"]["flag"] == 0, dx[key]
+    assert out["value"] > 0 and "engine_side_ab" not in json.dumps(out)
