@@ -1052,9 +1052,10 @@ int pcg_enable_direct_exchange(pcg_engine *e, int32_t on, int32_t *enabled_out)
         if (!e->comm) return set_error("pcg_enable_direct_exchange: the engine has no native communicator (pcg_set_comm_native)");
         if (e->s.active) return set_error("pcg_enable_direct_exchange: a solve is in progress");
         std::string why;
-        if (!e->be->direct_kernels_available()) why = "this back end has no direct-exchange kernels";
-        // collective: EVERY rank enters, with its own halo (possibly empty)
-        auto link = e->comm->direct_link(e->has_halo ? e->halo : HaloHost(), why);
+        const bool cannot = !e->be->direct_kernels_available();
+        if (cannot) why = "this back end has no direct-exchange kernels";
+        // collective: EVERY rank enters, with its own halo (possibly empty) and with what it already knows it cannot do
+        auto link = e->comm->direct_link(e->has_halo ? e->halo : HaloHost(), why, cannot);
         if (!link || !e->be->direct_kernels_available()) {
             (void)set_error("pcg_enable_direct_exchange: staying with ncclSend / ncclRecv - " + why);
             return 0;

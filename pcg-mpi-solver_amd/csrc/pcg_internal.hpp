@@ -488,7 +488,9 @@ public:
     // Direct exchange (DirectDesc above).  COLLECTIVE over every rank of the communicator, neighbours or not: the ranks publish
     // their buffers' handles and segment layouts, map their neighbours' and agree on the outcome.  -> null (on every rank, `why`
     // says why) when any rank could not map a neighbour; the exchange then stays on ncclSend / ncclRecv.
-    virtual std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) { (void)h; why = "this communicator has no direct exchange"; return nullptr; }
+    // `cannot`: this rank cannot use a link whatever the mapping says (its back end has no direct kernels; `why` says so): it still
+    // takes part in the agreement, which then fails on every rank.
+    virtual std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why, bool cannot = false) { (void)h; (void)cannot; why = "this communicator has no direct exchange"; return nullptr; }
 };
 // defined by the HIP side of the product library; the CPU test double has no native communicator
 std::unique_ptr<Comm> make_rccl_comm(int device, int rank, int nranks, const void *unique_ids /* 2 x 128 B */);

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -46,6 +47,44 @@
 
 namespace pcg {
 namespace {
+
+// Who is who among the ranks of a communicator ((gethostid(), getpid()) alone is not an identity - containers share the
+// 127.0.1.1-derived host id, torchrun workers of different nodes often share small pids).  A rank is "this process" only when it
+// carries this process's random nonce, and "this host" only when host id AND a hash of the kernel's boot id + host name agree;
+// everything else goes through hipIpcOpenMemHandle, whose failure falls back collectively.
+unsigned long long process_nonce()
+{
+    static const unsigned long long n = []() {
+        unsigned long long v = 0;
+        if (FILE *f = std::fopen("/dev/urandom", "rb")) { if (std::fread(&v, sizeof(v), 1, f) != 1) v = 0; std::fclose(f); }
+        if (v == 0) v = (unsigned long long)getpid() * 0x9e3779b97f4a7c15ull ^ (unsigned long long)(uintptr_t)&v;
+        return v & 0xffffffffffffull;                 // 48 bits: three exactly representable 16-bit fields of the record
+    }();
+    return n;
+}
+unsigned host_hash()
+{
+    static const unsigned h = []() {
+        char buf[320] = {0};
+        size_t n = 0;
+        if (FILE *f = std::fopen("/proc/sys/kernel/random/boot_id", "rb")) { n = std::fread(buf, 1, 64, f); std::fclose(f); }
+        (void)gethostname(buf + n, sizeof(buf) - n - 1);
+        unsigned v = 2166136261u;                     // FNV-1a
+        for (const char *p = buf; *p; ++p) v = (v ^ (unsigned char)*p) * 16777619u;
+        return v;
+    }();
+    return h;
+}
+constexpr int kIdWords = 5;                           // nonce 3 x 16 bits, host hash 2 x 16 bits
+inline void put_identity(double *q)
+{
+    const unsigned long long n = process_nonce();
+    const unsigned h = host_hash();
+    for (int k = 0; k < 3; ++k) q[k] = (double)((n >> (16 * k)) & 0xffffull);
+    q[3] = (double)(h & 0xffffu); q[4] = (double)(h >> 16);
+}
+inline bool same_process(const double *a, const double *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+inline bool same_host(const double *a, const double *b) { return a[3] == b[3] && a[4] == b[4]; }
 
 struct RcclApi {
     void *handle = nullptr;
@@ -311,16 +350,17 @@ public:
         if (mail_on_) return true;
         if (size_ > kMailMaxRanks) { mail_why_ = "more than 16 ranks"; return false; }
         read_timeout();
-        constexpr int R = 72;                       // record per rank: ok, pid, host id, device, pointer in 4 x 16 bits, 64 handle bytes
+        constexpr int R = 72 + kIdWords;            // record per rank: ok, pid, host id, device, pointer in 4 x 16 bits, 64 handle bytes, identity
         double fail = 0;
         auto soft = [&](hipError_t e, const char *what) {
             if (e != hipSuccess && fail == 0) { fail = 1; mail_why_ = std::string(what) + " -> " + hipGetErrorString(e); (void)hipGetLastError(); }
             return e == hipSuccess;
         };
         release_mailbox();
-        if (!soft(hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached)")) {
-            fail = 0; mail_why_.clear();
-            soft(hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(fine-grained)");
+        if (hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocUncached) != hipSuccess) {      // (not a failure yet: try the other kind)
+            (void)hipGetLastError();
+            box_ = nullptr;
+            soft(hipExtMallocWithFlags((void **)&box_, kBoxBytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(uncached, then fine-grained)");
         }
         if (box_) soft(hipMemset(box_, 0, kBoxBytes), "hipMemset(mailbox)");
         soft(hipHostMalloc((void **)&mail_err_, sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(mailbox error word)");
@@ -336,19 +376,25 @@ public:
         mine[0] = 1; mine[1] = (double)getpid(); mine[2] = (double)(unsigned)gethostid(); mine[3] = dev_;
         for (int k = 0; k < 4; ++k) mine[4 + k] = (double)((ptr >> (16 * k)) & 0xffffull);
         for (int k = 0; k < 64; ++k) mine[8 + k] = (double)((const unsigned char *)&h)[k];
-        double *d_rec = nullptr;
-        HIP_CHECK(hipMalloc((void **)&d_rec, sizeof(double) * (rec.size() + 8)));
-        HIP_CHECK(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+        put_identity(mine + 72);
+        // From here to the end the ranks are inside a sequence of collectives: a local HIP failure only raises `fail` (soft) - a throw
+        // would leave the peers blocked in boot_allreduce - and the staging buffer is freed on every path.
+        struct DevBuf { double *p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } dbuf;
+        soft(hipMalloc((void **)&dbuf.p, sizeof(double) * (rec.size() + 8)), "hipMalloc(exchange record)");
+        if (!dbuf.p) throw std::runtime_error("mailbox: " + mail_why_);        // (no device memory for 10 KB: nothing collective can work)
+        double *d_rec = dbuf.p;
+        if (!soft(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice), "hipMemcpy(record up)")) (void)hipMemset(d_rec, 0, sizeof(double) * rec.size());
         boot_allreduce(d_rec, rec.size());
-        HIP_CHECK(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        if (!soft(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost), "hipMemcpy(records down)")) std::fill(rec.begin(), rec.end(), 0.0);
+        mine = rec.data() + (size_t)rank_ * R;
         // ---- map every peer's mailbox
         for (int r = 0; r < size_ && fail == 0; ++r) {
             const double *q = rec.data() + (size_t)r * R;
             if (r == rank_) { peer_box_[r] = box_; continue; }
             if (q[0] != 1.0) { fail = 1; mail_why_ = "rank " + std::to_string(r) + " sent no record"; break; }
-            if (q[2] != mine[2]) { fail = 1; mail_why_ = "rank " + std::to_string(r) + " runs on another host"; break; }
+            if (q[2] != mine[2] || !same_host(q + 72, mine + 72)) { fail = 1; mail_why_ = "rank " + std::to_string(r) + " runs on another host"; break; }
             const int pdev = (int)q[3];
-            if (q[1] == mine[1]) {                                      // same process (device group, threads): the pointer itself
+            if (q[1] == mine[1] && same_process(q + 72, mine + 72)) {   // same process (device group, threads): the pointer itself
                 unsigned long long p = 0;
                 for (int k = 0; k < 4; ++k) p |= (unsigned long long)q[4 + k] << (16 * k);
                 if (pdev == dev_) {
@@ -379,34 +425,34 @@ public:
         }
         // ---- agree, then prove it: one all-reduce of known values through the mailboxes
         double *d_flag = d_rec + rec.size();
-        HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
-        boot_allreduce(d_flag, 1);
-        double any = 0;
-        HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
-        bool good = any == 0;
+        // agree(): the ranks' `fail` flags summed; a rank whose own copy up / down fails reports failure (and sees it)
+        auto agree = [&]() {
+            double any = 1;
+            const bool up = hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+            if (!up) { (void)hipGetLastError(); (void)hipMemset(d_flag, 0x3f, sizeof(double)); }   // (bytes 3f..3f: a positive double - the peers see a failure)
+            boot_allreduce(d_flag, 1);
+            if (hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); any = 1; }
+            return up && any == 0;
+        };
+        bool good = agree();
         if (good) {
             double v[kMailMaxCount];
             for (int k = 0; k < kMailMaxCount; ++k) v[k] = (double)((rank_ + 1) * (k + 1));
-            HIP_CHECK(hipMemcpy(d_rec, v, sizeof(v), hipMemcpyHostToDevice));
+            soft(hipMemcpy(d_rec, v, sizeof(v), hipMemcpyHostToDevice), "hipMemcpy(self-test values)");
             mail_on_ = true;
             const MailDesc m = mailbox_next();
             hipLaunchKernelGGL(k_mail_allreduce, dim3(1), dim3(64), 0, comm_stream_, d_rec, kMailMaxCount, m);
-            fail = hipGetLastError() != hipSuccess || hipStreamSynchronize(comm_stream_) != hipSuccess;
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(comm_stream_) != hipSuccess) { if (fail == 0) mail_why_ = "the mailbox self-test kernel failed"; fail = 1; }
             if (fail == 0) {
-                HIP_CHECK(hipMemcpy(v, d_rec, sizeof(v), hipMemcpyDeviceToHost));
+                if (!soft(hipMemcpy(v, d_rec, sizeof(v), hipMemcpyDeviceToHost), "hipMemcpy(self-test sums)")) v[0] = -1;
+                bool wrong = false;
                 for (int k = 0; k < kMailMaxCount; ++k)
-                    if (v[k] != (double)((k + 1) * size_ * (size_ + 1) / 2)) fail = 1;
-                if (*mail_err_) { fail = 1; *mail_err_ = 0; }
-                if (fail != 0) mail_why_ = "the mailbox self-test returned wrong sums (peer stores not visible?)";
-            } else {
-                mail_why_ = "the mailbox self-test kernel failed";
+                    if (v[k] != (double)((k + 1) * size_ * (size_ + 1) / 2)) wrong = true;
+                if (*mail_err_) { wrong = true; *mail_err_ = 0; }
+                if (wrong && fail == 0) { fail = 1; mail_why_ = "the mailbox self-test returned wrong sums (peer stores not visible?)"; }
             }
-            HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
-            boot_allreduce(d_flag, 1);
-            HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
-            good = any == 0;
+            good = agree();
         }
-        (void)hipFree(d_rec);
         if (!good) {
             if (mail_why_.empty()) mail_why_ = "another rank could not map a mailbox";
             release_mailbox();
@@ -453,12 +499,13 @@ public:
 
     // COLLECTIVE over every rank (neighbours or not), same discipline as enable_mailbox(): local failures only raise `fail`, the ranks
     // compare notes through the reduction communicator and take the same decision.
-    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) override
+    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why, bool cannot) override
     {
         HIP_CHECK(hipSetDevice(dev_));
-        why.clear();
-        constexpr int R = 73 + 3 * kDirectMaxPeers;      // ok, pid, host, device, pointer 4 x 16 bits, 64 handle bytes, n_peers, (peer, offset, count) x 32
-        double fail = 0;
+        constexpr int ID = 73 + 3 * kDirectMaxPeers;     // where the identity words start
+        constexpr int R = ID + kIdWords;                 // ok, pid, host, device, pointer 4 x 16 bits, 64 handle bytes, n_peers, (peer, offset, count) x 32, identity
+        double fail = cannot ? 1 : 0;                    // (a rank that already knows it cannot: it still takes part in the agreement)
+        if (!cannot) why.clear();
         auto soft = [&](hipError_t e, const char *what) {
             if (e != hipSuccess && fail == 0) { fail = 1; why = std::string(what) + " -> " + hipGetErrorString(e); (void)hipGetLastError(); }
             return e == hipSuccess;
@@ -466,14 +513,17 @@ public:
         auto link = std::make_unique<RcclDirectLink>();
         link->dev = dev_;
         link->stats = &st_;
-        if (size_ > kMailMaxRanks) { fail = 1; why = "more than 16 ranks"; }
-        if (h.n_peers > kDirectMaxPeers) { fail = 1; why = "more than 32 neighbours"; }
+        if (fail == 0 && size_ > kMailMaxRanks) { fail = 1; why = "more than 16 ranks"; }
+        if (fail == 0 && h.n_peers > kDirectMaxPeers) { fail = 1; why = "more than 32 neighbours"; }
         const int64_t total = h.n_peers > 0 ? h.send_ptr[(size_t)h.n_peers] : 0;
         link->flags_off = ((size_t)total * sizeof(double) + 127) / 128 * 128;
         const size_t bytes = link->flags_off + sizeof(unsigned long long) * kDirectMaxPeers;
-        if (!soft(hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached)")) {
-            fail = 0; why.clear();
-            soft(hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(fine-grained)");
+        // (the limit refusals above stay whatever the allocation does - ADVICE r5: resetting `fail` here let a part with more than 32
+        //  neighbours run into the mapping loop and write past kDirectMaxPeers)
+        if (hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            link->buf = nullptr;
+            soft(hipExtMallocWithFlags((void **)&link->buf, bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(uncached, then fine-grained)");
         }
         if (link->buf) soft(hipMemset(link->buf, 0, bytes), "hipMemset(direct buffer)");
         soft(hipHostMalloc((void **)&link->err, sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(direct error word)");
@@ -493,11 +543,15 @@ public:
             mine[74 + 3 * j] = (double)h.send_ptr[(size_t)j];
             mine[75 + 3 * j] = (double)(h.send_ptr[(size_t)j + 1] - h.send_ptr[(size_t)j]);
         }
-        double *d_rec = nullptr;
-        HIP_CHECK(hipMalloc((void **)&d_rec, sizeof(double) * (rec.size() + 8)));
-        HIP_CHECK(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+        put_identity(mine + ID);
+        struct DevBuf { double *p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } dbuf;       // (as in enable_mailbox: no throw between the collectives)
+        soft(hipMalloc((void **)&dbuf.p, sizeof(double) * (rec.size() + 8)), "hipMalloc(exchange record)");
+        if (!dbuf.p) throw std::runtime_error("direct exchange: " + why);
+        double *d_rec = dbuf.p;
+        if (!soft(hipMemcpy(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice), "hipMemcpy(record up)")) (void)hipMemset(d_rec, 0, sizeof(double) * rec.size());
         boot_allreduce(d_rec, rec.size());
-        HIP_CHECK(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        if (!soft(hipMemcpy(rec.data(), d_rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost), "hipMemcpy(records down)")) std::fill(rec.begin(), rec.end(), 0.0);
+        mine = rec.data() + (size_t)rank_ * R;
         // ---- map every NEIGHBOUR's buffer; find this rank's segment and arrival word in it
         DirectDesc &d = link->d;
         d = DirectDesc{};
@@ -510,7 +564,7 @@ public:
             if (p < 0 || p >= size_ || (p == rank_ && !allow_self_)) { fail = 1; why = "neighbour part id is not a peer rank"; break; }
             const double *q = rec.data() + (size_t)p * R;
             if (q[0] != 1.0) { fail = 1; why = "rank " + std::to_string(p) + " sent no record"; break; }
-            if (q[2] != mine[2]) { fail = 1; why = "rank " + std::to_string(p) + " runs on another host"; break; }
+            if (q[2] != mine[2] || !same_host(q + ID, mine + ID)) { fail = 1; why = "rank " + std::to_string(p) + " runs on another host"; break; }
             int k_me = -1;                                               // this rank's place in p's neighbour list
             for (int k = 0; k < (int)q[72]; ++k)
                 if ((int)q[73 + 3 * k] == rank_) { k_me = k; break; }
@@ -521,7 +575,7 @@ public:
             const size_t p_flags_off = (p_total * sizeof(double) + 127) / 128 * 128;
             void *base = nullptr;
             if (p == rank_) base = link->buf;                            // (tests: a part that is its own neighbour)
-            else if (q[1] == mine[1]) {                                  // same process: the pointer itself
+            else if (q[1] == mine[1] && same_process(q + ID, mine + ID)) {   // same process: the pointer itself
                 if ((int)q[3] == dev_) { fail = 1; why = "ranks " + std::to_string(rank_) + " and " + std::to_string(p) + " of one process share a device: their kernels are not guaranteed to run concurrently"; break; }
                 int can = 0;
                 soft(hipDeviceCanAccessPeer(&can, dev_, (int)q[3]), "hipDeviceCanAccessPeer");
@@ -545,11 +599,12 @@ public:
             d.peer_flag[j] = (unsigned long long *)((char *)base + p_flags_off) + k_me;
         }
         double *d_flag = d_rec + rec.size();
-        HIP_CHECK(hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice));
+        double any = 1;
+        const bool up = hipMemcpy(d_flag, &fail, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        if (!up) { (void)hipGetLastError(); (void)hipMemset(d_flag, 0x3f, sizeof(double)); }   // (bytes 3f..3f: a positive double - the peers see a failure)
         boot_allreduce(d_flag, 1);
-        double any = 0;
-        HIP_CHECK(hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost));
-        (void)hipFree(d_rec);
+        if (hipMemcpy(&any, d_flag, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); any = 1; }
+        if (!up) any = 1;
         if (any != 0) {
             if (why.empty()) why = "another rank could not map a neighbour's buffer";
             return nullptr;

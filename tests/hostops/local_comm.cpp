@@ -166,7 +166,7 @@ public:
     }
     // COLLECTIVE like the product's (every rank's k-th call belongs to generation k): the ranks publish buffer + layout, then every
     // rank looks up its segment and arrival word at each neighbour
-    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why) override
+    std::unique_ptr<DirectLink> direct_link(const HaloHost &h, std::string &why, bool = false) override
     {
         why.clear();
         auto link = std::make_unique<LocalDirectLink>();
