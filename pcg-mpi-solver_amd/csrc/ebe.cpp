@@ -683,6 +683,17 @@ void build_ebe(int64_t n_nodes, int32_t n_groups, const pcg_elem_group *gs, cons
         }
         C.node_cap_used = node_cap;
         cut_runs(node_cap, [&](size_t a, size_t b) { emit_or_split(a, b); });
+        if (std::getenv("PCG_EBE_PLAN_STATS")) {             // development: one line per chunk - nodes, hex tiles, other tiles, their k-steps
+            const size_t nc = C.hdr.size() / 8;
+            for (size_t c = 0; c < nc; ++c) {
+                const int32_t *h = &C.hdr[8 * c];
+                if (h[6] != kMixedClass) continue;
+                const int nht = M.hex_tile_type >= 0 ? M.chunk_hex_tiles[(size_t)h[4]] : 0;
+                int other = 0, ksteps = 0;
+                for (int t = nht; t < h[5]; ++t) { ++other; ksteps += 3 * M.types[(size_t)M.tile_type[(size_t)h[7] + t]].J; }
+                std::fprintf(stderr, "[plan] chunk %zu nodes %d hex_elems %d hex_tiles %d other_tiles %d other_ksteps %d\n", c, h[1], h[3], nht, other, ksteps);
+            }
+        }
     }
 
     // Chunks = octree-like cells: the spatially sorted element list of a group is split recursively at

@@ -651,11 +651,14 @@ public:
     void launch_mixed(int ph, int count, const double *ke, const double *x, double *y, bool dot, double *part, long long dot_lo)
     {
         if (mix_hex_tiles_) {                                     // every element on the matrix cores (k_ebe_mtile)
-            auto gom = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], x, y, d_ch_buf_, part, dot_lo); };
+            auto gom = [&](auto kern, int nw) { hipLaunchKernelGGL(kern, dim3(count), dim3(64 * nw), 0, ls_, mix_tab_[ph], x, y, d_ch_buf_, part, dot_lo); };
             if constexpr (MTM == 4) {
                 if (dot && stamp_launch_ >= 0 && count >= 64 && ++stamp_launch_ == 40) { launch_mtile_stamped(ph, count, x, y, part, dot_lo); return; }
+                // waves per workgroup (round 6, PCG_EBE_MTILE_WAVES): 5 / 6 shorten a chunk's chain where the chunks do not fill the GPU
+                if (mtile_waves_ == 5) { if (dot) gom(k_ebe_mtile<MTM, true, false, 5>, 5); else gom(k_ebe_mtile<MTM, false, false, 5>, 5); return; }
+                if (mtile_waves_ == 6) { if (dot) gom(k_ebe_mtile<MTM, true, false, 6>, 6); else gom(k_ebe_mtile<MTM, false, false, 6>, 6); return; }
             }
-            if (dot) gom(k_ebe_mtile<MTM, true>); else gom(k_ebe_mtile<MTM, false>);
+            if (dot) gom(k_ebe_mtile<MTM, true>, kWavesPerBlock); else gom(k_ebe_mtile<MTM, false>, kWavesPerBlock);
             return;
         }
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(count), dim3(kChunkThreads), 0, ls_, mix_tab_[ph], ke, x, y, d_ch_buf_, part, dot_lo); };
@@ -668,15 +671,19 @@ public:
     // shader clock at its phase boundaries - and the means over the waves go to stderr (cycles).  Same results, one slower launch.
     int stamp_launch_ = getenv("PCG_EBE_STAMPS") && atoi(getenv("PCG_EBE_STAMPS")) ? 0 : -1;
     bool mix_hex_tiles_ = false;
+    int mtile_waves_ = getenv("PCG_EBE_MTILE_WAVES") ? atoi(getenv("PCG_EBE_MTILE_WAVES")) : kWavesPerBlock;
     void launch_mtile_stamped(int ph, int count, const double *x, double *y, double *part, long long dot_lo)
     {
-        const size_t nw = (size_t)count * kWavesPerBlock;
+        const int NWs = mtile_waves_ == 5 || mtile_waves_ == 6 ? mtile_waves_ : kWavesPerBlock;
+        const size_t nw = (size_t)count * NWs;
         unsigned long long *d = nullptr;
         HIP_CHECK(hipMalloc((void **)&d, nw * 16 * sizeof(unsigned long long)));
         HIP_CHECK(hipMemsetAsync(d, 0, nw * 16 * sizeof(unsigned long long), ls_));
         MixTab T = mix_tab_[ph];
         T.stamps = d;
-        hipLaunchKernelGGL((k_ebe_mtile<4, true, true>), dim3(count), dim3(kChunkThreads), 0, ls_, T, x, y, d_ch_buf_, part, dot_lo);
+        if (NWs == 5) hipLaunchKernelGGL((k_ebe_mtile<4, true, true, 5>), dim3(count), dim3(320), 0, ls_, T, x, y, d_ch_buf_, part, dot_lo);
+        else if (NWs == 6) hipLaunchKernelGGL((k_ebe_mtile<4, true, true, 6>), dim3(count), dim3(384), 0, ls_, T, x, y, d_ch_buf_, part, dot_lo);
+        else hipLaunchKernelGGL((k_ebe_mtile<4, true, true>), dim3(count), dim3(kChunkThreads), 0, ls_, T, x, y, d_ch_buf_, part, dot_lo);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ls_));
         std::vector<unsigned long long> h(nw * 16);

@@ -955,12 +955,16 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mixed
 //     bits), Ck, six LDS reads, six products, six adds.  The next tile's record is requested a tile ahead.
 // The other types' tiles follow as in k_ebe_mixed (fragments streamed through the register ring).
 // ------------------------------------------------------------------------------------------------
-template <int MTM, bool DOT, bool STAMP = false>
-__global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile(MixTab T, const double *__restrict__ x, double *__restrict__ y,
-                                                                                   double *__restrict__ buf, double *__restrict__ partials,
-                                                                                   long long dot_lo)
+// NW (round 6): waves per workgroup.  A chunk's tiles are dealt to its waves round-robin, so more waves shorten every wave's chain of tiles
+// (the launch lasts as long as ONE chunk where the chunks do not fill the GPU: 661 chunks x 4 waves = 2.6 waves per SIMD at 1 M dof);
+// the tables keep their stride of 768 entries per chunk, thread t stages the entries t, t + 64 NW, ... below 768.  The ORDER of the
+// additions at a node does not depend on NW (colour after colour, then the other types' tiles in ascending order): same y, bit for bit.
+template <int MTM, bool DOT, bool STAMP = false, int NW = kWavesPerBlock>
+__global__ __launch_bounds__(64 * NW, (NW >= 6 ? 5 : (MTM <= 4 ? 4 : 3))) void k_ebe_mtile(MixTab T, const double *__restrict__ x, double *__restrict__ y,
+                                                                                            double *__restrict__ buf, double *__restrict__ partials,
+                                                                                            long long dot_lo)
 {
-    constexpr int NPT = 3, MAXN = kChunkThreads * NPT, JM = (4 * MTM) / 3;
+    constexpr int NT = 64 * NW, MAXN = kChunkThreads * 3, NPT = (MAXN + NT - 1) / NT, JM = (4 * MTM) / 3;
     __shared__ double xs[3 * MAXN];
     __shared__ double ys[3 * MAXN];
     __shared__ int turn;                                         // tiles of this chunk that have completed their adds
@@ -969,7 +973,7 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if ((threadIdx.x & 63) == 0) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + k] = t;
+            if ((threadIdx.x & 63) == 0) T.stamps[((size_t)blockIdx.x * NW + wave) * 16 + k] = t;
         }
     };
     stamp(0);
@@ -992,10 +996,12 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
         int g[NPT];
 #pragma unroll
         for (int j = 0; j < NPT; ++j) {
-            const size_t n = (size_t)b * MAXN + threadIdx.x + j * kChunkThreads;
-            g[j] = ntload(T.nodes + n);
-            dst[j] = ntload(T.dst + n);
-            ts[j] = (int)__builtin_nontemporal_load(T.tslot + n);
+            const int idx = (int)threadIdx.x + j * NT;
+            const bool in = MAXN % NT == 0 || idx < MAXN;          // (NW = 5: the last round of a thread may lie beyond the chunk's 768 entries)
+            const size_t n = (size_t)b * MAXN + (in ? idx : 0);
+            g[j] = in ? ntload(T.nodes + n) : -1;
+            dst[j] = in ? ntload(T.dst + n) : INT_MIN;
+            ts[j] = in ? (int)__builtin_nontemporal_load(T.tslot + n) : 0;
         }
         double xg[NPT][3];
 #pragma unroll
@@ -1024,15 +1030,15 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
     // ---- hex tiles: wave w takes the tiles w, w + 4, ... -----------------------------------------------------------------------
     // (Deferring a tile's adds behind the next tile's matrix instructions was measured and lost, session r: a wave issues in order, its
     //  twelve matrix instructions hold it for their 768 cycles of the pipe, and with four waves per SIMD in this phase the pipe is busy.)
-    for (int t = wave_u; t < n_hex_tiles; t += kWavesPerBlock) { // wave-uniform
+    for (int t = wave_u; t < n_hex_tiles; t += NW) { // wave-uniform
         unsigned long long tt0 = 0, tt1 = 0, tt2 = 0;
         if constexpr (STAMP) tt0 = __builtin_amdgcn_s_memtime();
         const uint2 rec = rec_next;
         const double c = ck_next;
         const int wait_for = T.twait[tile0 + t];                 // (scalar load)
-        if (t + kWavesPerBlock < n_hex_tiles) {
-            rec_next = T.hrec[(tile0 + t + kWavesPerBlock) * 64 + lane];
-            ck_next = T.tck[(tile0 + t + kWavesPerBlock) * 16 + le];
+        if (t + NW < n_hex_tiles) {
+            rec_next = T.hrec[(tile0 + t + NW) * 64 + lane];
+            ck_next = T.tck[(tile0 + t + NW) * 16 + le];
         }
         const int l0 = 3 * (int)(rec.x & 0xffffu), l1 = 3 * (int)(rec.x >> 16);
         const unsigned sw = rec.y;
@@ -1063,13 +1069,13 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
     stamp(8);
     // ---- the other types' tiles: four at a time (one per wave), added in ascending order (k_ebe_mixed) --------------------------------
     int2 info_next = n_hex_tiles + wave_u < n_tiles ? T.tinfo[tile0 + n_hex_tiles + wave_u] : make_int2(0, 0);
-    for (int t0 = n_hex_tiles; t0 < n_tiles; t0 += kWavesPerBlock) { // block-uniform
+    for (int t0 = n_hex_tiles; t0 < n_tiles; t0 += NW) { // block-uniform
         unsigned long long tt0 = 0, tt1 = 0, tt2 = 0;
         if constexpr (STAMP) tt0 = __builtin_amdgcn_s_memtime();
         const int ti = t0 + wave_u;
         const bool have = ti < n_tiles;                          // wave-uniform
         const int2 info = info_next;                             // this tile's header was requested a round ago:
-        if (ti + kWavesPerBlock < n_tiles) info_next = T.tinfo[tile0 + ti + kWavesPerBlock];   // header -> fragments is the dependent chain
+        if (ti + NW < n_tiles) info_next = T.tinfo[tile0 + ti + NW];   // header -> fragments is the dependent chain
         d4m_t acc[MTM];
         int tl3[JM];
         unsigned tsw = 0u;
@@ -1143,16 +1149,22 @@ __global__ __launch_bounds__(kChunkThreads, (MTM <= 4 ? 4 : 3)) void k_ebe_mtile
             }
         }
     if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
-        double v[1] = {dot};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+        __shared__ double lds[NW];
+        const double sw = wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) lds[wave] = sw;
+        __syncthreads();
+        if (threadIdx.x == 0) {                                      // (block_sum's order for NW = 4: wave after wave)
+            double tot = lds[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) tot += lds[w];
+            partials[blockIdx.x] = tot;
+        }
     }
     stamp(11);
     if constexpr (STAMP) {
         if ((threadIdx.x & 63) == 0) {
-            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 12 + k] = tile_acc[4 + k];
-            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * kWavesPerBlock + wave) * 16 + 2 + k] = tile_acc[k];
+            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * NW + wave) * 16 + 12 + k] = tile_acc[4 + k];
+            for (int k = 0; k < 4; ++k) T.stamps[((size_t)blockIdx.x * NW + wave) * 16 + 2 + k] = tile_acc[k];
         }
     }
 }

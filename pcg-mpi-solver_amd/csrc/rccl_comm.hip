@@ -480,6 +480,7 @@ public:
         if (v == 0.0) return false;
         mail_on_ = false;                           // every rank takes this branch together
         mail_why_ = "switched off after a poll timed out on some rank";
+        std::fprintf(stderr, "[pcg] rank %d: a poll of an engine-side wait timed out on some rank - all ranks return to the collective library\n", rank_);
         if (mail_err_) *mail_err_ = 0;
         return true;
     }

