@@ -403,7 +403,7 @@ def main():
     extras_guard = None
     if world > 1 and rank == 0:
         import threading
-        deadline = float(os.environ.get("PCG_BENCH_EXTRAS_DEADLINE_S", "900"))
+        deadline = float(os.environ.get("PCG_BENCH_EXTRAS_DEADLINE_S", "480"))     # (the extras budget is 150 s + the CPU leg; the launcher gives the ranks 900 s)
 
         def bail():
             out["extras"] = f"the optional objects did not finish within {deadline:.0f} s (PCG_BENCH_EXTRAS_DEADLINE_S): headline only, printed by the watchdog; the job was ended"
