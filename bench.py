@@ -141,6 +141,26 @@ def main():
             except Exception as ex:                    # noqa: BLE001
                 native_err = repr(ex)[:300]
                 comm = None
+            if native_err is None and os.environ.get("PCG_BENCH_NO_PROBE") != "1":
+                # First contact (round 6): before the 10 M-dof system is built, ONE small solve of each operator through the native
+                # communicator - exchange, all-reduces, look-ahead, a 2 197-node brick in `world` parts - so that an RCCL call that
+                # raises on this node (a refused send / recv group, a symbol, a stream mode) costs two seconds and ends in the
+                # collective fall-back below instead of in the headline window with nothing printed.
+                try:
+                    pb = Brick(13, seed=0)
+                    pp = make_parts(pb, block_partition(pb, *default_grid(world)), only=[rank])[0]
+                    for kind in ("sell", "ebe"):
+                        pp.pop("_pcg_mi355x_operator", None)
+                        pm.configure(comm=comm, device=dev, operator=kind)
+                        pm.update_bc(pp); pm.update_preconditioner(pp); pm.solve(pp)
+                        info = pp["_pcg_mi355x_info"]
+                        pp.pop("_pcg_mi355x_operator").close()
+                        if info.flag != 0:
+                            raise RuntimeError(f"first-contact probe [{kind}]: flag {info.flag} after {info.iter} iterations")
+                    if rank == 0:
+                        log(f"first-contact probe of the native communicator: ok ({info.iter} iterations on {world} parts)")
+                except Exception as ex:                # noqa: BLE001
+                    native_err = "first-contact probe: " + repr(ex)[:260]
             bad = torch.tensor([0 if native_err is None else 1], dtype=torch.int32, device=torch.device("cpu") if share else torch.device("cuda", dev))
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if int(bad.item()):
@@ -363,15 +383,18 @@ def main():
         if args.workload == "octree":
             out["config"]["format"] += "; rows longer than their slice's base width continue in an overflow part (k_spmv_ovf; roofline.avg_launch_ms covers both launches)"
         out["config"]["spmv_achieved_GBps"] = achieved
-        kname = "k_spmv_dict" if head_kind == "dict" else f"k_spmv<{info['slice_rows'] // 64},true,{'true' if col_bytes == 2 else 'false'}>"
+        # round 6: one apply = L launches of k_spmv (y written at the end of each, kernels_spmv.hpp HOLD): the roofline is quoted per LAUNCH -
+        # bytes / L over apply time / L - so that a profiler's per-kernel average is the same quantity
+        L = op.spmv_launches_per_apply(torch.cuda.get_device_properties(dev).multi_processor_count) if head_kind == "sell" and args.workload == "brick" else 1
+        kname = "k_spmv_dict" if head_kind == "dict" else f"k_spmv<{info['slice_rows'] // 64},true,{'true' if col_bytes == 2 else 'false'}{',false,true' if L > 1 else ''}>"
         out["roofline"] = {
             "bound": "hbm", "kernel": kname + " SELL-BSR3 SpMV + fused p.Ap" + (", this rank's part" if world > 1 else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "bytes_per_launch": sell_bytes,
+            "bytes_per_launch": sell_bytes / L, "launches_per_apply": L, "bytes_per_apply": sell_bytes, "avg_apply_ms": m["op_ms"],
             "bytes_definition": f"stored operator: {72 + col_bytes} B per stored 3x3 block (72 B values + one {8 * col_bytes}-bit column"
                                 + (" offset from the slice's base column" if col_bytes == 2 else "") + ") + x in + y out (16 B/dof) + slice "
                                 "pointers - the algorithmic traffic of the block format (pcg_operator_cost)",
-            "avg_launch_ms": m["op_ms"], "launches_timed": m["n_op"], "traffic": None,
+            "avg_launch_ms": m["op_ms"] / L, "launches_timed": m["n_op"] * L, "traffic": None,
             "hbm_stream_this_box": stream, "frac_of_stream_read": achieved / stream["read_GBps"] if stream else None,
             "csr_equivalent_bytes": alg_bytes, "csr_equivalent_GBps": alg_bytes / t_k / 1e9,
             "csr_equivalent_note": "SURVEY 8(d) formula 12 nnz + 20 n: a scalar-CSR kernel's traffic for the same product; NOT what this "
@@ -476,7 +499,9 @@ def main():
             out["pmc_traffic"] = pmc_live
             live = pmc_live.get(f"{wl}:{head_kind}")
             if live and out.get("roofline"):
-                out["roofline"].update(traffic=live["bytes"], traffic_note=pmc_note(live), traffic_over_bytes=live["bytes"] / out["roofline"]["bytes_per_launch"])
+                Lr = out["roofline"].get("launches_per_apply", 1)          # (the PMC passes sum an apply's launches)
+                out["roofline"].update(traffic=live["bytes"] / Lr, traffic_per_apply=live["bytes"], traffic_note=pmc_note(live),
+                                       traffic_over_bytes=live["bytes"] / Lr / out["roofline"]["bytes_per_launch"])
                 if live.get("vec") and out.get("roofline_vector_phase"):
                     v = out["roofline_vector_phase"]
                     v.update(traffic=live["vec"]["bytes"], traffic_over_bytes=live["vec"]["bytes"] / v["bytes_per_launch"])
@@ -488,7 +513,7 @@ def main():
         try:        # no live passes: the committed passes of an identical launch (profiles/pmc_traffic.json), marked as such in the full record
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"N{N}_rpl{info['slice_rows'] // 64}" + ("_col16" if col_bytes == 2 else ""))
             if pmc:
-                out["roofline"].update(traffic=pmc["traffic_bytes_per_launch"], traffic_over_bytes=pmc["traffic_bytes_per_launch"] / sell_bytes,
+                out["roofline"].update(traffic=pmc["traffic_bytes_per_launch"] / L, traffic_over_bytes=pmc["traffic_bytes_per_launch"] / sell_bytes,
                                        traffic_note="from profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch "
                                                     "(gfx950-corrected), collected on another box in another session - NOT a measurement of this run")
         except OSError:

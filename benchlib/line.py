@@ -44,7 +44,8 @@ def compact(full: dict) -> dict:
     out["config"] = {"workload": _short(cfg.get("workload", ""), 160), **_pick(cfg, ("dofs", "nnz", "parts", "operator"))}
     rf = full.get("roofline")
     if isinstance(rf, dict):
-        r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "launches_timed", "traffic_over_bytes"))
+        r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "launches_timed", "traffic_over_bytes",
+                       "launches_per_apply", "avg_apply_ms"))
         r["kernel"] = _short(rf.get("kernel", ""), 60)
         sc = rf.get("scalar_csr_same_run")
         if isinstance(sc, dict):                                # SURVEY 8(d)'s literal CSR kernel at the same size: 12 nnz + 20 n bytes over ITS time

@@ -49,7 +49,7 @@ def pmc_child(args):
 
 
 PMC_OPERATOR_KERNELS = {"sell": ("k_spmv",), "dict": ("k_spmv_dict",), "ebe": ("k_ebe",)}      # substrings of the kernels of one operator apply
-PMC_PRIMARY = {"sell": ("k_spmv<", "k_spmv_win<"), "dict": ("k_spmv_dict<",), "ebe": ("k_ebe_hexs<", "k_ebe_hex<", "k_ebe_mixed<", "k_ebe_mtile<")}   # one launch per apply
+PMC_PRIMARY = {"sell": ("k_spmv<", "k_spmv_win<"), "dict": ("k_spmv_dict<",), "ebe": ("k_ebe_hexs<", "k_ebe_hex<", "k_ebe_mixed<", "k_ebe_mtile<")}   # the launch(es) that make an apply
 
 
 def pmc_traffic_live(args, segments):
@@ -89,6 +89,9 @@ def pmc_traffic_live(args, segments):
         kind = seg.split(":")[1]
         res = {"kernels": {}}
         applies = sum(1 for name, _ in raw["FETCH_SIZE"][i] if any(p in name for p in PMC_PRIMARY[kind]))
+        n_vec = sum(1 for name, _ in raw["FETCH_SIZE"][i] if "k_vec<true" in name)
+        if n_vec > 0:
+            applies = n_vec            # one fused vector launch per iteration = per apply (round 6: an apply of k_spmv may be several launches)
         tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
         vec = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -143,6 +143,10 @@ class HipBackend : public Backend {
         return (int)(g < 8 ? 8 : g);
     }
     int spmv_blocks_per_cu_ = 4;
+    // y stores at the end of a launch (round 6): slices a wave may hold per launch, 1 .. kSpmvHold; 0 = off (PCG_SPMV_HOLD)
+    int spmv_hold_ = getenv("PCG_SPMV_HOLD") ? std::max(0, std::min(kSpmvHold, atoi(getenv("PCG_SPMV_HOLD")))) : kSpmvHold;
+    bool spmv_hold_split_ = !(getenv("PCG_SPMV_HOLD_SPLIT") && atoi(getenv("PCG_SPMV_HOLD_SPLIT")) == 0);   // 0: one launch, a wave flushes whenever its slots are full
+    int spmv_launches_ = 1;           // launches of the last k_spmv apply (HOLD cuts the slice range)
     int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
     bool bench_dot_ = false;
     // Non-temporal accesses in the vector kernels (PCG_VEC_NT, bit mask; A/B: tools/vec_nt_ab.py re-reads it per solve).
@@ -1088,6 +1092,25 @@ public:
     void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
         const PackArgs pk{d_fptr_, d_fpos_, pack_send_};
+        if (RPL == 1 && spmv_hold_ && !(pack_send_ && !dot)) {
+            // round 6 (kernels_spmv.hpp HOLD): y is written at the END of a launch, from LDS; the slices go in as many launches as a
+            // wave's share needs slots (10 M dof: 13 slices per wave -> 4 launches of 4 slots).  PCG_SPMV_HOLD=0: one launch, stores as they come.
+            const int64_t waves = (int64_t)grid * kWavesPerBlock, per_wave = (hi - lo + waves - 1) / waves;
+            const int parts = spmv_hold_split_ ? (int)std::max<int64_t>(1, (per_wave + spmv_hold_ - 1) / spmv_hold_) : 1;
+            for (int q = 0; q < parts; ++q) {
+                const int64_t a = lo + (hi - lo) * q / parts, b = lo + (hi - lo) * (q + 1) / parts;
+                const int flags = xcd_aware_ | (vec_nt_ & 2) | (q > 0 ? 32 : 0);
+                if (dot)
+                    hipLaunchKernelGGL((k_spmv<1, true, COL16, false, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                                       x, y, d_flags_, d_part_spmv_, a, b, n_nodes_, flags, d_ov_mask_, pk);
+                else
+                    hipLaunchKernelGGL((k_spmv<1, false, COL16, false, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
+                                       x, y, d_flags_, d_part_spmv_, a, b, n_nodes_, flags, d_ov_mask_, pk);
+            }
+            spmv_launches_ = parts;
+            return;
+        }
+        spmv_launches_ = 1;
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
                                x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);

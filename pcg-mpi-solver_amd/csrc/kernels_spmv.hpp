@@ -18,7 +18,18 @@ namespace pcg {
 // neighbours' contributions arrive at in the receive buffer, pcg_set_halo).  Rows that continue in an overflow part pack there.
 struct PackArgs { const int *fptr, *fpos; double *send; };
 
-template <int RPL, bool DOT, bool COL16, bool PACK = false>
+// HOLD (round 6): a wave keeps the y of the slices it computes in LDS (kSpmvHold slices of 192 doubles per wave) and writes them at the
+// END of the launch, as coalesced 16-B stores; the launcher cuts the slice range into launches a wave's share of which fits the slots.
+// Why: 81 MB of y stores trickling into a 6.9 GB read stream cost up to 13 % of the launch - and HOW MUCH depends on the box (the spread
+// of rounds 1 - 5: 1.03 ... 1.20 ms for the same launch).  tools/micro/spmv_ablation rebuilds the kernel piece by piece: values + columns
+// + x gathers + multiply-adds run at 1.040 ms on EVERY box; adding the stores gives 1.05 ms on a fast box and 1.19 - 1.24 ms on a slow
+// one, whatever their width or cache policy (coalesced, nt, sc1: 1.13 - 1.17 ms); the same stores issued after the reads of a quarter of
+// the slices - four launches, launch overheads included - give 1.053 ms (profiles/r06_spmv_ablation_*).  Reads and writes in separate
+// phases are what the slow boxes' memory system wants.  Same values at the same addresses: y bit-identical.
+// (xcd_aware bit 5: this launch ADDS its block's dot partial to the one a previous launch of the same apply left there.)
+constexpr int kSpmvHold = 4;
+
+template <int RPL, bool DOT, bool COL16, bool PACK = false, bool HOLD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ slice_ptr, const void *__restrict__ cols_any,
                                                  const int *__restrict__ colbase,
                                                  const double *__restrict__ vals, const double *__restrict__ x,
@@ -44,6 +55,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
     const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
     const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
     double dot = 0.0;
+    __shared__ double held[HOLD ? kWavesPerBlock * kSpmvHold * 192 : 1];
+    int n_held = 0;
+    int64_t held_s[kSpmvHold];
+    auto flush_held = [&]() {                                  // the held slices' 192 doubles each as 16-B pairs, lanes 0..63 then 0..31
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes (a wave reads only its own slots)
+#pragma unroll
+        for (int q = 0; q < kSpmvHold; ++q)
+            if (q < n_held) {
+                const double *st = held + ((size_t)wid * kSpmvHold + q) * 192;
+                double *yb = y + 3 * held_s[q] * 64;
+                const int64_t rows_left = n_nodes - held_s[q] * 64;              // (the matrix's last slice may be partial)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int e = 128 * t + 2 * lane;
+                    if (e < 192) {
+                        if ((e + 1) / 3 < rows_left) *reinterpret_cast<v2d_t *>(yb + e) = *reinterpret_cast<const v2d_t *>(st + e);
+                        else if (e / 3 < rows_left) yb[e] = st[e];
+                    }
+                }
+            }
+        n_held = 0;
+    };
     for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
         const int64_t base = slice_ptr[s];
         const int w = (int)(slice_ptr[s + 1] - base);
@@ -86,7 +119,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
             const int64_t row = s * C + (int64_t)lane * RPL + h;
             if (row < n_nodes) {
                 double *yp = y + 3 * row;
-                if (xcd_aware & 2) {
+                if (HOLD && RPL == 1) {                                      // kept in LDS, written when the slots are full / after the loop
+                    double *st = held + ((size_t)wid * kSpmvHold + n_held) * 192 + 3 * lane;
+                    st[0] = acc[h][0]; st[1] = acc[h][1]; st[2] = acc[h][2];
+                } else if (xcd_aware & 2) {
                     __builtin_nontemporal_store(acc[h][0], yp); __builtin_nontemporal_store(acc[h][1], yp + 1);
                     __builtin_nontemporal_store(acc[h][2], yp + 2);
                 } else { yp[0] = acc[h][0]; yp[1] = acc[h][1]; yp[2] = acc[h][2]; }
@@ -108,12 +144,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                 }
             }
         }
+        if constexpr (HOLD && RPL == 1) {
+            held_s[n_held++] = s;
+            if (n_held == kSpmvHold) flush_held();               // (a launch cut to the slots never gets here before its last slice)
+        }
     }
+    if constexpr (HOLD && RPL == 1) flush_held();                // every read of this launch has been issued: now the stores
     if constexpr (DOT) {
         __shared__ double lds[kWavesPerBlock];
         double v[1] = {dot};
         block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+        if (threadIdx.x == 0) partials[blockIdx.x] = (xcd_aware & 32) ? partials[blockIdx.x] + v[0] : v[0];
     }
 }
 
