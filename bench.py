@@ -385,12 +385,13 @@ def main():
         out["config"]["spmv_achieved_GBps"] = achieved
         # round 6: one apply = L launches of k_spmv (y written at the end of each, kernels_spmv.hpp HOLD): the roofline is quoted per LAUNCH -
         # bytes / L over apply time / L - so that a profiler's per-kernel average is the same quantity
-        L = op.spmv_launches_per_apply(torch.cuda.get_device_properties(dev).multi_processor_count) if head_kind == "sell" and args.workload == "brick" else 1
+        tuning = op.tuning_info()                       # (decided by the engine at the first solve: measured, same bits either way)
+        L = tuning["spmv_launches_per_apply"] if head_kind == "sell" and args.workload == "brick" else 1
         kname = "k_spmv_dict" if head_kind == "dict" else f"k_spmv<{info['slice_rows'] // 64},true,{'true' if col_bytes == 2 else 'false'}{',false,true' if L > 1 else ''}>"
         out["roofline"] = {
             "bound": "hbm", "kernel": kname + " SELL-BSR3 SpMV + fused p.Ap" + (", this rank's part" if world > 1 else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "bytes_per_launch": sell_bytes / L, "launches_per_apply": L, "bytes_per_apply": sell_bytes, "avg_apply_ms": m["op_ms"],
+            "bytes_per_launch": sell_bytes / L, "launches_per_apply": L, "bytes_per_apply": sell_bytes, "avg_apply_ms": m["op_ms"], "tuning": tuning,
             "bytes_definition": f"stored operator: {72 + col_bytes} B per stored 3x3 block (72 B values + one {8 * col_bytes}-bit column"
                                 + (" offset from the slice's base column" if col_bytes == 2 else "") + ") + x in + y out (16 B/dof) + slice "
                                 "pointers - the algorithmic traffic of the block format (pcg_operator_cost)",

@@ -51,8 +51,9 @@ typedef struct pcg_asm pcg_asm;
  * hooks of a part without neighbours unconditionally - since 3 only with collective_exchange != 0);
  * 4 = pcg_abi_version(), pcg_result.fused_fallbacks (round 4);
  * 5 = pcg_comm_enable_mailbox(), pcg_group_enable_mailbox() (round 5; no struct changed);
- * 6 = pcg_enable_direct_exchange(), pcg_group_enable_direct_exchange(), pcg_create_ebe flags bit 2 (round 5; no struct changed). */
-#define PCG_ABI_VERSION 6
+ * 6 = pcg_enable_direct_exchange(), pcg_group_enable_direct_exchange(), pcg_create_ebe flags bit 2 (round 5; no struct changed);
+ * 7 = pcg_tuning_info() (round 6; read-only, no struct changed). */
+#define PCG_ABI_VERSION 7
 int pcg_abi_version(void);
 const char *pcg_last_error(void);
 const char *pcg_backend_name(void);          /* "hip-gfx950" for the product library */
@@ -333,6 +334,12 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
  * creation when the environment has PCG_MATRIX_FINGERPRINT (0 otherwise): lets tests assert that two construction paths
  * produce the same operator. */
 int pcg_matrix_fingerprint(pcg_engine *e, uint64_t *out);
+/* What the engine decided by MEASUREMENT at its first solve (round 6; assembled operators of >= 1 M dof, nothing below):
+ * spmv_launches_per_apply: launches of the SpMV kernel one apply makes - 1, or the slice range in several launches that write their y
+ * at their end (csrc/kernels_spmv.hpp HOLD; same bits; PCG_SPMV_HOLD=0 / 4 forces a form) - measurement code quotes per-LAUNCH bytes and
+ * times next to a profiler's per-kernel average; vectors_placed: 1 when the roles of the solve's vectors were handed out by timing the
+ * SpMV on every candidate buffer (PCG_VEC_PLACEMENT=0 switches that off).  Either pointer may be NULL.  Before the first solve: 1 and 0. */
+int pcg_tuning_info(pcg_engine *e, int32_t *spmv_launches_per_apply, int32_t *vectors_placed);
 /* n_unique: distinct blocks of the value dictionary (0 = plain values); n_in_lds (may be NULL): how many of them - the most
  * frequent ones - the SpMV kernel keeps in LDS; lds_share (may be NULL): the share of the stored blocks those cover. */
 int pcg_matrix_dictionary(pcg_engine *e, int64_t *n_unique, int64_t *n_in_lds, double *lds_share);

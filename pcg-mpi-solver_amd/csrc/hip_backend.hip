@@ -143,10 +143,12 @@ class HipBackend : public Backend {
         return (int)(g < 8 ? 8 : g);
     }
     int spmv_blocks_per_cu_ = 4;
-    // y stores at the end of a launch (round 6): slices a wave may hold per launch, 1 .. kSpmvHold; 0 = off (PCG_SPMV_HOLD)
-    int spmv_hold_ = getenv("PCG_SPMV_HOLD") ? std::max(0, std::min(kSpmvHold, atoi(getenv("PCG_SPMV_HOLD")))) : kSpmvHold;
-    bool spmv_hold_split_ = !(getenv("PCG_SPMV_HOLD_SPLIT") && atoi(getenv("PCG_SPMV_HOLD_SPLIT")) == 0);   // 0: one launch, a wave flushes whenever its slots are full
-    int spmv_launches_ = 1;           // launches of the last k_spmv apply (HOLD cuts the slice range)
+    // k_spmv in `parts` launches that write their y at their end (round 6, kernels_spmv.hpp HOLD) or in one launch: the same bits; which is
+    // faster depends on the box and on where the vectors landed, so tune_operator() times both on the solve's own vectors.
+    // PCG_SPMV_HOLD=0 / 4 forces one form (and switches the timing off).
+    bool spmv_split_ = getenv("PCG_SPMV_HOLD") ? atoi(getenv("PCG_SPMV_HOLD")) != 0 : false;
+    bool spmv_split_forced_ = getenv("PCG_SPMV_HOLD") != nullptr;
+    int spmv_launches_ = 1;           // launches of the last k_spmv apply
     int xcd_aware_ = 0;        // A/B on MI355X (profiles/r01_tune_spmv.json): plain round-robin 1.156 ms vs XCD-partitioned 1.185 ms
     bool bench_dot_ = false;
     // Non-temporal accesses in the vector kernels (PCG_VEC_NT, bit mask; A/B: tools/vec_nt_ab.py re-reads it per solve).
@@ -1092,34 +1094,37 @@ public:
     void launch_spmv_c(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int grid, const void *cols)
     {
         const PackArgs pk{d_fptr_, d_fpos_, pack_send_};
-        if (RPL == 1 && spmv_hold_ && !(pack_send_ && !dot)) {
-            // round 6 (kernels_spmv.hpp HOLD): y is written at the END of a launch, from LDS; the slices go in as many launches as a
-            // wave's share needs slots (10 M dof: 13 slices per wave -> 4 launches of 4 slots).  PCG_SPMV_HOLD=0: one launch, stores as they come.
+        const int fl = xcd_aware_ | (vec_nt_ & 2);
+        // Sub-ranges (kernels_spmv.hpp HOLD): the slice range is walked in `parts` pieces a wave's share of which fits the kernel's LDS slots -
+        // in ONE launch (part = -1: stores as they come) or in `parts` launches that write their y at their end (spmv_split_); the same
+        // bits either way.  Interface rows with the pack epilogue and 128-row slices: one piece.
+        int parts = 1;
+        if (RPL == 1 && !(pack_send_ && !dot)) {
             const int64_t waves = (int64_t)grid * kWavesPerBlock, per_wave = (hi - lo + waves - 1) / waves;
-            const int parts = spmv_hold_split_ ? (int)std::max<int64_t>(1, (per_wave + spmv_hold_ - 1) / spmv_hold_) : 1;
+            parts = (int)std::max<int64_t>(1, (per_wave + kSpmvHold - 1) / kSpmvHold);
+        }
+        spmv_launches_ = 1;
+        if (RPL == 1 && parts > 1 && spmv_split_) {
             for (int q = 0; q < parts; ++q) {
-                const int64_t a = lo + (hi - lo) * q / parts, b = lo + (hi - lo) * (q + 1) / parts;
-                const int flags = xcd_aware_ | (vec_nt_ & 2) | (q > 0 ? 32 : 0);
                 if (dot)
                     hipLaunchKernelGGL((k_spmv<1, true, COL16, false, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                                       x, y, d_flags_, d_part_spmv_, a, b, n_nodes_, flags, d_ov_mask_, pk);
+                                       x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, fl, d_ov_mask_, pk, parts, q);
                 else
                     hipLaunchKernelGGL((k_spmv<1, false, COL16, false, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                                       x, y, d_flags_, d_part_spmv_, a, b, n_nodes_, flags, d_ov_mask_, pk);
+                                       x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, fl, d_ov_mask_, pk, parts, q);
             }
             spmv_launches_ = parts;
             return;
         }
-        spmv_launches_ = 1;
         if (dot)
             hipLaunchKernelGGL((k_spmv<RPL, true, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, fl, d_ov_mask_, pk, parts, -1);
         else if (pack_send_ && RPL == 1)
             hipLaunchKernelGGL((k_spmv<1, false, COL16, true>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, fl, d_ov_mask_, pk, parts, -1);
         else
             hipLaunchKernelGGL((k_spmv<RPL, false, COL16>), dim3(grid), dim3(kBlock), 0, st_, d_slice_ptr_, cols, d_colbase_, d_vals_,
-                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, xcd_aware_ | (vec_nt_ & 2), d_ov_mask_, pk);
+                               x, y, d_flags_, d_part_spmv_, lo, hi, n_nodes_, fl, d_ov_mask_, pk, parts, -1);
     }
     // overflow part of a split matrix (k_spmv_ovf) for the base slices [lo, hi): its partials follow those of the base launch
     int launch_overflow(const double *x, double *y, int64_t lo, int64_t hi, bool dot, int part_off)
@@ -1502,6 +1507,32 @@ public:
         HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
         release(a); if (b) release(b); release(out);
         return 0;
+    }
+    int operator_launches_per_apply() const override
+    {
+        if (ebe_ || C_ != 64 || n_windows_ > 0 || d_bidx_ || !spmv_split_) return 1;
+        const int grid = spmv_grid(n_slices_);
+        const int64_t waves = (int64_t)grid * kWavesPerBlock, per_wave = (n_slices_ + waves - 1) / waves;
+        return (int)std::max<int64_t>(1, (per_wave + kSpmvHold - 1) / kSpmvHold);
+    }
+    int tune_operator(const double *x, double *y) override
+    {
+        if (ebe_ || C_ != 64 || n_windows_ > 0 || d_bidx_ || spmv_split_forced_) return operator_launches_per_apply();
+        spmv_split_ = true;
+        const int parts = operator_launches_per_apply();
+        spmv_split_ = false;
+        if (parts <= 1) return 1;
+        float ms[4];
+        double t[2];
+        for (int form = 0; form < 2; ++form) {               // 0: one launch, 1: `parts` launches with their y at the end
+            spmv_split_ = form == 1;
+            bench_spmv(x, y, 1, 4, ms);
+            t[form] = std::min(std::min(ms[0], ms[1]), std::min(ms[2], ms[3]));
+        }
+        spmv_split_ = t[1] < 0.99 * t[0];                     // (the launches' own cost: only a clear win)
+        if (getenv("PCG_VEC_PLACEMENT_LOG"))
+            fprintf(stderr, "[pcg] k_spmv: one launch %.4f ms, %d launches with y at their end %.4f ms -> %s\n", t[0], parts, t[1], spmv_split_ ? "split" : "one launch");
+        return operator_launches_per_apply();
     }
     int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) override
     {

@@ -20,13 +20,17 @@ struct PackArgs { const int *fptr, *fpos; double *send; };
 
 // HOLD (round 6): a wave keeps the y of the slices it computes in LDS (kSpmvHold slices of 192 doubles per wave) and writes them at the
 // END of the launch, as coalesced 16-B stores; the launcher cuts the slice range into launches a wave's share of which fits the slots.
-// Why: 81 MB of y stores trickling into a 6.9 GB read stream cost up to 13 % of the launch - and HOW MUCH depends on the box (the spread
-// of rounds 1 - 5: 1.03 ... 1.20 ms for the same launch).  tools/micro/spmv_ablation rebuilds the kernel piece by piece: values + columns
-// + x gathers + multiply-adds run at 1.040 ms on EVERY box; adding the stores gives 1.05 ms on a fast box and 1.19 - 1.24 ms on a slow
-// one, whatever their width or cache policy (coalesced, nt, sc1: 1.13 - 1.17 ms); the same stores issued after the reads of a quarter of
-// the slices - four launches, launch overheads included - give 1.053 ms (profiles/r06_spmv_ablation_*).  Reads and writes in separate
-// phases are what the slow boxes' memory system wants.  Same values at the same addresses: y bit-identical.
-// (xcd_aware bit 5: this launch ADDS its block's dot partial to the one a previous launch of the same apply left there.)
+// Why: 81 MB of y stores trickling into a 6.9 GB read stream can cost up to 13 % of the launch - how much depends on the box and on where
+// the vectors landed (the spread of rounds 1 - 5: 1.03 ... 1.20 ms for the same launch).  tools/micro/spmv_ablation rebuilds the kernel
+// piece by piece: values + columns + x gathers + multiply-adds run at 1.040 ms on EVERY box; the stores add 0.01 ms on a fast box and
+// 0.15 - 0.20 ms on a slow one whatever their width or cache policy (coalesced, nt, sc1: still + 0.10 - 0.13); the same stores issued after
+// the reads of a quarter of the slices - four launches, launch overheads included - give 1.053 ms (profiles/r06_spmv_ablation_*).  On a
+// slow box reads and writes in separate phases win 5 - 11 %; on a fast one the three extra launches cost 2 - 4 %: the engine TIMES both forms
+// on its own vectors at the first solve and keeps the faster (Backend::tune_operator, PCG_SPMV_HOLD=0 / 4 forces one).
+//
+// Both forms produce the SAME BITS - y and the dot partials - because both walk the slice range in the same `parts` sub-ranges with the
+// same slice -> wave assignment inside each: part = q (0 <= q < parts): this launch is sub-range q alone (HOLD: its y from LDS at the end;
+// its block partial is added to the one launch q - 1 left); part = -1: one launch walks all sub-ranges, block partial = ((v0 + v1) + ...).
 constexpr int kSpmvHold = 4;
 
 template <int RPL, bool DOT, bool COL16, bool PACK = false, bool HOLD = false>
@@ -34,28 +38,22 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
                                                  const int *__restrict__ colbase,
                                                  const double *__restrict__ vals, const double *__restrict__ x,
                                                  double *__restrict__ y, const uint8_t *__restrict__ flags,
-                                                 double *__restrict__ partials, int64_t slice_lo, int64_t slice_hi,
+                                                 double *__restrict__ partials, int64_t slice_lo_all, int64_t slice_hi_all,
                                                  int64_t n_nodes, int xcd_aware, const unsigned long long *__restrict__ ov_mask,
-                                                 PackArgs pk)
+                                                 PackArgs pk, int parts, int part)
 {
     constexpr int C = 64 * RPL;
     using DV = typename VecT<RPL>::d;
     using IV = typename VecT<RPL>::i;
     using CV = typename std::conditional<COL16, typename std::conditional<RPL == 1, unsigned short, ushort2>::type, IV>::type;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // Slice -> wave mapping.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
-    // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
-    // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
-    const int64_t S = slice_hi - slice_lo;
     const bool xa = (xcd_aware & 1) != 0;                    // bit 1 of the argument: non-temporal y stores
     const int xcd = xa ? (blockIdx.x & 7) : 0;
     const int64_t lb = xa ? (blockIdx.x >> 3) : blockIdx.x;
     const int64_t blocks_per_xcd = xa ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;   // blocks with b&7 == xcd
-    const int64_t c_lo = xa ? slice_lo + (S * xcd) / 8 : slice_lo;
-    const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
     const int64_t wstride = blocks_per_xcd * kWavesPerBlock;
-    double dot = 0.0;
     __shared__ double held[HOLD ? kWavesPerBlock * kSpmvHold * 192 : 1];
+    __shared__ double lds[kWavesPerBlock];
     int n_held = 0;
     int64_t held_s[kSpmvHold];
     auto flush_held = [&]() {                                  // the held slices' 192 doubles each as 16-B pairs, lanes 0..63 then 0..31
@@ -77,6 +75,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
             }
         n_held = 0;
     };
+    double total = 0.0;                                          // thread 0: this block's dot partial over the sub-ranges of this launch
+    const int sub_lo = part >= 0 ? part : 0, sub_hi = part >= 0 ? part + 1 : parts;
+    for (int sub = sub_lo; sub < sub_hi; ++sub) {
+    // Slice -> wave mapping inside a sub-range.  Default (xcd_aware = 0): wave g of the grid takes slices g, g + G, ... so the
+    // whole chip streams one region of the matrix.  xcd_aware = 1: block b runs on XCD b & 7 (observed;
+    // speed only, never correctness) and each XCD owns one contiguous eighth of the slice range.
+    const int64_t slice_lo = slice_lo_all + (slice_hi_all - slice_lo_all) * sub / parts;
+    const int64_t slice_hi = slice_lo_all + (slice_hi_all - slice_lo_all) * (sub + 1) / parts;
+    const int64_t S = slice_hi - slice_lo;
+    const int64_t c_lo = xa ? slice_lo + (S * xcd) / 8 : slice_lo;
+    const int64_t c_hi = xa ? slice_lo + (S * (xcd + 1)) / 8 : slice_hi;
+    double dot = 0.0;
     for (int64_t s = c_lo + lb * kWavesPerBlock + wid; s < c_hi; s += wstride) {
         const int64_t base = slice_ptr[s];
         const int w = (int)(slice_ptr[s + 1] - base);
@@ -149,12 +159,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int64_t *__restrict__ sli
             if (n_held == kSpmvHold) flush_held();               // (a launch cut to the slots never gets here before its last slice)
         }
     }
-    if constexpr (HOLD && RPL == 1) flush_held();                // every read of this launch has been issued: now the stores
     if constexpr (DOT) {
-        __shared__ double lds[kWavesPerBlock];
         double v[1] = {dot};
         block_sum<1>(v, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = (xcd_aware & 32) ? partials[blockIdx.x] + v[0] : v[0];
+        if (threadIdx.x == 0) total = sub == sub_lo ? v[0] : total + v[0];
+        if (sub + 1 < sub_hi) __syncthreads();                         // (the next sub-range's block_sum reuses lds)
+    }
+    }
+    if constexpr (HOLD && RPL == 1) flush_held();                // every read of this launch has been issued: now the stores
+    if constexpr (DOT) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = part > 0 ? partials[blockIdx.x] + total : total;
     }
 }
 

@@ -15,6 +15,8 @@
 //     host sees them in the one status read-back per iteration;
 //   * XMin (:555-558) is tracked by rotating three x buffers instead of copying.
 #include <algorithm>
+#include <cstdio>
+#include <numeric>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -71,6 +73,7 @@ struct pcg_engine {
     // direct exchange (round 5, opt-in pcg_enable_direct_exchange; pcg_internal.hpp DirectDesc): this engine's peer-mapped receive
     // buffer.  Used by the applies of the ITERATION only (the all-reduce behind every one of them is what orders a neighbour's next
     // write behind this rank's reads); set-up applies and the true-residual branch stay on ncclSend / ncclRecv.
+    bool vectors_placed = false;          // the roles of the solve's vectors were handed out by measurement (ensure_solver_buffers)
     std::unique_ptr<DirectLink> direct;
     bool ebe_one_phase = false;           // matrix-free engine built without an interface-first phase (pcg_create_ebe flags bit 2)
     bool multi() const { return comm != nullptr || has_hooks; }
@@ -373,13 +376,70 @@ struct pcg_engine {
 
 namespace {
 
+// The eleven vectors of a solve.  Round 6: for a large ASSEMBLED operator the ROLES are handed out by measurement.  The same k_spmv launch
+// on the same matrix takes 1.03 ms or 1.19 ms depending on WHICH buffers hold x and y (one process, one box, two operator instances:
+// profiles/r06_sessionK3_*: in the loop 1.037 / 1.192 ms, stand-alone on the scratch vectors 1.02 ms both) - where a 81 MB vector lands
+// physically decides how its traffic collides with the 6.9 GB value stream, and nothing the engine can ask the allocator for controls
+// that.  So the engine allocates a few buffers more than it needs, times one apply with each of them as y (x fixed) and then as x (y = the
+// best), gives q the best y and the ring of search directions the three best x, and frees the rest.  On a box whose default placement
+// was a bad one: 1.2015 -> 1.0365 ms per launch in the loop (profiles/r06_sessionK9_*: y candidates 1.016 ... 1.204 ms).  ~0.15 s at the
+// first solve of an engine (>= 1 M dof, assembled); addresses only, no value changes.  PCG_VEC_PLACEMENT=0: roles in allocation order.
 void ensure_solver_buffers(pcg_engine *e)
 {
     if (e->v_b) return;
-    e->v_b = e->vec(); e->v_q = e->vec();
-    for (int k = 0; k < 2; ++k) e->v_r[k] = e->vec();
-    for (int k = 0; k < 3; ++k) e->v_p[k] = e->vec();
-    for (int k = 0; k < 4; ++k) e->v_x[k] = e->vec();
+    constexpr int kRoles = 11, kExtra = 5;
+    const char *env = std::getenv("PCG_VEC_PLACEMENT");
+    const bool tune = e->kind == 0 && e->n >= 1000000 && !(env && std::atoi(env) == 0);
+    std::vector<double *> c;
+    for (int k = 0; k < kRoles + (tune ? kExtra : 0); ++k) c.push_back(e->vec());
+    if (tune) {
+        Backend &be = *e->be;
+        const size_t bytes = sizeof(double) * (size_t)e->n;
+        {                                                   // a pseudo-random operand (not zeros: data-dependent power), the same in every candidate
+            std::vector<double> h((size_t)e->n);
+            uint64_t sd = 0x9E3779B97F4A7C15ull;
+            for (auto &v : h) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5; }
+            be.h2d(c[0], h.data(), bytes);
+            for (size_t k = 1; k < c.size(); ++k) be.d2d(c[k], c[0], bytes);
+            be.sync();
+        }
+        auto time_apply = [&](const double *x, double *y) {
+            float ms[3];
+            be.bench_spmv(x, y, 1, 3, ms);
+            return (double)std::min(ms[0], std::min(ms[1], ms[2]));
+        };
+        std::vector<double> ty(c.size(), 1e30), tx(c.size(), 1e30);
+        for (size_t k = 1; k < c.size(); ++k) ty[k] = time_apply(c[0], c[k]);
+        const size_t iy = (size_t)(std::min_element(ty.begin(), ty.end()) - ty.begin());
+        for (size_t k = 0; k < c.size(); ++k)
+            if (k != iy) tx[k] = time_apply(c[k], c[iy]);
+        std::vector<size_t> order(c.size());
+        std::iota(order.begin(), order.end(), (size_t)0);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tx[a] < tx[b]; });      // (iy sorts last: tx = 1e30)
+        std::vector<double *> picked = {c[iy], c[order[0]], c[order[1]], c[order[2]]};
+        const double worst_y = *std::max_element(ty.begin() + 1, ty.end());
+        if (std::getenv("PCG_VEC_PLACEMENT_LOG"))
+            std::fprintf(stderr, "[pcg] vector placement: y %.4f ms (worst candidate %.4f), x %.4f / %.4f / %.4f ms (worst %.4f)\n", ty[iy], worst_y,
+                         tx[order[0]], tx[order[1]], tx[order[2]], tx[order[c.size() - 2]]);
+        std::vector<double *> rest;
+        for (size_t k = 3; k + 1 < order.size(); ++k) rest.push_back(c[order[k]]);
+        for (size_t k = 0; k < rest.size(); ++k)
+            if ((int)k < kRoles - 4) picked.push_back(rest[k]); else be.release(rest[k]);
+        c.swap(picked);                                     // q, p ring, then b, r, r, x, x, x, x
+        (void)be.tune_operator(c[1], c[0]);                 // one launch, or several that write their y at their end: same bits, the faster one
+        for (auto *v : c) be.zero(v, bytes);
+        e->v_q = c[0];
+        for (int k = 0; k < 3; ++k) e->v_p[k] = c[1 + k];
+        e->v_b = c[4];
+        for (int k = 0; k < 2; ++k) e->v_r[k] = c[5 + k];
+        for (int k = 0; k < 4; ++k) e->v_x[k] = c[7 + k];
+        e->vectors_placed = true;
+        return;
+    }
+    e->v_b = c[0]; e->v_q = c[1];
+    for (int k = 0; k < 2; ++k) e->v_r[k] = c[2 + k];
+    for (int k = 0; k < 3; ++k) e->v_p[k] = c[4 + k];
+    for (int k = 0; k < 4; ++k) e->v_x[k] = c[7 + k];
 }
 
 // One pass of the reference's `for i in range(MaxIter)` body (:438-562).  Returns true when the
@@ -1338,6 +1398,14 @@ int pcg_matrix_info(pcg_engine *e, int64_t *nnzb, int64_t *stored_blocks, int64_
 }
 
 // ---- single-kernel entry points for the per-kernel parity tests ----------------------------------
+int pcg_tuning_info(pcg_engine *e, int32_t *spmv_launches_per_apply, int32_t *vectors_placed)
+{
+    if (!e) return set_error("pcg_tuning_info: null");
+    if (spmv_launches_per_apply) *spmv_launches_per_apply = e->be ? e->be->operator_launches_per_apply() : 1;
+    if (vectors_placed) *vectors_placed = e->vectors_placed ? 1 : 0;
+    return 0;
+}
+
 int pcg_matrix_fingerprint(pcg_engine *e, uint64_t *out)
 {
     if (!e || !out) return set_error("pcg_matrix_fingerprint: null");

@@ -443,6 +443,10 @@ public:
     virtual void collect_profile(double *ms_sum, int64_t *count) = 0;
     virtual void collect_profile_vec(double *ms_sum, int64_t *count) { *ms_sum = 0; *count = 0; }   // the vec_update launches
     virtual int bench_spmv(const double *x, double *y, int warmup, int reps, float *ms_each) = 0;
+    // Round 6: choose, by timing a few applies on the vectors a solve will use, between forms of the operator that produce the same bits
+    // (HIP: k_spmv in one launch or in several that write their y at their end).  -> launches per apply of the form kept.
+    virtual int tune_operator(const double *x, double *y) { (void)x; (void)y; return 1; }
+    virtual int operator_launches_per_apply() const { return 1; }
     // stream microbenchmark over `bytes` of device memory: mode 0 read-only, 1 copy (read + write); ms per repetition
     virtual int bench_hbm(size_t bytes, int mode, int reps, float *ms_each) = 0;
 };

@@ -53,7 +53,7 @@ class CommStats(C.Structure):
                 ("n_allreduce", C.c_int64), ("n_halo_timed", C.c_int64), ("n_allreduce_timed", C.c_int64)]
 
 
-ABI_VERSION = 6            # include/pcg_mi355x.h PCG_ABI_VERSION: the struct layouts above belong to this version
+ABI_VERSION = 7            # include/pcg_mi355x.h PCG_ABI_VERSION: the struct layouts above belong to this version
 RCCL_ID_BYTES = 256
 FORMAT_DICTIONARY = 0x100
 
@@ -124,6 +124,7 @@ _SIGS = {
     "pcg_operator_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcg_matrix_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "pcg_matrix_fingerprint": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "pcg_tuning_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pcg_matrix_dictionary": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pcg_k_update_p": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32]),
     "pcg_k_fused_update": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P, _P]),

@@ -360,23 +360,11 @@ class Operator:
         check(self._L.pcg_operator_cost(self._h, C.byref(b), C.byref(f)), "pcg_operator_cost")
         return b.value, f.value
 
-    def spmv_launches_per_apply(self, n_cu=256):
-        """How many launches of `k_spmv` one apply of a plain (64-row slices, unsplit or base part) assembled operator makes - the mirror
-        of csrc/hip_backend.hip launch_spmv_c (round 6: y is written at the END of a launch from LDS, kSpmvHold = 4 slices per wave, so
-        the slice range goes in ceil(slices per wave / 4) launches; PCG_SPMV_HOLD=0: 1).  For measurement code (bench.py) that quotes
-        per-LAUNCH bytes and times next to a profiler's per-kernel average."""
-        import os
-        hold = os.environ.get("PCG_SPMV_HOLD")
-        hold = 4 if hold is None else max(0, min(4, int(hold)))
-        info = self.matrix_info()
-        if hold == 0 or info["slice_rows"] != 64 or os.environ.get("PCG_SPMV_HOLD_SPLIT") == "0":
-            return 1
-        s = info["n_slices"]
-        per_cu = int(os.environ.get("PCG_SPMV_BLOCKS_PER_CU", "4"))
-        g = min((s + 3) // 4, n_cu * per_cu, 4096)
-        g = max(8, (g + 7) // 8 * 8)
-        per_wave = (s + 4 * g - 1) // (4 * g)
-        return max(1, (per_wave + hold - 1) // hold)
+    def tuning_info(self):
+        """{"spmv_launches_per_apply", "vectors_placed"}: what the engine decided by measurement at its first solve (pcg_tuning_info, ABI 7)."""
+        a, b = C.c_int32(1), C.c_int32(0)
+        check(self._L.pcg_tuning_info(self._h, C.byref(a), C.byref(b)), "pcg_tuning_info")
+        return {"spmv_launches_per_apply": int(a.value), "vectors_placed": bool(b.value)}
 
     def matrix_dictionary(self):
         """Distinct 3x3 blocks of the value dictionary (PCG_FORMAT_DICTIONARY); 0 = plain values."""

@@ -881,3 +881,44 @@ def test_nccl_hooks_world_size_1(gpu_lib, tmp_path):
     assert int(o["n_allreduce"]) > 200
     check_solution_against_golden(g, int(o["flag"]), int(o["iter"]), float(o["relres"]), o["Un"], o["history"])
     assert bool(o["a2a_ok"])            # the halo collective (async all_to_all_single on pointer views, engine stream) on RCCL
+
+
+def test_spmv_forms_and_vector_placement_leave_every_bit_alone(gpu_lib, monkeypatch, capfd):
+    """Round 6: two things the engine now decides by MEASUREMENT at the first solve of an assembled operator of >= 1 M dof -
+    (1) which of its buffers play q and the ring of search directions (the same k_spmv launch runs at 1.02 or 1.20 ms depending on where
+    its y landed physically: ensure_solver_buffers times every candidate), (2) whether k_spmv runs as one launch or as several that write
+    their y at their end from LDS (kernels_spmv.hpp HOLD) - must not change a bit: both forms walk the slice range in the same sub-ranges
+    with the same slice -> wave assignment, and buffers are addresses.  Brick N = 102 (3.18 M dof: 16 582 slices, 5 per wave -> 2 sub-ranges),
+    60 iterations: residual history, iterate and flag identical between one launch / split / auto, placement on / off."""
+    import copy
+    import pcg_mi355x as pm
+    b = Brick(102, seed=3)
+    part = make_parts(b)[0]
+    part["GlobData"]["MaxIter"] = 60
+    out = {}
+    monkeypatch.setenv("PCG_VEC_PLACEMENT_LOG", "1")
+    for tag, hold, place in (("one launch", "0", "0"), ("split", "4", "0"), ("split, placed", "4", "1"), ("auto", None, None)):
+        for k, v in (("PCG_SPMV_HOLD", hold), ("PCG_VEC_PLACEMENT", place)):
+            if v is None: monkeypatch.delenv(k, raising=False)
+            else: monkeypatch.setenv(k, v)
+        P = copy.deepcopy(part)
+        pm.configure(comm=None, device=0, operator="sell")
+        try:
+            pm.update_bc(P); pm.update_preconditioner(P); pm.solve(P, history=True)
+            info = P["_pcg_mi355x_info"]
+            tun = P["_pcg_mi355x_operator"].tuning_info()
+            out[tag] = (info.flag, info.iter, info.relres, info.history.copy(), P["Un"].copy(), tun)
+        finally:
+            op = P.pop("_pcg_mi355x_operator", None)
+            if op is not None: op.close()
+            pm.configure()
+    err = capfd.readouterr().err
+    assert out["one launch"][5] == {"spmv_launches_per_apply": 1, "vectors_placed": False}
+    assert out["split"][5] == {"spmv_launches_per_apply": 2, "vectors_placed": False}
+    assert out["split, placed"][5]["vectors_placed"] and out["auto"][5]["vectors_placed"]
+    assert "vector placement: y" in err and "k_spmv: one launch" in err, err[-1500:]      # (the auto run timed both forms)
+    ref = out["one launch"]
+    assert ref[0] == 1 and len(ref[3]) == 60
+    for tag, o in out.items():
+        assert o[:3] == ref[:3], tag
+        assert np.array_equal(o[3], ref[3]) and np.array_equal(o[4], ref[4]), tag
