@@ -151,6 +151,7 @@ def main():
                     pp = make_parts(pb, block_partition(pb, *default_grid(world)), only=[rank])[0]
                     for kind in ("sell", "ebe"):
                         pp.pop("_pcg_mi355x_operator", None)
+                        pp["Un"] = np.zeros(pp["NDOF"])                  # (not the warm start the first operator's solution would be)
                         pm.configure(comm=comm, device=dev, operator=kind)
                         pm.update_bc(pp); pm.update_preconditioner(pp); pm.solve(pp)
                         info = pp["_pcg_mi355x_info"]
