@@ -388,7 +388,7 @@ def main():
         # bytes / L over apply time / L - so that a profiler's per-kernel average is the same quantity
         tuning = op.tuning_info()                       # (decided by the engine at the first solve: measured, same bits either way)
         L = tuning["spmv_launches_per_apply"] if head_kind == "sell" and args.workload == "brick" else 1
-        kname = "k_spmv_dict" if head_kind == "dict" else f"k_spmv<{info['slice_rows'] // 64},true,{'true' if col_bytes == 2 else 'false'}{',false,true' if L > 1 else ''}>"
+        kname = "k_spmv_dict" if head_kind == "dict" else f"k_spmv<{info['slice_rows'] // 64},true,{'true' if col_bytes == 2 else 'false'},false,{'true' if L > 1 else 'false'}>"
         out["roofline"] = {
             "bound": "hbm", "kernel": kname + " SELL-BSR3 SpMV + fused p.Ap" + (", this rank's part" if world > 1 else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
