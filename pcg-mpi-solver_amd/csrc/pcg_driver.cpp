@@ -380,16 +380,16 @@ namespace {
 // on the same matrix takes 1.03 ms or 1.19 ms depending on WHICH buffers hold x and y (one process, one box, two operator instances:
 // profiles/r06_sessionK3_*: in the loop 1.037 / 1.192 ms, stand-alone on the scratch vectors 1.02 ms both) - where a 81 MB vector lands
 // physically decides how its traffic collides with the 6.9 GB value stream, and nothing the engine can ask the allocator for controls
-// that.  So the engine allocates a few buffers more than it needs, times one apply with each of them as y (x fixed) and then as x (y = the
-// best), gives q the best y and the ring of search directions the three best x, and frees the rest.  On a box whose default placement
-// was a bad one: 1.2015 -> 1.0365 ms per launch in the loop (profiles/r06_sessionK9_*: y candidates 1.016 ... 1.204 ms).  ~0.15 s at the
-// first solve of an engine (>= 1 M dof, assembled); addresses only, no value changes.  PCG_VEC_PLACEMENT=0: roles in allocation order.
+// that.  So the engine allocates a few buffers more than it needs, times one apply with each of them as y, gives q the best, the rings
+// the next ones, and gives the worst back.  On a box whose default placement was a bad one: 1.2015 -> 1.0365 ms per launch in the loop
+// (profiles/r06_sessionK9_*: y candidates 1.016 ... 1.204 ms).  ~0.1 s at the first solve of an engine (>= 1 M dof); addresses only, no
+// value changes.  PCG_VEC_PLACEMENT=0: roles in allocation order.
 void ensure_solver_buffers(pcg_engine *e)
 {
     if (e->v_b) return;
     constexpr int kRoles = 11, kExtra = 5;
     const char *env = std::getenv("PCG_VEC_PLACEMENT");
-    const bool tune = e->kind == 0 && e->n >= 1000000 && !(env && std::atoi(env) == 0);
+    const bool tune = e->kind == 0 && e->n >= 1000000 && !(env && std::atoi(env) == 0);      // (matrix-free: measured, no effect - r06_sessionP*)
     std::vector<double *> c;
     for (int k = 0; k < kRoles + (tune ? kExtra : 0); ++k) c.push_back(e->vec());
     if (tune) {
@@ -408,31 +408,33 @@ void ensure_solver_buffers(pcg_engine *e)
             be.bench_spmv(x, y, 1, 3, ms);
             return (double)std::min(ms[0], std::min(ms[1], ms[2]));
         };
-        std::vector<double> ty(c.size(), 1e30), tx(c.size(), 1e30);
+        // Only WRITES care where a buffer lives (reads: every candidate within 1 %; writes: 1.02 ... 1.20 ms, MEASUREMENTS_r06.md section 6g), and
+        // every vector of a solve but b is written by some launch (q by the operator; r', x', p' by k_vec, rotating through their rings): so the
+        // candidates are ranked ONCE, as the operator's y, the best becomes q, the next ones the rings, b takes the worst one kept, and the
+        // kExtra worst are given back.
+        std::vector<double> ty(c.size(), 1e30);
         for (size_t k = 1; k < c.size(); ++k) ty[k] = time_apply(c[0], c[k]);
-        const size_t iy = (size_t)(std::min_element(ty.begin(), ty.end()) - ty.begin());
-        for (size_t k = 0; k < c.size(); ++k)
-            if (k != iy) tx[k] = time_apply(c[k], c[iy]);
+        {                                                   // (candidate 0 was x so far: time it as y against the best of the others)
+            const size_t ib = (size_t)(std::min_element(ty.begin() + 1, ty.end()) - ty.begin());
+            ty[0] = time_apply(c[ib], c[0]);
+        }
         std::vector<size_t> order(c.size());
         std::iota(order.begin(), order.end(), (size_t)0);
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tx[a] < tx[b]; });      // (iy sorts last: tx = 1e30)
-        std::vector<double *> picked = {c[iy], c[order[0]], c[order[1]], c[order[2]]};
-        const double worst_y = *std::max_element(ty.begin() + 1, ty.end());
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ty[a] < ty[b]; });
         if (std::getenv("PCG_VEC_PLACEMENT_LOG"))
-            std::fprintf(stderr, "[pcg] vector placement: y %.4f ms (worst candidate %.4f), x %.4f / %.4f / %.4f ms (worst %.4f)\n", ty[iy], worst_y,
-                         tx[order[0]], tx[order[1]], tx[order[2]], tx[order[c.size() - 2]]);
-        std::vector<double *> rest;
-        for (size_t k = 3; k + 1 < order.size(); ++k) rest.push_back(c[order[k]]);
-        for (size_t k = 0; k < rest.size(); ++k)
-            if ((int)k < kRoles - 4) picked.push_back(rest[k]); else be.release(rest[k]);
-        c.swap(picked);                                     // q, p ring, then b, r, r, x, x, x, x
+            std::fprintf(stderr, "[pcg] vector placement: %zu candidates as y: best %.4f ms, kept up to %.4f ms, given back %.4f ... %.4f ms\n", c.size(), ty[order[0]],
+                         ty[order[kRoles - 1]], ty[order[kRoles]], ty[order[c.size() - 1]]);
+        std::vector<double *> picked;
+        for (int k = 0; k < kRoles; ++k) picked.push_back(c[order[(size_t)k]]);
+        for (size_t k = kRoles; k < order.size(); ++k) be.release(c[order[k]]);
+        c.swap(picked);                                     // q, p ring, r, r, x, x, x, x, b  (best to worst)
         (void)be.tune_operator(c[1], c[0]);                 // one launch, or several that write their y at their end: same bits, the faster one
         for (auto *v : c) be.zero(v, bytes);
         e->v_q = c[0];
         for (int k = 0; k < 3; ++k) e->v_p[k] = c[1 + k];
-        e->v_b = c[4];
-        for (int k = 0; k < 2; ++k) e->v_r[k] = c[5 + k];
-        for (int k = 0; k < 4; ++k) e->v_x[k] = c[7 + k];
+        for (int k = 0; k < 2; ++k) e->v_r[k] = c[4 + k];
+        for (int k = 0; k < 4; ++k) e->v_x[k] = c[6 + k];
+        e->v_b = c[10];
         e->vectors_placed = true;
         return;
     }
