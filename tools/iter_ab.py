@@ -19,7 +19,7 @@ kinds = sys.argv[2].split(",")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 switches = [a.split("=", 1) for a in sys.argv[4:]] or [["PCG_VEC_FUSED", "1|0"]]
 out = []
-CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT", "PCG_EBE_GREEDY_CHUNKS", "PCG_EBE_STREAMS", "PCG_EBE_ROWS_LDS", "PCG_EBE_DIRECT", "PCG_EBE_XCD", "PCG_SPMV_XCD", "PCG_SELL_SPLIT", "PCG_EBE_MIXED", "PCG_NODE_ORDER", "PCG_SPMV_OVF", "PCG_EBE_MIX_FLAGS", "PCG_EBE_TILE_CAP", "PCG_EBE_HEX_CAP", "PCG_EBE_HEX_FLAGS", "PCG_SPMV_OVF_WINDOW", "PCG_EBE_NODE_CAP", "PCG_EBE_MIX_SHELLS", "PCG_EBE_MIX_MTM", "PCG_EBE_HEX_TILES", "PCG_EBE_TARGET_CHUNKS", "PCG_EBE_MTILE_WAVES", "PCG_SPMV_HOLD", "PCG_VEC_PLACEMENT")   # read when the operator is built
+CREATE = ("PCG_LOOK_AHEAD", "PCG_SPMV_COL16", "PCG_SPMV_DICT_LDS", "PCG_SPMV_DICT_BLOCK", "PCG_EBE_EPT", "PCG_EBE_GREEDY_CHUNKS", "PCG_EBE_STREAMS", "PCG_EBE_ROWS_LDS", "PCG_EBE_DIRECT", "PCG_EBE_XCD", "PCG_SPMV_XCD", "PCG_SELL_SPLIT", "PCG_EBE_MIXED", "PCG_NODE_ORDER", "PCG_SPMV_OVF", "PCG_EBE_MIX_FLAGS", "PCG_EBE_TILE_CAP", "PCG_EBE_HEX_CAP", "PCG_EBE_HEX_FLAGS", "PCG_SPMV_OVF_WINDOW", "PCG_EBE_NODE_CAP", "PCG_EBE_MIX_SHELLS", "PCG_EBE_MIX_MTM", "PCG_EBE_HEX_TILES", "PCG_EBE_TARGET_CHUNKS", "PCG_EBE_MTILE_WAVES", "PCG_SPMV_HOLD", "PCG_VEC_PLACEMENT", "PCG_SPMV_PLACEMENTS")   # read when the operator is built
 create = [sw for sw in switches if sw[0].split("+")[0] in CREATE] or [["_", "-"]]      # A+B=a1+b1|a2+b2: several variables switched together
 switches = [sw for sw in switches if sw[0].split("+")[0] not in CREATE] or [["_", "-"]]
 for N in Ns:
