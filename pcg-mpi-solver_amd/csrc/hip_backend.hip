@@ -1510,14 +1510,14 @@ public:
     }
     int operator_launches_per_apply() const override
     {
-        if (ebe_ || C_ != 64 || n_windows_ > 0 || d_bidx_ || !spmv_split_) return 1;
+        if (ebe_ || bs_ != 3 || C_ != 64 || n_windows_ > 0 || d_bidx_ || !spmv_split_) return 1;
         const int grid = spmv_grid(n_slices_);
         const int64_t waves = (int64_t)grid * kWavesPerBlock, per_wave = (n_slices_ + waves - 1) / waves;
         return (int)std::max<int64_t>(1, (per_wave + kSpmvHold - 1) / kSpmvHold);
     }
     int tune_operator(const double *x, double *y) override
     {
-        if (ebe_ || C_ != 64 || n_windows_ > 0 || d_bidx_ || spmv_split_forced_) return operator_launches_per_apply();
+        if (ebe_ || bs_ != 3 || C_ != 64 || n_windows_ > 0 || d_bidx_ || spmv_split_forced_) return operator_launches_per_apply();
         spmv_split_ = true;
         const int parts = operator_launches_per_apply();
         spmv_split_ = false;

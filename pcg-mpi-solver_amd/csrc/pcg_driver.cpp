@@ -1355,6 +1355,7 @@ int pcg_bench_spmv(pcg_engine *e, int32_t warmup, int32_t reps, float *ms_each)
     return guarded("pcg_bench_spmv", e, [&]() -> int {
         // (round 6: where y lives decides 1.02 or 1.20 ms for the same launch; once a solve has placed the engine's vectors by timing, the
         //  stand-alone launch uses those - between solves nothing else needs them - so that it measures what the loop runs)
+        if (!e->s.active) ensure_solver_buffers(e);          // (an engine that never solved - a scalar copy - gets its vectors placed here)
         const bool placed = e->vectors_placed && !e->s.active;
         double *dx = placed ? e->v_p[0] : e->scratch(0), *dy = placed ? e->v_q : e->scratch(1);
         std::vector<double> hx((size_t)e->n);
